@@ -1,0 +1,419 @@
+/*
+ * env2048_oracle.c -- CPU ORACLE for the batched 2048 environment step.
+ *
+ * THIS FILE IS TEST INFRASTRUCTURE, NOT PRODUCT.  It is a scalar, reference-shaped
+ * restatement of the algorithm in the reference's NumPy engine
+ * (/root/reference/twentyfortyeight/core/gameboard.py, gamemove.py) in the packed
+ * log2 domain used by the HIP path.  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load it; simulate_2048_amd/ never does.
+ *
+ * Parity pin: the functions below are checked (tests/test_oracle_golden.py, -m "not gpu")
+ * against fixtures under tests/golden/ that oracle/gen_golden.py produced by importing the
+ * reference NumPy engine in the build container, and against the known-answer vectors of
+ * the reference's own tests.  The Philox4x32-10 generator is pinned by
+ * the Random123 known-answer vectors.
+ *
+ * Board layout (build contract): 16 bytes, byte i = 4*row + col,
+ * value e: 0 = empty, e >= 1 means tile 2^e.
+ *
+ * Every function cites the reference lines it follows as  [ref: file:lines].
+ */
+#include <stdint.h>
+#include <stddef.h>
+#include <string.h>
+
+#define ORACLE_API __attribute__((visibility("default")))
+
+#define FLAG_AUTO_RESET 1u
+#define FLAG_RANDOM_ACTIONS 2u
+
+/* ------------------------------------------------------------------------------------ */
+/* Philox4x32-10 (Salmon et al., SC'11; Random123).  Build-defined RNG contract.        */
+/* ------------------------------------------------------------------------------------ */
+#define PHILOX_M0 0xD2511F53u
+#define PHILOX_M1 0xCD9E8D57u
+#define PHILOX_W0 0x9E3779B9u
+#define PHILOX_W1 0xBB67AE85u
+/* P(tile 4) = 0.1  [ref: gameboard.py:13,16-17]  ->  r < floor(0.1 * 2^32) */
+#define SPAWN4_THRESHOLD 429496729u
+
+ORACLE_API void oracle_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+    uint32_t k0 = key[0], k1 = key[1];
+    for (int round = 0; round < 10; ++round) {
+        uint64_t p0 = (uint64_t)PHILOX_M0 * c0;
+        uint64_t p1 = (uint64_t)PHILOX_M1 * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += PHILOX_W0;
+        k1 += PHILOX_W1;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* Counter scheme (DESIGN.md "RNG contract"): key = seed, counter = (env_lo, step_lo, step_hi,
+ * stream + 2*env_hi); stream 0 = step block, stream 1 = reset block. */
+static void env_block(uint64_t seed, uint64_t env, uint64_t step, uint32_t stream, uint32_t out[4])
+{
+    uint32_t ctr[4] = { (uint32_t)env, (uint32_t)step, (uint32_t)(step >> 32),
+                        stream + 2u * (uint32_t)(env >> 32) };
+    uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
+    oracle_philox4x32_10(ctr, key, out);
+}
+
+ORACLE_API void oracle_env_block(uint64_t seed, uint64_t env, uint64_t step, uint32_t stream, uint32_t out[4])
+{
+    env_block(seed, env, step, stream, out);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Deterministic engine                                                                  */
+/* ------------------------------------------------------------------------------------ */
+
+/* [ref: gameboard.py:23-69 merge_column]  Drop zeros, merge equal neighbours left to right,
+ * each tile merging at most once; score = sum of merged VALUES (2^(e+1)).  Returns the
+ * unpadded result length through *out_len, like the reference's variable-length array. */
+ORACLE_API int64_t oracle_merge_column(const uint8_t column[4], uint8_t out[4], int *out_len)
+{
+    uint8_t non_zero[4];
+    int n = 0;
+    for (int i = 0; i < 4; ++i)
+        if (column[i] != 0) non_zero[n++] = column[i];          /* :46 column[column != 0] */
+    if (n <= 1) {                                                /* :47-48 */
+        for (int i = 0; i < n; ++i) out[i] = non_zero[i];
+        *out_len = n;
+        return 0;
+    }
+    int64_t score = 0;
+    int m = 0;
+    int i = 0;
+    while (i < n - 1) {                                          /* :56 */
+        if (non_zero[i] == non_zero[i + 1]) {                    /* :57 */
+            uint8_t merged = (uint8_t)(non_zero[i] + 1);         /* value*2 == exponent+1 */
+            out[m++] = merged;
+            score += (int64_t)1 << merged;                       /* :60 score += merged */
+            i += 2;
+        } else {
+            out[m++] = non_zero[i];
+            i += 1;
+        }
+    }
+    if (i == n - 1) out[m++] = non_zero[n - 1];                  /* :66-67 */
+    *out_len = m;
+    return score;
+}
+
+/* [ref: gameboard.py:72-102 slide_and_merge]  merge_column on every row, left-padded into zeros. */
+ORACLE_API int64_t oracle_slide_and_merge(const uint8_t board[16], uint8_t out[16])
+{
+    int64_t score = 0;
+    memset(out, 0, 16);                                          /* :94 zeros_like */
+    for (int r = 0; r < 4; ++r) {                                /* :97 */
+        uint8_t merged[4];
+        int len = 0;
+        score += oracle_merge_column(board + 4 * r, merged, &len);
+        for (int c = 0; c < len; ++c) out[4 * r + c] = merged[c]; /* :100 */
+    }
+    return score;
+}
+
+/* numpy.rot90(m, k) for a 4x4 array: k counter-clockwise quarter turns, k taken mod 4
+ * (negative k allowed), as used at gameboard.py:127,129,316,320. */
+ORACLE_API void oracle_rot90(const uint8_t in[16], int k, uint8_t out[16])
+{
+    uint8_t cur[16], nxt[16];
+    memcpy(cur, in, 16);
+    k = ((k % 4) + 4) % 4;
+    for (int t = 0; t < k; ++t) {
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j)
+                nxt[4 * i + j] = cur[4 * j + (3 - i)];           /* one CCW turn */
+        memcpy(cur, nxt, 16);
+    }
+    memcpy(out, cur, 16);
+}
+
+/* [ref: gameboard.py:105-129 latent_state]  rot90(k=action) -> slide_and_merge -> rot90(k=-action).
+ * No spawn, no validity check. */
+ORACLE_API int64_t oracle_latent_state(const uint8_t board[16], int action, uint8_t out[16])
+{
+    uint8_t rotated[16], updated[16];
+    oracle_rot90(board, action, rotated);                        /* :127 */
+    int64_t reward = oracle_slide_and_merge(rotated, updated);   /* :128 */
+    oracle_rot90(updated, -action, out);                         /* :129 */
+    return reward;
+}
+
+/* [ref: gamemove.py:132-164 can_move]  "would a left move change this board". */
+ORACLE_API int oracle_can_move(const uint8_t board[16])
+{
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 3; ++c) {
+            uint8_t left = board[4 * r + c], right = board[4 * r + c + 1];
+            if (left == 0 && right != 0) return 1;               /* :158-160 can_slide */
+            if (left != 0 && left == right) return 1;            /* :163-164 can_merge */
+        }
+    return 0;
+}
+
+/* [ref: gamemove.py:45-83 legal_actions_mask]  bit a set <=> action a legal
+ * (0 left, 1 up, 2 right, 3 down), from horizontal / vertical adjacency without rotation. */
+ORACLE_API uint8_t oracle_legal_actions_mask(const uint8_t board[16])
+{
+    int h_merge = 0, v_merge = 0, left = 0, right = 0, up = 0, down = 0;
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 3; ++c) {
+            uint8_t l = board[4 * r + c], rr = board[4 * r + c + 1];
+            if (l != 0 && l == rr) h_merge = 1;                  /* :64-65 */
+            if (l == 0 && rr != 0) left = 1;                     /* :72 */
+            if (rr == 0 && l != 0) right = 1;                    /* :73 */
+        }
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 4; ++c) {
+            uint8_t t = board[4 * r + c], b = board[4 * (r + 1) + c];
+            if (t != 0 && t == b) v_merge = 1;                   /* :68-69 */
+            if (t == 0 && b != 0) up = 1;                        /* :74 */
+            if (b == 0 && t != 0) down = 1;                      /* :75 */
+        }
+    return (uint8_t)(((left | h_merge) << 0) | ((up | v_merge) << 1) |
+                     ((right | h_merge) << 2) | ((down | v_merge) << 3)); /* :77-82 */
+}
+
+/* [ref: gameboard.py:328-348 is_done]  all cells non-zero, no equal vertical neighbours,
+ * no equal horizontal neighbours.  (The all-zero board is NOT done here -- NumPy semantics,
+ * SURVEY.md App. A.5.) */
+ORACLE_API int oracle_is_done(const uint8_t board[16])
+{
+    for (int i = 0; i < 16; ++i)
+        if (board[i] == 0) return 0;                             /* np_all(state != 0) */
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 4; ++c)
+            if (board[4 * r + c] == board[4 * (r + 1) + c]) return 0; /* state[:-1] == state[1:] */
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 3; ++c)
+            if (board[4 * r + c] == board[4 * r + c + 1]) return 0;   /* state[:, :-1] == state[:, 1:] */
+    return 1;
+}
+
+ORACLE_API int oracle_count_empty(const uint8_t board[16])           /* [ref: reinforce/game/core.py:445-460] */
+{
+    int n = 0;
+    for (int i = 0; i < 16; ++i) n += (board[i] == 0);
+    return n;
+}
+
+ORACLE_API int oracle_max_exponent(const uint8_t board[16])          /* [ref: reinforce/game/core.py:427-442] log2 of max_tile */
+{
+    int m = 0;
+    for (int i = 0; i < 16; ++i) if (board[i] > m) m = board[i];
+    return m;
+}
+
+/* Place exponent e in the k-th empty cell, cells enumerated row-major exactly like
+ * argwhere(state == 0) [ref: gameboard.py:275,287; after_state_lazy :200-202;
+ * reinforce/game/core.py:206-213 cumsum/argmax].  Returns the flat index, or -1 if k is out
+ * of range (board unchanged) -- the full-board case of gameboard.py:277-278. */
+ORACLE_API int oracle_fill_cell_kv(uint8_t board[16], int k, uint8_t e)
+{
+    int seen = 0;
+    for (int i = 0; i < 16; ++i) {
+        if (board[i] == 0) {
+            if (seen == k) { board[i] = e; return i; }
+            ++seen;
+        }
+    }
+    return -1;
+}
+
+/* Build contract for turning two Philox words into a spawn:
+ * k = floor(r_cell * n_empty / 2^32), exponent 2 iff r_val < SPAWN4_THRESHOLD else 1. */
+static inline int spawn_rank(uint32_t r_cell, int n_empty)
+{
+    return (int)(((uint64_t)r_cell * (uint64_t)n_empty) >> 32);
+}
+static inline uint8_t spawn_exponent(uint32_t r_val)
+{
+    return (r_val < SPAWN4_THRESHOLD) ? 2 : 1;
+}
+
+ORACLE_API void oracle_spawn_from_words(uint32_t r_cell, uint32_t r_val, int n_empty, int *k, int *e)
+{
+    *k = spawn_rank(r_cell, n_empty);
+    *e = spawn_exponent(r_val);
+}
+
+/* Fresh board: two sequential single spawns on the empty board
+ * [ref: twentyfortyeight.py:100-101 zeros + fill_cells(2); reinforce/game/core.py:339-342],
+ * drawn from ONE stream-1 block: (r0,r1) among 16 empties, (r2,r3) among the remaining 15. */
+ORACLE_API void oracle_reset_board(uint64_t seed, uint64_t env, uint64_t step, uint8_t board[16])
+{
+    uint32_t r[4];
+    env_block(seed, env, step, 1u, r);
+    memset(board, 0, 16);
+    oracle_fill_cell_kv(board, spawn_rank(r[0], 16), spawn_exponent(r[1]));
+    oracle_fill_cell_kv(board, spawn_rank(r[2], 15), spawn_exponent(r[3]));
+}
+
+/* [ref: gameboard.py:291-325 next_state + twentyfortyeight.py:132-133 step;
+ *  reinforce/game/env.py:103-119 step]  One transition of one board, in place.
+ *  rotated = rot90(state,k=action); if can_move(rotated): slide, un-rotate, spawn ONE tile,
+ *  reward = score; else: board unchanged, reward 0, no spawn.  done = is_done(new board).
+ *  With FLAG_AUTO_RESET a terminal board is replaced by a fresh one (done still reports 1).
+ *  action is taken mod 4, as rot90 does (gameboard.py:316). */
+static int64_t step_one(uint8_t board[16], int action, uint64_t seed, uint64_t env, uint64_t step,
+                        uint32_t flags, const uint32_t blk[4], int *done_out, int *changed_out)
+{
+    uint8_t rotated[16];
+    int64_t reward = 0;
+    int changed = 0;
+    action &= 3;
+    oracle_rot90(board, action, rotated);                        /* :316 */
+    if (oracle_can_move(rotated)) {                              /* :317 */
+        uint8_t updated[16];
+        reward = oracle_slide_and_merge(rotated, updated);       /* :319 */
+        oracle_rot90(updated, -action, board);                   /* :320 */
+        int n_empty = oracle_count_empty(board);
+        oracle_fill_cell_kv(board, spawn_rank(blk[0], n_empty), spawn_exponent(blk[1])); /* :323 */
+        changed = 1;
+    }                                                            /* :325 else: state, 0 */
+    int done = oracle_is_done(board);                            /* twentyfortyeight.py:133 */
+    if (done && (flags & FLAG_AUTO_RESET))
+        oracle_reset_board(seed, env, step, board);
+    *done_out = done;
+    if (changed_out) *changed_out = changed;
+    return reward;
+}
+
+/* [ref: reinforce/game/core.py:346-377 encode_observation]  log2(tile)/16, 0 for empty. */
+static void encode_obs(const uint8_t board[16], float obs[16])
+{
+    for (int i = 0; i < 16; ++i) obs[i] = (float)board[i] * 0.0625f;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Batched drivers: same argument meaning as include/env2048.h                           */
+/* ------------------------------------------------------------------------------------ */
+
+ORACLE_API int oracle_step_batch(uint64_t n, uint64_t env_base, uint8_t *boards, const uint8_t *actions,
+                                 int32_t *reward, uint8_t *done, uint8_t *legal, float *obs,
+                                 uint64_t seed, uint64_t step_index, uint32_t flags, int threads)
+{
+    (void)threads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(threads > 0 ? threads : 1)
+#endif
+    for (int64_t i = 0; i < (int64_t)n; ++i) {
+        uint8_t *b = boards + 16 * (size_t)i;
+        uint32_t blk[4];
+        env_block(seed, env_base + (uint64_t)i, step_index, 0u, blk);
+        int action = (flags & FLAG_RANDOM_ACTIONS) ? (int)(blk[2] & 3u) : (int)actions[i];
+        int d = 0;
+        int64_t r = step_one(b, action, seed, env_base + (uint64_t)i, step_index, flags, blk, &d, NULL);
+        if (reward) reward[i] = (int32_t)r;
+        if (done) done[i] = (uint8_t)d;
+        if (legal) legal[i] = oracle_legal_actions_mask(b);
+        if (obs) encode_obs(b, obs + 16 * (size_t)i);
+    }
+    return 0;
+}
+
+ORACLE_API int oracle_reset_batch(uint64_t n, uint64_t env_base, uint8_t *boards, uint8_t *done,
+                                  uint64_t seed, uint64_t step_index, int threads)
+{
+    (void)threads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(threads > 0 ? threads : 1)
+#endif
+    for (int64_t i = 0; i < (int64_t)n; ++i) {
+        oracle_reset_board(seed, env_base + (uint64_t)i, step_index, boards + 16 * (size_t)i);
+        if (done) done[i] = 0;
+    }
+    return 0;
+}
+
+/* T consecutive steps with on-device-style random actions (r2 & 3 of each step block). */
+ORACLE_API int oracle_rollout_batch(uint64_t n, uint64_t env_base, uint8_t *boards, uint64_t seed,
+                                    uint64_t step0, uint32_t T, int64_t *return_sum, uint32_t *episodes,
+                                    uint32_t *valid_moves, uint32_t flags, int threads)
+{
+    (void)threads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(threads > 0 ? threads : 1)
+#endif
+    for (int64_t i = 0; i < (int64_t)n; ++i) {
+        uint8_t *b = boards + 16 * (size_t)i;
+        int64_t ret = 0;
+        uint32_t eps = 0, moves = 0;
+        for (uint32_t t = 0; t < T; ++t) {
+            uint32_t blk[4];
+            uint64_t step = step0 + t;
+            env_block(seed, env_base + (uint64_t)i, step, 0u, blk);
+            int d = 0, ch = 0;
+            ret += step_one(b, (int)(blk[2] & 3u), seed, env_base + (uint64_t)i, step, flags, blk, &d, &ch);
+            eps += (uint32_t)d;
+            moves += (uint32_t)ch;
+        }
+        if (return_sum) return_sum[i] = ret;
+        if (episodes) episodes[i] = eps;
+        if (valid_moves) valid_moves[i] = moves;
+    }
+    return 0;
+}
+
+/* Afterstate only [ref: gameboard.py:105-129 latent_state; reinforce/game/core.py:129-170]:
+ * out = slide/merge of in under action; reward = score (NOT zeroed for invalid moves: an
+ * invalid move merges nothing, so it is 0 anyway); changed = (out != in)
+ * [ref: reinforce/game/core.py:258]. */
+ORACLE_API int oracle_afterstate_batch(uint64_t n, const uint8_t *boards_in, const uint8_t *actions,
+                                       uint8_t *boards_out, int32_t *reward, uint8_t *changed)
+{
+    for (uint64_t i = 0; i < n; ++i) {
+        uint8_t out[16];
+        int64_t r = oracle_latent_state(boards_in + 16 * i, actions[i] & 3, out);
+        if (changed) changed[i] = (uint8_t)(memcmp(out, boards_in + 16 * i, 16) != 0);
+        if (reward) reward[i] = (int32_t)r;
+        memcpy(boards_out + 16 * i, out, 16);
+    }
+    return 0;
+}
+
+/* Injected spawn [ref: gameboard.py:174-244 after_state_lazy + generate_outcome]:
+ * place exponent spawn_e[i] at the spawn_k[i]-th empty cell (row-major). placed[i] = flat
+ * index or 0xFF when k is out of range (board unchanged). */
+ORACLE_API int oracle_spawn_batch(uint64_t n, uint8_t *boards, const uint8_t *spawn_k,
+                                  const uint8_t *spawn_e, uint8_t *placed)
+{
+    for (uint64_t i = 0; i < n; ++i) {
+        int idx = oracle_fill_cell_kv(boards + 16 * i, spawn_k[i], spawn_e[i]);
+        if (placed) placed[i] = (uint8_t)(idx < 0 ? 0xFF : idx);
+    }
+    return 0;
+}
+
+/* Board status: done / legal bitmask / f32 obs / max exponent / empty count. */
+ORACLE_API int oracle_status_batch(uint64_t n, const uint8_t *boards, uint8_t *done, uint8_t *legal,
+                                   float *obs, uint8_t *max_exp, uint8_t *n_empty)
+{
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint8_t *b = boards + 16 * i;
+        if (done) done[i] = (uint8_t)oracle_is_done(b);
+        if (legal) legal[i] = oracle_legal_actions_mask(b);
+        if (obs) encode_obs(b, obs + 16 * i);
+        if (max_exp) max_exp[i] = (uint8_t)oracle_max_exponent(b);
+        if (n_empty) n_empty[i] = (uint8_t)oracle_count_empty(b);
+    }
+    return 0;
+}
+
+ORACLE_API int oracle_openmp_enabled(void)
+{
+#ifdef _OPENMP
+    return 1;
+#else
+    return 0;
+#endif
+}

@@ -1,0 +1,305 @@
+#!/usr/bin/env python3
+"""
+Generate tests/golden/*.npz from the REAL reference NumPy engine.
+
+Run in the build container only (the reference lives at /root/reference and never travels):
+
+    PYTHONDONTWRITEBYTECODE=1 python3 oracle/gen_golden.py
+
+Every expected output stored here is produced by calling the reference's own functions
+(``twentyfortyeight.core.gameboard`` / ``gamemove`` / ``utils``); this script only chooses the
+inputs and, for the stochastic part, injects the spawn choice (k-th empty cell, value) through
+the reference's ``after_state_lazy`` + ``generate_outcome`` so that the build's Philox contract
+can be replayed through the reference engine.  Fixtures are data (inputs + expected outputs),
+stored as packed log2 exponents (uint8) unless noted.
+
+Fixture sets:
+  rows.npz          G1  all 18^4 rows e in [0,17]: merge_column result (padded), score, can_move
+  afterstates.npz   G2  boards x 4 actions: latent_state, reward, validity; legal mask, is_done
+  next_state.npz    G3  real next_state(board, action, seed=numpy seed): board', reward, inferred (k, e), done
+  trajectories.npz  G4  full games under the build's Philox contract replayed by the reference engine
+  resets.npz        G5  reset boards under the Philox contract (two sequential injected spawns)
+  transforms.npz        encode_flatten(...,31) one-hot observations and normalize_reward values
+"""
+
+from __future__ import annotations
+
+import hashlib
+import sys
+from pathlib import Path
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO))
+sys.path.insert(0, '/root/reference')
+sys.dont_write_bytecode = True
+
+from twentyfortyeight.core import gameboard as ref_board  # noqa: E402  (reference, read-only)
+from twentyfortyeight.core import gamemove as ref_move  # noqa: E402
+from twentyfortyeight.utils.binary import encode_flatten as ref_encode_flatten  # noqa: E402
+from twentyfortyeight.utils.normalize import normalize_reward as ref_normalize_reward  # noqa: E402
+
+import oracle  # noqa: E402  (only its Philox contract is used here, to choose injected spawns)
+
+OUT = REPO / 'tests' / 'golden'
+MAX_E = 17  # largest reachable tile on 4x4 is 2^17
+
+
+def to_values(exps: np.ndarray) -> np.ndarray:
+    e = np.asarray(exps, dtype=np.int64)
+    return np.where(e > 0, np.int64(1) << e, 0).astype(np.int64)
+
+
+def to_exps(values: np.ndarray) -> np.ndarray:
+    v = np.asarray(values, dtype=np.int64)
+    out = np.zeros(v.shape, dtype=np.uint8)
+    nz = v > 0
+    out[nz] = np.round(np.log2(v[nz])).astype(np.uint8)
+    assert np.all(to_values(out) == v)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# G1: exhaustive rows
+# ------------------------------------------------------------------------------------------------
+def gen_rows():
+    base = MAX_E + 1
+    n = base**4
+    out_rows = np.zeros((n, 4), dtype=np.uint8)
+    scores = np.zeros(n, dtype=np.int32)
+    can_move = np.zeros(n, dtype=np.uint8)
+    for idx in range(n):
+        digits = [(idx // base**3) % base, (idx // base**2) % base, (idx // base) % base, idx % base]
+        row = to_values(np.array(digits))
+        score, merged = ref_board.merge_column(row)
+        padded = np.zeros(4, dtype=np.int64)
+        padded[: len(merged)] = merged
+        out_rows[idx] = to_exps(padded)
+        scores[idx] = int(score)
+        can_move[idx] = int(ref_move.can_move(row.reshape(1, 4)))
+    np.savez_compressed(OUT / 'rows.npz', max_e=np.int32(MAX_E), merged=out_rows, score=scores, can_move=can_move)
+    return n
+
+
+# ------------------------------------------------------------------------------------------------
+# Board mixture
+# ------------------------------------------------------------------------------------------------
+def random_play_boards(rng: np.random.Generator, count: int) -> list[np.ndarray]:
+    """States visited by the reference engine itself under uniform random actions."""
+    boards = []
+    seed = 10_000
+    while len(boards) < count:
+        state = np.zeros((4, 4), dtype=np.int64)
+        state = ref_board.fill_cells(state=state, number_tile=2, seed=seed)
+        seed += 1
+        for _ in range(600):
+            if rng.random() < 0.12:
+                boards.append(state.copy())
+            if ref_board.is_done(state):
+                boards.append(state.copy())
+                break
+            state, _ = ref_board.next_state(state.copy(), int(rng.integers(0, 4)), seed=seed)
+            seed += 1
+    return boards[:count]
+
+
+def mixture(rng: np.random.Generator, n_play: int, n_uniform: int, n_dense: int, n_big: int) -> np.ndarray:
+    boards = [to_exps(b).reshape(16) for b in random_play_boards(rng, n_play)]
+    for _ in range(n_uniform):  # uniform small exponents, many empties
+        boards.append(rng.integers(0, 7, size=16).astype(np.uint8))
+    for _ in range(n_dense):  # dense / near-terminal: few distinct exponents, 0-2 empties
+        b = rng.integers(1, 5, size=16).astype(np.uint8)
+        for _ in range(int(rng.integers(0, 3))):
+            b[int(rng.integers(0, 16))] = 0
+        boards.append(b)
+    for _ in range(n_big):  # big tiles up to 2^17
+        b = rng.integers(0, MAX_E + 1, size=16).astype(np.uint8)
+        b[rng.random(16) < 0.3] = 0
+        boards.append(b)
+    hand = [
+        np.zeros(16, dtype=np.uint8),  # all-zero: NOT done in the NumPy engine
+        np.arange(1, 17, dtype=np.uint8),  # staircase 2..65536: done (tests/test_board.py:53-56)
+        np.array([1, 2] * 8, dtype=np.uint8).reshape(4, 4).reshape(16),
+        to_exps(np.array([[2, 4, 2, 4], [4, 2, 4, 2], [2, 4, 2, 4], [4, 2, 4, 2]])).reshape(16),  # checkerboard
+        to_exps(np.array([[2, 4, 2, 4], [4, 2, 4, 2], [2, 4, 2, 4], [4, 2, 2, 2]])).reshape(16),
+        np.full(16, 16, dtype=np.uint8),  # all 65536: every move merges to 2^17
+        np.full(16, 17, dtype=np.uint8),
+        to_exps(np.array([[2, 0, 0, 0], [2, 0, 0, 0], [0, 0, 0, 0], [0, 0, 0, 0]])).reshape(16),
+    ]
+    boards.extend(hand)
+    return np.stack(boards).astype(np.uint8)
+
+
+# ------------------------------------------------------------------------------------------------
+# G2: afterstates + legality + terminal
+# ------------------------------------------------------------------------------------------------
+def gen_afterstates(rng):
+    boards = mixture(rng, n_play=3000, n_uniform=1200, n_dense=1200, n_big=600)
+    n = boards.shape[0]
+    after = np.zeros((n, 4, 16), dtype=np.uint8)
+    reward = np.zeros((n, 4), dtype=np.int32)
+    valid = np.zeros((n, 4), dtype=np.uint8)
+    legal = np.zeros(n, dtype=np.uint8)
+    done = np.zeros(n, dtype=np.uint8)
+    for i in range(n):
+        state = to_values(boards[i]).reshape(4, 4)
+        for a in range(4):
+            new_state, r = ref_board.latent_state(state, a)
+            after[i, a] = to_exps(new_state).reshape(16)
+            reward[i, a] = int(r)
+            valid[i, a] = int(ref_move.can_move(np.rot90(state, k=a)))  # the test next_state applies (:316-317)
+        mask = ref_move.legal_actions_mask(state)
+        legal[i] = sum(int(bool(m)) << a for a, m in enumerate(mask))
+        assert set(ref_move.legal_actions(state)) == {a for a in range(4) if mask[a]}
+        assert set(ref_move.illegal_actions(state)) == {a for a in range(4) if not mask[a]}
+        done[i] = int(ref_board.is_done(state))
+    np.savez_compressed(OUT / 'afterstates.npz', boards=boards, after=after, reward=reward, valid=valid,
+                        legal=legal, done=done)
+    return n
+
+
+# ------------------------------------------------------------------------------------------------
+# G3: the reference's real next_state with its own (NumPy PCG64) seeded spawn
+# ------------------------------------------------------------------------------------------------
+def gen_next_state(rng):
+    boards = mixture(rng, n_play=2400, n_uniform=600, n_dense=800, n_big=200)
+    n = boards.shape[0]
+    actions = rng.integers(0, 4, size=n).astype(np.uint8)
+    seeds = rng.integers(1, 2**31 - 1, size=n).astype(np.int64)
+    out = np.zeros((n, 16), dtype=np.uint8)
+    reward = np.zeros(n, dtype=np.int32)
+    spawn_k = np.full(n, 255, dtype=np.uint8)  # 255 = no spawn (invalid move)
+    spawn_e = np.zeros(n, dtype=np.uint8)
+    done = np.zeros(n, dtype=np.uint8)
+    for i in range(n):
+        state = to_values(boards[i]).reshape(4, 4)
+        new_state, r = ref_board.next_state(state.copy(), int(actions[i]), seed=int(seeds[i]))
+        out[i] = to_exps(new_state).reshape(16)
+        reward[i] = int(r)
+        done[i] = int(ref_board.is_done(new_state))
+        after, _ = ref_board.latent_state(state, int(actions[i]))
+        diff = np.argwhere(np.asarray(new_state) != np.asarray(after))
+        if ref_move.can_move(np.rot90(state, k=int(actions[i]))):
+            assert len(diff) == 1, (state, actions[i], new_state)
+            cell = (int(diff[0][0]), int(diff[0][1]))
+            _, cells, _ = ref_board.after_state_lazy(after)
+            spawn_k[i] = cells.index(cell)
+            spawn_e[i] = int(np.log2(new_state[cell]))
+        else:
+            assert len(diff) == 0 and int(r) == 0 and np.array_equal(new_state, state)
+    np.savez_compressed(OUT / 'next_state.npz', boards=boards, actions=actions, numpy_seeds=seeds, out=out,
+                        reward=reward, spawn_k=spawn_k, spawn_e=spawn_e, done=done)
+    return n
+
+
+# ------------------------------------------------------------------------------------------------
+# Reference engine driven by the build's Philox contract (injected spawns)
+# ------------------------------------------------------------------------------------------------
+def ref_spawn(state: np.ndarray, r_cell: int, r_val: int) -> np.ndarray:
+    """One spawn through after_state_lazy/generate_outcome with (k, e) from two Philox words."""
+    base, cells, n_empty = ref_board.after_state_lazy(state)
+    if n_empty == 0:
+        return state
+    k, e = oracle.spawn_from_words(r_cell, r_val, n_empty)
+    new_state, _ = ref_board.generate_outcome(base, cells[k], 1 << e, n_empty)
+    return new_state
+
+
+def ref_reset(seed: int, env: int, step: int) -> np.ndarray:
+    r = oracle.env_block(seed, env, step, 1)
+    state = np.zeros((4, 4), dtype=np.int64)
+    state = ref_spawn(state, int(r[0]), int(r[1]))
+    state = ref_spawn(state, int(r[2]), int(r[3]))
+    return state
+
+
+def ref_step(state: np.ndarray, action: int, blk) -> tuple[np.ndarray, int]:
+    """next_state's control flow (gameboard.py:316-325) with the spawn injected."""
+    rotated = np.rot90(state, k=action)
+    if ref_move.can_move(rotated):
+        reward, updated = ref_board.slide_and_merge(rotated)
+        new_state = np.rot90(updated, k=-action)
+        new_state = ref_spawn(new_state, int(blk[0]), int(blk[1]))
+        return new_state, int(reward)
+    return state, 0
+
+
+def gen_trajectories():
+    sets = {}
+    for name, seed, env_base, n_env, T, auto_reset, step0 in [
+        ('auto', 0x2048, 1000, 40, 420, 1, 7),
+        ('plain', 0xC0FFEE, (1 << 32) + 5, 16, 420, 0, 0),  # env index above 2^32 exercises env_hi
+    ]:
+        boards0 = np.zeros((n_env, 16), dtype=np.uint8)
+        boards = np.zeros((T, n_env, 16), dtype=np.uint8)
+        actions = np.zeros((T, n_env), dtype=np.uint8)
+        reward = np.zeros((T, n_env), dtype=np.int32)
+        done = np.zeros((T, n_env), dtype=np.uint8)
+        legal = np.zeros((T, n_env), dtype=np.uint8)
+        for j in range(n_env):
+            env = env_base + j
+            state = ref_reset(seed, env, step0)
+            boards0[j] = to_exps(state).reshape(16)
+            for t in range(T):
+                step = step0 + t
+                blk = oracle.env_block(seed, env, step, 0)
+                a = int(blk[2]) & 3
+                state, r = ref_step(state, a, blk)
+                d = bool(ref_board.is_done(state))
+                if d and auto_reset:
+                    state = ref_reset(seed, env, step)
+                actions[t, j] = a
+                reward[t, j] = r
+                done[t, j] = int(d)
+                boards[t, j] = to_exps(state).reshape(16)
+                mask = ref_move.legal_actions_mask(state)
+                legal[t, j] = sum(int(bool(m)) << b for b, m in enumerate(mask))
+        sets[name] = dict(seed=np.uint64(seed), env_base=np.uint64(env_base), step0=np.uint64(step0),
+                          auto_reset=np.uint8(auto_reset), boards0=boards0, boards=boards, actions=actions,
+                          reward=reward, done=done, legal=legal)
+    flat = {f'{k}_{f}': v for k, d in sets.items() for f, v in d.items()}
+    np.savez_compressed(OUT / 'trajectories.npz', **flat)
+    return {k: (int(d['done'].sum()), d['boards'].shape) for k, d in sets.items()}
+
+
+def gen_resets():
+    seed, step, env_base, n = 0xABCDEF0123, 3, 77, 4096
+    boards = np.zeros((n, 16), dtype=np.uint8)
+    for j in range(n):
+        boards[j] = to_exps(ref_reset(seed, env_base + j, step)).reshape(16)
+    np.savez_compressed(OUT / 'resets.npz', seed=np.uint64(seed), step=np.uint64(step),
+                        env_base=np.uint64(env_base), boards=boards)
+    return n
+
+
+def gen_transforms(rng):
+    boards = mixture(rng, n_play=200, n_uniform=20, n_dense=20, n_big=16)
+    n = boards.shape[0]
+    onehot = np.zeros((n, 16 * 31), dtype=np.uint8)
+    for i in range(n):
+        onehot[i] = ref_encode_flatten(to_values(boards[i]).reshape(4, 4), encodage_size=31).astype(np.uint8)
+    rewards = np.array([0, 4, 8, 12, 16, 20, 28, 60, 64, 128, 2048, 4100, 65536, 131072, 2**20], dtype=np.int64)
+    norm = np.array([float(ref_normalize_reward(float(r))) for r in rewards], dtype=np.float64)
+    np.savez_compressed(OUT / 'transforms.npz', boards=boards, onehot31=onehot, rewards=rewards,
+                        normalized=norm)
+    return n
+
+
+def main():
+    OUT.mkdir(parents=True, exist_ok=True)
+    rng = np.random.default_rng(20480)
+    print('rows', gen_rows())
+    print('afterstates', gen_afterstates(rng))
+    print('next_state', gen_next_state(rng))
+    print('trajectories', gen_trajectories())
+    print('resets', gen_resets())
+    print('transforms', gen_transforms(rng))
+    with open(OUT / 'SHA256SUMS', 'w') as fh:
+        for p in sorted(OUT.glob('*.npz')):
+            fh.write(f'{hashlib.sha256(p.read_bytes()).hexdigest()}  {p.name}\n')
+            print(p.name, p.stat().st_size)
+
+
+if __name__ == '__main__':
+    main()
