@@ -1,0 +1,160 @@
+/*
+ * env2048.h -- C-ABI of the MI355X-native batched 2048 environment (libenv2048.so).
+ *
+ * The reference (schalappe/simulate_2048) is pure Python: it has no FFI/plugin interface for
+ * this path, only ordinary Python call signatures.  This header therefore DEFINES the boundary a
+ * maintainer would bind with ctypes; each entry point names the reference
+ * function(s) it replaces as [replaces: file:lines] (paths relative to the reference repo root).
+ *
+ * Conventions
+ *   - Every pointer is a DEVICE pointer on HIP device `device` (plain hipMalloc memory or the
+ *     storage of a torch tensor); the caller owns every buffer; the library allocates nothing
+ *     and keeps no per-batch state.  Environment state is exactly `boards` + (seed, step_index).
+ *   - `stream` is a hipStream_t (NULL = the device's default stream).  Calls are ASYNCHRONOUS on
+ *     that stream; the caller synchronises.  Entry points are re-entrant and thread-safe.
+ *   - Return value: 0 (ENV2048_OK) or a negative error code; env2048_last_error() returns a
+ *     thread-local message for the last failure on the calling thread.  No exceptions, no traps
+ *     on bad *data* (actions are taken mod 4; exponents > 31 are undefined input).
+ *   - n == 0 is a successful no-op.
+ *   - There is NO CPU fallback: without a usable HIP device every compute entry point fails
+ *     with ENV2048_ERR_DEVICE.
+ *
+ * Board layout ("packed log2"): 16 bytes per board, byte i = 4*row + col (row-major, the order
+ * of ndarray.flatten()), value e: 0 = empty, e >= 1 means tile 2^e.  `boards` must be 16-byte
+ * aligned; int32/float/int64 arrays naturally aligned.
+ *
+ * Actions: 0 = left, 1 = up, 2 = right, 3 = down  [twentyfortyeight/envs/twentyfortyeight.py:19].
+ *
+ * RNG contract (build-defined; the reference's PCG64 / threefry bitstreams are not part of its
+ * tested behaviour): Philox4x32-10, key = (seed_lo, seed_hi),
+ * counter = (env_lo, step_lo, step_hi, stream + 2*env_hi) where env = env_base + i is the GLOBAL
+ * environment index, so results do not depend on how a batch is sliced across GPUs.
+ *   stream 0 ("step block") words (r0,r1,r2,r3):
+ *       spawn cell  k = floor(r0 * n_empty / 2^32)  -> k-th empty cell in row-major order
+ *       spawn tile  4 (e=2) iff r1 < 429496729 (= floor(0.1 * 2^32)), else 2 (e=1)
+ *       r2 & 3      the on-device random action (ENV2048_FLAG_RANDOM_ACTIONS, env2048_rollout)
+ *   stream 1 ("reset block"): (r0,r1) first spawn among 16 empties, (r2,r3) second spawn among
+ *       the remaining 15 -- two sequential single spawns on an empty board.
+ */
+#ifndef ENV2048_H
+#define ENV2048_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(ENV2048_BUILDING)
+#define ENV2048_EXPORT __attribute__((visibility("default")))
+#else
+#define ENV2048_EXPORT
+#endif
+
+#define ENV2048_ABI_VERSION 1
+
+#define ENV2048_OK 0
+#define ENV2048_ERR_INVALID_ARG (-1) /* NULL required pointer, bad flag bits */
+#define ENV2048_ERR_ALIGNMENT (-2)   /* misaligned buffer */
+#define ENV2048_ERR_DEVICE (-3)      /* no such device / no HIP runtime / no GPU */
+#define ENV2048_ERR_RANGE (-4)       /* env_base + n overflows the 2^63 global index range */
+#define ENV2048_ERR_HIP_BASE (-1000) /* HIP runtime error e is reported as -1000 - e */
+
+/* step / rollout flags */
+#define ENV2048_FLAG_AUTO_RESET 1u     /* a board that became terminal is replaced by a fresh one */
+#define ENV2048_FLAG_RANDOM_ACTIONS 2u /* ignore `actions`; use r2 & 3 of the step block */
+
+ENV2048_EXPORT int env2048_abi_version(void);
+ENV2048_EXPORT const char *env2048_last_error(void);
+/* Number of HIP devices visible to the process, or a negative error code. */
+ENV2048_EXPORT int env2048_device_count(void);
+
+/*
+ * Fresh boards: zeros + two spawned tiles.  Writes boards[i] for i in [0,n) and, if non-NULL,
+ * done[i] = 0.  Uses the stream-1 block of (env_base + i, step_index).
+ * [replaces: twentyfortyeight/envs/twentyfortyeight.py:84-104 reset;
+ *            reinforce/game/core.py:324-343 create_initial_board; reinforce/game/env.py:55-76 reset,
+ *            :176-190 batched_reset]
+ */
+ENV2048_EXPORT int env2048_reset(int device, void *stream, uint64_t n, uint64_t env_base, uint8_t *boards, uint8_t *done,
+                  uint64_t seed, uint64_t step_index);
+
+/*
+ * One environment transition per board, in place:
+ *     a = action & 3;  after = slide+merge(board, a);  reward = sum of merged tile values
+ *     if after != board: board = after with one spawned tile   (valid move)
+ *     else:              board unchanged, reward = 0, no spawn   (invalid move)
+ *     done = board full and no equal horizontally/vertically adjacent pair (post-spawn board)
+ *     if (flags & AUTO_RESET) and done: board = fresh board from the stream-1 block of the
+ *                                       same (env, step_index); done[i] still reports 1
+ * A board that is already terminal has no valid move, so stepping it is a no-op with reward 0
+ * and done = 1 -- the reference's explicit done-guard (reinforce/game/env.py:103-104).
+ * Outputs (each may be NULL except boards/done; `actions` may be NULL only with RANDOM_ACTIONS):
+ *     reward[i]  int32 score delta            legal[i]  bit a set <=> action a legal on the
+ *     done[i]    0/1                                     board written back
+ *     obs[16*i..] float32 log2(tile)/16 of the board written back (0 for empty)
+ * [replaces: twentyfortyeight/core/gameboard.py:291-325 next_state, :328-348 is_done;
+ *            twentyfortyeight/envs/twentyfortyeight.py:106-133 step;
+ *            reinforce/game/core.py:234-272 next_state, :275-321 legal_actions_mask/is_done,
+ *            :346-377 encode_observation; reinforce/game/env.py:79-133 step, :193-245 batched_*]
+ */
+ENV2048_EXPORT int env2048_step(int device, void *stream, uint64_t n, uint64_t env_base, uint8_t *boards,
+                 const uint8_t *actions, int32_t *reward, uint8_t *done, uint8_t *legal, float *obs,
+                 uint64_t seed, uint64_t step_index, uint32_t flags);
+
+/*
+ * T consecutive transitions per board, boards held in registers, actions drawn on device
+ * (r2 & 3 of each step block): identical to T calls of env2048_step(..., step0 + t,
+ * flags | RANDOM_ACTIONS).  Per-environment outputs (each may be NULL):
+ *     return_sum[i]  int64 sum of rewards      episodes[i]  number of transitions with done = 1
+ *     valid_moves[i] number of transitions that changed the board
+ * [replaces: the env side of reinforce/training/self_play.py:314-368 play_parallel_games loop]
+ */
+ENV2048_EXPORT int env2048_rollout(int device, void *stream, uint64_t n, uint64_t env_base, uint8_t *boards, uint64_t seed,
+                    uint64_t step0, uint32_t T, int64_t *return_sum, uint32_t *episodes, uint32_t *valid_moves,
+                    uint32_t flags);
+
+/*
+ * Afterstate only (deterministic half of a move): boards_out = slide+merge(boards_in, action),
+ * reward = merge score, changed = (boards_out != boards_in).  boards_out may alias boards_in.
+ * [replaces: twentyfortyeight/core/gameboard.py:23-129 merge_column/slide_and_merge/latent_state;
+ *            twentyfortyeight/core/gamemove.py:132-164 can_move (== changed);
+ *            reinforce/game/core.py:32-170 merge_row/slide_and_merge/latent_state]
+ */
+ENV2048_EXPORT int env2048_afterstate(int device, void *stream, uint64_t n, const uint8_t *boards_in, const uint8_t *actions,
+                       uint8_t *boards_out, int32_t *reward, uint8_t *changed);
+
+/*
+ * Chance half of a move with the outcome given by the caller: put exponent spawn_e[i] into the
+ * spawn_k[i]-th empty cell (row-major).  placed[i] (may be NULL) = flat cell index, or 0xFF when
+ * spawn_k[i] >= number of empty cells (board unchanged).
+ * [replaces: twentyfortyeight/core/gameboard.py:174-244 after_state_lazy + generate_outcome,
+ *            :247-288 fill_cells (cell order); reinforce/game/core.py:173-231 fill_cells]
+ */
+ENV2048_EXPORT int env2048_spawn(int device, void *stream, uint64_t n, uint8_t *boards, const uint8_t *spawn_k,
+                  const uint8_t *spawn_e, uint8_t *placed);
+
+/*
+ * Read-only board status; every output may be NULL.
+ *     done / legal / obs as in env2048_step;  max_exp[i] = log2(max tile);  n_empty[i] = #zeros
+ * [replaces: twentyfortyeight/core/gameboard.py:328-348 is_done;
+ *            twentyfortyeight/core/gamemove.py:45-129 legal_actions_mask/legal/illegal_actions;
+ *            reinforce/game/core.py:275-321, :346-377, :427-460 max_tile/count_empty]
+ */
+ENV2048_EXPORT int env2048_status(int device, void *stream, uint64_t n, const uint8_t *boards, uint8_t *done, uint8_t *legal,
+                   float *obs, uint8_t *max_exp, uint8_t *n_empty);
+
+/*
+ * Tile values <-> packed exponents, n boards of 16 cells.  pack: value v (0 or a power of two)
+ * -> e = log2(v) (0 for 0); unpack: e -> 2^e (0 for 0).  int32 matches the reinforce/game board
+ * dtype (reinforce/game/core.py:340), int64 the NumPy env's (twentyfortyeight.py:39,101).
+ */
+ENV2048_EXPORT int env2048_pack_i32(int device, void *stream, uint64_t n, const int32_t *values, uint8_t *boards);
+ENV2048_EXPORT int env2048_unpack_i32(int device, void *stream, uint64_t n, const uint8_t *boards, int32_t *values);
+ENV2048_EXPORT int env2048_pack_i64(int device, void *stream, uint64_t n, const int64_t *values, uint8_t *boards);
+ENV2048_EXPORT int env2048_unpack_i64(int device, void *stream, uint64_t n, const uint8_t *boards, int64_t *values);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ENV2048_H */

@@ -1,0 +1,148 @@
+"""
+Host-side batched 2048 environment: owns the device buffers (torch tensors are used purely as
+device-memory handles) and drives the HIP kernels through the C-ABI (``capi.Library``).
+
+State of a batch = ``boards`` (N x 16 packed log2 bytes) + ``(seed, step_index)``; everything else
+is an output buffer.  ``env_base`` is the global index of element 0, so a batch that is sliced
+across GPUs (``sharding.shard_range``) produces exactly the boards the unsliced batch would.
+
+Mirrors the batched half of the reference API (``reinforce/game/env.py:176-245`` batched_reset /
+batched_step / batched_get_observation / batched_get_legal_actions) in packed form; the literal
+drop-in shims built on top of it live in ``simulate_2048_amd.reinforce.game``.
+"""
+
+from __future__ import annotations
+
+import torch
+
+from . import capi
+
+
+def _stream_handle(device: torch.device):
+    """(device ordinal, hipStream_t) of torch's CURRENT stream on `device`."""
+    if device.type != 'cuda':
+        return -1, None
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    return index, torch.cuda.current_stream(device).cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+class BatchedEnv2048:
+    """N independent 2048 boards stepped in lock-step on one GPU.
+
+    Parameters
+    ----------
+    num_envs : int
+        Boards in this batch (this rank's slice when sharded).
+    seed : int
+        64-bit Philox key shared by the whole (global) batch.
+    device : str | torch.device
+        A HIP device ('cuda', 'cuda:0', ...).  CPU devices are refused unless a non-default
+        ``lib`` is injected (the test-suite does that with an oracle-backed stand-in).
+    env_base : int
+        Global index of board 0 (multi-GPU slicing).
+    auto_reset : bool
+        Replace a board by a fresh one in the same step in which it became terminal
+        (new capability; the reference freezes finished games, reinforce/game/env.py:103-104).
+    with_legal, with_obs : bool
+        Also emit the legal-action bitmask / the f32 observation from the step kernel
+        (what reinforce/training/self_play.py:316-317 asks the env for every move).
+    """
+
+    def __init__(self, num_envs: int, seed: int = 0, *, device='cuda', env_base: int = 0, auto_reset: bool = False,
+                 with_legal: bool = False, with_obs: bool = False, lib=None):
+        self.device = torch.device(device)
+        if lib is None:
+            if self.device.type != 'cuda':
+                raise RuntimeError(
+                    f'BatchedEnv2048 runs on HIP devices only (got device={self.device}); there is no CPU fallback'
+                )
+            lib = capi.library()
+            if lib.device_count() <= 0:
+                raise RuntimeError('no HIP device visible to libenv2048')
+        self.lib = lib
+        self.num_envs = int(num_envs)
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.env_base = int(env_base)
+        self.auto_reset = bool(auto_reset)
+        self.step_index = 0
+        n = self.num_envs
+        self.boards = torch.zeros((n, 16), dtype=torch.uint8, device=self.device)
+        self.reward = torch.zeros((n,), dtype=torch.int32, device=self.device)
+        self.done = torch.zeros((n,), dtype=torch.uint8, device=self.device)
+        self.legal = torch.zeros((n,), dtype=torch.uint8, device=self.device) if with_legal else None
+        self.obs = torch.zeros((n, 16), dtype=torch.float32, device=self.device) if with_obs else None
+
+    # ------------------------------------------------------------------------------------------
+    @property
+    def flags(self) -> int:
+        return capi.FLAG_AUTO_RESET if self.auto_reset else 0
+
+    def reset(self, step_index: int | None = None) -> torch.Tensor:
+        """Fresh boards for the whole batch (two spawned tiles each). Returns ``boards``."""
+        if step_index is not None:
+            self.step_index = int(step_index)
+        dev, stream = _stream_handle(self.device)
+        self.lib.reset(dev, stream, self.num_envs, self.env_base, _p(self.boards), _p(self.done), self.seed,
+                       self.step_index)
+        self.reward.zero_()
+        if self.legal is not None or self.obs is not None:
+            self.lib.status(dev, stream, self.num_envs, _p(self.boards), None, _p(self.legal), _p(self.obs), None, None)
+        return self.boards
+
+    def step(self, actions: torch.Tensor | None = None):
+        """One transition per board, in place; asynchronous on torch's current stream.
+
+        ``actions``: uint8 tensor (N,) on the same device, values taken mod 4 (0 left, 1 up,
+        2 right, 3 down); ``None`` draws uniform random actions on device from the step block.
+        Returns ``(boards, reward, done)`` -- views of the persistent buffers.
+        """
+        flags = self.flags
+        if actions is None:
+            flags |= capi.FLAG_RANDOM_ACTIONS
+        else:
+            if actions.dtype != torch.uint8 or actions.device != self.boards.device or not actions.is_contiguous():
+                actions = actions.to(device=self.boards.device, dtype=torch.uint8).contiguous()
+            if actions.numel() != self.num_envs:
+                raise ValueError(f'expected {self.num_envs} actions, got {actions.numel()}')
+        dev, stream = _stream_handle(self.device)
+        self.lib.step(dev, stream, self.num_envs, self.env_base, _p(self.boards), _p(actions), _p(self.reward),
+                      _p(self.done), _p(self.legal), _p(self.obs), self.seed, self.step_index, flags)
+        self.step_index += 1
+        return self.boards, self.reward, self.done
+
+    def rollout(self, num_steps: int):
+        """``num_steps`` transitions with on-device random actions in ONE kernel (boards stay in
+        registers).  Returns dict(return_sum int64, episodes uint32->int32 view, valid_moves)."""
+        n = self.num_envs
+        ret = torch.zeros((n,), dtype=torch.int64, device=self.device)
+        eps = torch.zeros((n,), dtype=torch.int32, device=self.device)
+        moves = torch.zeros((n,), dtype=torch.int32, device=self.device)
+        dev, stream = _stream_handle(self.device)
+        self.lib.rollout(dev, stream, n, self.env_base, _p(self.boards), self.seed, self.step_index, int(num_steps),
+                         _p(ret), _p(eps), _p(moves), self.flags | capi.FLAG_RANDOM_ACTIONS)
+        self.step_index += int(num_steps)
+        return {'return_sum': ret, 'episodes': eps, 'valid_moves': moves}
+
+    def status(self):
+        """done / legal bitmask / f32 obs / max exponent / empty count of the current boards."""
+        n = self.num_envs
+        out = {
+            'done': torch.zeros((n,), dtype=torch.uint8, device=self.device),
+            'legal': torch.zeros((n,), dtype=torch.uint8, device=self.device),
+            'obs': torch.zeros((n, 16), dtype=torch.float32, device=self.device),
+            'max_exp': torch.zeros((n,), dtype=torch.uint8, device=self.device),
+            'n_empty': torch.zeros((n,), dtype=torch.uint8, device=self.device),
+        }
+        dev, stream = _stream_handle(self.device)
+        self.lib.status(dev, stream, n, _p(self.boards), _p(out['done']), _p(out['legal']), _p(out['obs']),
+                        _p(out['max_exp']), _p(out['n_empty']))
+        return out
+
+    def set_boards(self, boards) -> None:
+        """Overwrite the state with packed boards (anything convertible to an (N,16) uint8 tensor)."""
+        b = torch.as_tensor(boards, dtype=torch.uint8).reshape(self.num_envs, 16)
+        self.boards.copy_(b)

@@ -1,0 +1,141 @@
+"""
+ctypes binding of ``libenv2048.so`` (include/env2048.h) -- the thin layer between Python host code
+and the HIP kernels.  No torch types cross the ABI: callers hand over raw device pointers
+(``tensor.data_ptr()``), a device ordinal and a ``hipStream_t`` handle.
+
+There is deliberately no CPU fallback here: if the library is missing, cannot be loaded, or no HIP
+device is usable, the calls raise.
+"""
+
+from __future__ import annotations
+
+import ctypes
+from pathlib import Path
+
+ABI_VERSION = 1
+
+OK = 0
+ERR_INVALID_ARG = -1
+ERR_ALIGNMENT = -2
+ERR_DEVICE = -3
+ERR_RANGE = -4
+ERR_HIP_BASE = -1000
+
+FLAG_AUTO_RESET = 1
+FLAG_RANDOM_ACTIONS = 2
+
+LIB_PATH = Path(__file__).resolve().parent / 'lib' / 'libenv2048.so'
+
+_c_int = ctypes.c_int
+_u32 = ctypes.c_uint32
+_u64 = ctypes.c_uint64
+_ptr = ctypes.c_void_p
+
+# name -> (restype, argtypes): exactly the prototypes of include/env2048.h
+PROTOTYPES = {
+    'env2048_abi_version': (_c_int, []),
+    'env2048_last_error': (ctypes.c_char_p, []),
+    'env2048_device_count': (_c_int, []),
+    'env2048_reset': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _ptr, _u64, _u64]),
+    'env2048_step': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _u64, _u64, _u32]),
+    'env2048_rollout': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _u64, _u64, _u32, _ptr, _ptr, _ptr, _u32]),
+    'env2048_afterstate': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    'env2048_spawn': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr]),
+    'env2048_status': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    'env2048_pack_i32': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr]),
+    'env2048_unpack_i32': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr]),
+    'env2048_pack_i64': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr]),
+    'env2048_unpack_i64': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr]),
+}
+
+
+class Env2048Error(RuntimeError):
+    """A C-ABI call returned a negative code; ``code`` holds it, the message is env2048_last_error()."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f'libenv2048 error {code}: {message}')
+        self.code = code
+
+
+class Library:
+    """Loaded ``libenv2048.so`` with typed entry points; every compute call raises on failure."""
+
+    def __init__(self, path: str | Path | None = None):
+        self.path = Path(path) if path else LIB_PATH
+        if not self.path.exists():
+            raise FileNotFoundError(
+                f'{self.path} not found: build it with `python -m simulate_2048_amd.build` '
+                '(needs hipcc; there is no CPU fallback)'
+            )
+        self._dll = ctypes.CDLL(str(self.path))
+        for name, (restype, argtypes) in PROTOTYPES.items():
+            fn = getattr(self._dll, name)  # AttributeError if the .so does not export it
+            fn.restype = restype
+            fn.argtypes = argtypes
+        version = self._dll.env2048_abi_version()
+        if version != ABI_VERSION:
+            raise RuntimeError(f'{self.path}: ABI version {version}, this binding expects {ABI_VERSION}')
+
+    # -- plumbing -----------------------------------------------------------------------------
+    def last_error(self) -> str:
+        return (self._dll.env2048_last_error() or b'').decode('utf-8', 'replace')
+
+    def _check(self, rc: int) -> None:
+        if rc != OK:
+            raise Env2048Error(rc, self.last_error())
+
+    def abi_version(self) -> int:
+        return self._dll.env2048_abi_version()
+
+    def device_count(self) -> int:
+        """Number of visible HIP devices; raises Env2048Error when the HIP runtime is unusable."""
+        rc = self._dll.env2048_device_count()
+        if rc < 0:
+            raise Env2048Error(rc, self.last_error())
+        return rc
+
+    # -- compute entry points (raw pointers in, nothing out; asynchronous on `stream`) --------
+    def reset(self, device, stream, n, env_base, boards, done, seed, step_index) -> None:
+        self._check(self._dll.env2048_reset(device, stream, n, env_base, boards, done, seed, step_index))
+
+    def step(self, device, stream, n, env_base, boards, actions, reward, done, legal, obs, seed, step_index,
+             flags) -> None:
+        self._check(self._dll.env2048_step(device, stream, n, env_base, boards, actions, reward, done, legal, obs,
+                                           seed, step_index, flags))
+
+    def rollout(self, device, stream, n, env_base, boards, seed, step0, T, return_sum, episodes, valid_moves,
+                flags) -> None:
+        self._check(self._dll.env2048_rollout(device, stream, n, env_base, boards, seed, step0, T, return_sum,
+                                              episodes, valid_moves, flags))
+
+    def afterstate(self, device, stream, n, boards_in, actions, boards_out, reward, changed) -> None:
+        self._check(self._dll.env2048_afterstate(device, stream, n, boards_in, actions, boards_out, reward, changed))
+
+    def spawn(self, device, stream, n, boards, spawn_k, spawn_e, placed) -> None:
+        self._check(self._dll.env2048_spawn(device, stream, n, boards, spawn_k, spawn_e, placed))
+
+    def status(self, device, stream, n, boards, done, legal, obs, max_exp, n_empty) -> None:
+        self._check(self._dll.env2048_status(device, stream, n, boards, done, legal, obs, max_exp, n_empty))
+
+    def pack_i32(self, device, stream, n, values, boards) -> None:
+        self._check(self._dll.env2048_pack_i32(device, stream, n, values, boards))
+
+    def unpack_i32(self, device, stream, n, boards, values) -> None:
+        self._check(self._dll.env2048_unpack_i32(device, stream, n, boards, values))
+
+    def pack_i64(self, device, stream, n, values, boards) -> None:
+        self._check(self._dll.env2048_pack_i64(device, stream, n, values, boards))
+
+    def unpack_i64(self, device, stream, n, boards, values) -> None:
+        self._check(self._dll.env2048_unpack_i64(device, stream, n, boards, values))
+
+
+_default: Library | None = None
+
+
+def library() -> Library:
+    """Process-wide default Library (loads simulate_2048_amd/lib/libenv2048.so on first use)."""
+    global _default
+    if _default is None:
+        _default = Library()
+    return _default

@@ -1,0 +1,378 @@
+"""
+GPU parity tests (-m gpu): the HIP path, called through the C-ABI (capi.Library), against
+
+* the golden fixtures generated from the reference NumPy engine (tests/golden), bit for bit;
+* the CPU oracle on seeded random inputs at sizes it finishes in seconds, bit for bit;
+* size-independent properties at BASELINE.json's full sizes (2^20 boards): slicing invariance,
+  rollout == T single steps, tile-mass conservation, checksums against the oracle.
+
+Everything here is integer / byte / index work: the bar is bit-exact (obs floats included: they
+are exact multiples of 1/16).
+"""
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from simulate_2048_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+DEV = 0
+
+
+@pytest.fixture(scope='module')
+def lib():
+    L = capi.library()
+    assert L.device_count() >= 1
+    return L
+
+
+def cu(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda(DEV).contiguous()
+
+
+def stream():
+    return torch.cuda.current_stream(DEV).cuda_stream
+
+
+def p(t):
+    return None if t is None else t.data_ptr()
+
+
+def hip_step(lib, boards, actions, seed, step_index, *, env_base=0, flags=0, extras=False):
+    n = boards.shape[0]
+    b = cu(boards)
+    a = None if actions is None else cu(actions, torch.uint8)
+    reward = torch.full((n,), -7, dtype=torch.int32, device='cuda')
+    done = torch.full((n,), 9, dtype=torch.uint8, device='cuda')
+    legal = torch.full((n,), 255, dtype=torch.uint8, device='cuda') if extras else None
+    obs = torch.full((n, 16), -1.0, dtype=torch.float32, device='cuda') if extras else None
+    lib.step(DEV, stream(), n, env_base, p(b), p(a), p(reward), p(done), p(legal), p(obs), seed, step_index, flags)
+    torch.cuda.synchronize()
+    out = {'boards': b.cpu().numpy(), 'reward': reward.cpu().numpy(), 'done': done.cpu().numpy()}
+    if extras:
+        out['legal'] = legal.cpu().numpy()
+        out['obs'] = obs.cpu().numpy()
+    return out
+
+
+def hip_afterstate(lib, boards, actions):
+    n = boards.shape[0]
+    b = cu(boards)
+    out = torch.zeros_like(b)
+    reward = torch.zeros((n,), dtype=torch.int32, device='cuda')
+    changed = torch.zeros((n,), dtype=torch.uint8, device='cuda')
+    a = cu(actions, torch.uint8)  # keep every device buffer referenced until the kernel has run
+    lib.afterstate(DEV, stream(), n, p(b), p(a), p(out), p(reward), p(changed))
+    torch.cuda.synchronize()
+    return {'boards': out.cpu().numpy(), 'reward': reward.cpu().numpy(), 'changed': changed.cpu().numpy()}
+
+
+def hip_status(lib, boards):
+    n = boards.shape[0]
+    b = cu(boards)
+    done = torch.zeros((n,), dtype=torch.uint8, device='cuda')
+    legal = torch.zeros((n,), dtype=torch.uint8, device='cuda')
+    obs = torch.zeros((n, 16), dtype=torch.float32, device='cuda')
+    max_exp = torch.zeros((n,), dtype=torch.uint8, device='cuda')
+    n_empty = torch.zeros((n,), dtype=torch.uint8, device='cuda')
+    lib.status(DEV, stream(), n, p(b), p(done), p(legal), p(obs), p(max_exp), p(n_empty))
+    torch.cuda.synchronize()
+    return {k: v.cpu().numpy() for k, v in dict(done=done, legal=legal, obs=obs, max_exp=max_exp, n_empty=n_empty).items()}
+
+
+def hip_spawn(lib, boards, k, e):
+    n = boards.shape[0]
+    b = cu(boards)
+    placed = torch.zeros((n,), dtype=torch.uint8, device='cuda')
+    kk, ee = cu(k, torch.uint8), cu(e, torch.uint8)
+    lib.spawn(DEV, stream(), n, p(b), p(kk), p(ee), p(placed))
+    torch.cuda.synchronize()
+    return {'boards': b.cpu().numpy(), 'placed': placed.cpu().numpy()}
+
+
+def hip_reset(lib, n, seed, step_index, env_base=0):
+    b = torch.full((n, 16), 77, dtype=torch.uint8, device='cuda')
+    done = torch.full((n,), 9, dtype=torch.uint8, device='cuda')
+    lib.reset(DEV, stream(), n, env_base, p(b), p(done), seed, step_index)
+    torch.cuda.synchronize()
+    return b.cpu().numpy(), done.cpu().numpy()
+
+
+def hip_rollout(lib, boards, seed, step0, T, env_base=0, flags=0):
+    n = boards.shape[0]
+    b = cu(boards)
+    ret = torch.zeros((n,), dtype=torch.int64, device='cuda')
+    eps = torch.zeros((n,), dtype=torch.int32, device='cuda')
+    moves = torch.zeros((n,), dtype=torch.int32, device='cuda')
+    lib.rollout(DEV, stream(), n, env_base, p(b), seed, step0, T, p(ret), p(eps), p(moves), flags)
+    torch.cuda.synchronize()
+    return {'boards': b.cpu().numpy(), 'return_sum': ret.cpu().numpy(), 'episodes': eps.cpu().numpy().astype(np.uint32),
+            'valid_moves': moves.cpu().numpy().astype(np.uint32)}
+
+
+def random_boards(rng, n):
+    """Mixture that hits every branch: sparse, dense/near-terminal, big tiles, hand cases."""
+    parts = [
+        rng.integers(0, 7, size=(n // 4, 16)),
+        np.where(rng.random((n // 4, 16)) < 0.08, 0, rng.integers(1, 5, size=(n // 4, 16))),
+        np.where(rng.random((n // 4, 16)) < 0.3, 0, rng.integers(0, 18, size=(n // 4, 16))),
+        rng.integers(1, 4, size=(n - 3 * (n // 4), 16)),
+    ]
+    b = np.concatenate(parts).astype(np.uint8)
+    b[0] = 0
+    b[1] = np.arange(1, 17)
+    b[2] = 16
+    b[3] = 17
+    return b
+
+
+# ---------------------------------------------------------------------------- golden fixtures
+def test_rows_exhaustive_on_gpu(lib, golden):
+    """All 18^4 rows, each as row 0 of a board moved left AND as column 0 moved up, etc."""
+    g = golden['rows']
+    base = int(g['max_e']) + 1
+    idx = np.arange(base**4)
+    rows = np.stack([(idx // base**3) % base, (idx // base**2) % base, (idx // base) % base, idx % base], axis=1).astype(np.uint8)
+    n = rows.shape[0]
+    for action in range(4):
+        boards = np.zeros((n, 4, 4), dtype=np.uint8)
+        line = rows if action in (0, 1) else rows[:, ::-1]
+        want = g['merged'] if action in (0, 1) else g['merged'][:, ::-1]
+        if action in (0, 2):
+            boards[:, 2, :] = line
+        else:
+            boards[:, :, 1] = line
+        res = hip_afterstate(lib, boards.reshape(n, 16), np.full(n, action, dtype=np.uint8))
+        got = res['boards'].reshape(n, 4, 4)
+        got_line = got[:, 2, :] if action in (0, 2) else got[:, :, 1]
+        np.testing.assert_array_equal(got_line, want)
+        np.testing.assert_array_equal(res['reward'], g['score'])
+        np.testing.assert_array_equal(res['changed'], g['can_move'])
+        assert (got != 0).sum() == (want != 0).sum()  # nothing leaked into the other lines
+
+
+def test_afterstates_golden(lib, golden):
+    g = golden['afterstates']
+    boards = g['boards']
+    n = boards.shape[0]
+    for a in range(4):
+        res = hip_afterstate(lib, boards, np.full(n, a, dtype=np.uint8))
+        np.testing.assert_array_equal(res['boards'], g['after'][:, a])
+        np.testing.assert_array_equal(res['reward'], g['reward'][:, a])
+        np.testing.assert_array_equal(res['changed'], g['valid'][:, a])
+    st = hip_status(lib, boards)
+    np.testing.assert_array_equal(st['legal'], g['legal'])
+    np.testing.assert_array_equal(st['done'], g['done'])
+    np.testing.assert_array_equal(st['n_empty'], (boards == 0).sum(axis=1))
+    np.testing.assert_array_equal(st['max_exp'], boards.max(axis=1))
+    np.testing.assert_array_equal(st['obs'], boards.astype(np.float32) / 16.0)
+
+
+def test_next_state_golden(lib, golden):
+    """The reference's REAL next_state outputs, replayed with its spawn choice injected."""
+    g = golden['next_state']
+    after = hip_afterstate(lib, g['boards'], g['actions'])
+    moved = g['spawn_k'] != 255
+    np.testing.assert_array_equal(after['changed'].astype(bool), moved)
+    k = np.where(moved, g['spawn_k'], 200).astype(np.uint8)
+    out = hip_spawn(lib, after['boards'], k, g['spawn_e'])
+    np.testing.assert_array_equal(out['boards'], g['out'])
+    np.testing.assert_array_equal(np.where(moved, after['reward'], 0), g['reward'])
+    np.testing.assert_array_equal(hip_status(lib, out['boards'])['done'], g['done'])
+    ref = oracle.spawn_batch(after['boards'], k, g['spawn_e'])
+    np.testing.assert_array_equal(out['placed'], ref['placed'])
+
+
+@pytest.mark.parametrize('name', ['auto', 'plain'])
+def test_trajectories_golden(lib, golden, name):
+    g = golden['trajectories']
+    seed, env_base, step0 = int(g[f'{name}_seed']), int(g[f'{name}_env_base']), int(g[f'{name}_step0'])
+    flags = capi.FLAG_AUTO_RESET if int(g[f'{name}_auto_reset']) else 0
+    T, n = g[f'{name}_actions'].shape
+    boards, done = hip_reset(lib, n, seed, step0, env_base)
+    np.testing.assert_array_equal(boards, g[f'{name}_boards0'])
+    assert not done.any()
+    for t in range(T):
+        res = hip_step(lib, boards, g[f'{name}_actions'][t], seed, step0 + t, env_base=env_base, flags=flags, extras=True)
+        boards = res['boards']
+        np.testing.assert_array_equal(boards, g[f'{name}_boards'][t], err_msg=f't={t}')
+        np.testing.assert_array_equal(res['reward'], g[f'{name}_reward'][t])
+        np.testing.assert_array_equal(res['done'], g[f'{name}_done'][t])
+        np.testing.assert_array_equal(res['legal'], g[f'{name}_legal'][t])
+        np.testing.assert_array_equal(res['obs'], boards.astype(np.float32) / 16.0)
+    ro = hip_rollout(lib, g[f'{name}_boards0'], seed, step0, T, env_base, flags)
+    np.testing.assert_array_equal(ro['boards'], boards)
+    np.testing.assert_array_equal(ro['return_sum'], g[f'{name}_reward'].sum(axis=0))
+    np.testing.assert_array_equal(ro['episodes'], g[f'{name}_done'].sum(axis=0))
+
+
+def test_resets_golden(lib, golden):
+    g = golden['resets']
+    boards, done = hip_reset(lib, g['boards'].shape[0], int(g['seed']), int(g['step']), int(g['env_base']))
+    np.testing.assert_array_equal(boards, g['boards'])
+    assert not done.any()
+
+
+# ---------------------------------------------------------------------------- seeded vs oracle
+@pytest.mark.parametrize('flags', [0, capi.FLAG_AUTO_RESET, capi.FLAG_RANDOM_ACTIONS,
+                                   capi.FLAG_AUTO_RESET | capi.FLAG_RANDOM_ACTIONS])
+def test_step_matches_oracle_random_boards(lib, flags):
+    rng = np.random.default_rng(1 + flags)
+    n = 50_003  # ragged: not a multiple of the block or wave size
+    boards = random_boards(rng, n)
+    actions = rng.integers(0, 256, size=n).astype(np.uint8)  # any byte: taken mod 4
+    seed, step, env_base = 0xDEADBEEFCAFEF00D, (1 << 40) + 3, (1 << 33) + 11
+    acts = None if flags & capi.FLAG_RANDOM_ACTIONS else actions
+    got = hip_step(lib, boards, acts, seed, step, env_base=env_base, flags=flags, extras=True)
+    ref = oracle.step_batch(boards, acts, seed, step, env_base=env_base, flags=flags, want_legal=True, want_obs=True,
+                            threads=8)
+    for k in ('boards', 'reward', 'done', 'legal', 'obs'):
+        np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
+    lean = hip_step(lib, boards, acts, seed, step, env_base=env_base, flags=flags, extras=False)
+    for k in ('boards', 'reward', 'done'):
+        np.testing.assert_array_equal(lean[k], ref[k], err_msg='lean ' + k)
+
+
+def test_long_random_play_matches_oracle(lib):
+    """4096 games x 300 steps with auto-reset: every branch of real play, compared every step."""
+    n, T, seed = 4096, 300, 20480
+    boards, _ = hip_reset(lib, n, seed, 0)
+    ref_boards, _ = oracle.reset_batch(n, seed, 0, threads=8)
+    np.testing.assert_array_equal(boards, ref_boards)
+    b = cu(boards)
+    reward = torch.zeros((n,), dtype=torch.int32, device='cuda')
+    done = torch.zeros((n,), dtype=torch.uint8, device='cuda')
+    flags = capi.FLAG_AUTO_RESET | capi.FLAG_RANDOM_ACTIONS
+    episodes = 0
+    for t in range(T):
+        lib.step(DEV, stream(), n, 0, p(b), None, p(reward), p(done), None, None, seed, t, flags)
+        ref = oracle.step_batch(ref_boards, None, seed, t, flags=flags, threads=8)
+        ref_boards = ref['boards']
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(b.cpu().numpy(), ref_boards, err_msg=f't={t}')
+        np.testing.assert_array_equal(reward.cpu().numpy(), ref['reward'])
+        np.testing.assert_array_equal(done.cpu().numpy(), ref['done'])
+        episodes += int(ref['done'].sum())
+    assert episodes > n  # every env finished at least one game on average (mean length ~142)
+
+
+def test_empty_and_single(lib):
+    lib.step(DEV, stream(), 0, 0, None, None, None, None, None, None, 1, 2, 0)  # n = 0: no-op, no pointer checks
+    lib.reset(DEV, stream(), 0, 0, None, None, 1, 2)
+    one = oracle.pack_values([[2, 2, 0, 0], [0] * 4, [0] * 4, [0] * 4]).reshape(1, 16)
+    got = hip_step(lib, one, np.array([0], dtype=np.uint8), 42, 0)
+    ref = oracle.step_batch(one, [0], 42, 0)
+    np.testing.assert_array_equal(got['boards'], ref['boards'])
+    assert got['reward'][0] == 4  # tests/test_environment.py:138-149
+
+
+def test_pack_unpack_roundtrip(lib):
+    rng = np.random.default_rng(5)
+    n = 10_001
+    exps = rng.integers(0, 18, size=(n, 16)).astype(np.uint8)
+    for dtype, pack, unpack in ((torch.int32, lib.pack_i32, lib.unpack_i32), (torch.int64, lib.pack_i64, lib.unpack_i64)):
+        b = cu(exps)
+        vals = torch.zeros((n, 16), dtype=dtype, device='cuda')
+        unpack(DEV, stream(), n, p(b), p(vals))
+        back = torch.zeros_like(b)
+        pack(DEV, stream(), n, p(vals), p(back))
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(vals.cpu().numpy(), oracle.unpack_values(exps))
+        np.testing.assert_array_equal(back.cpu().numpy(), exps)
+
+
+# ---------------------------------------------------------------------------- error behaviour
+def test_error_codes(lib):
+    b = torch.zeros((8, 16), dtype=torch.uint8, device='cuda')
+    d = torch.zeros((8,), dtype=torch.uint8, device='cuda')
+    a = torch.zeros((8,), dtype=torch.uint8, device='cuda')
+    with pytest.raises(capi.Env2048Error) as e:
+        lib.step(DEV, stream(), 8, 0, p(b), None, None, p(d), None, None, 0, 0, 0)  # actions NULL without RANDOM_ACTIONS
+    assert e.value.code == capi.ERR_INVALID_ARG
+    with pytest.raises(capi.Env2048Error) as e:
+        lib.step(DEV, stream(), 8, 0, p(b) + 4, p(a), None, p(d), None, None, 0, 0, 0)
+    assert e.value.code == capi.ERR_ALIGNMENT
+    with pytest.raises(capi.Env2048Error) as e:
+        lib.step(DEV, stream(), 8, 0, p(b), p(a), None, p(d), None, None, 0, 0, 8)
+    assert e.value.code == capi.ERR_INVALID_ARG
+    with pytest.raises(capi.Env2048Error) as e:
+        lib.step(99, stream(), 8, 0, p(b), p(a), None, p(d), None, None, 0, 0, 0)
+    assert e.value.code == capi.ERR_DEVICE
+    with pytest.raises(capi.Env2048Error) as e:
+        lib.step(DEV, stream(), 8, (1 << 63), p(b), p(a), None, p(d), None, None, 0, 0, 0)
+    assert e.value.code == capi.ERR_RANGE
+
+
+# ---------------------------------------------------------------------------- full-size properties
+FULL_N = 1 << 20
+
+
+def test_full_size_slicing_invariance_and_rollout(lib):
+    """2^20 boards: two half-batches with the right env_base == the whole batch; the fused
+    rollout == T single steps; total tile mass is conserved by every non-reset step."""
+    seed, T = 0x2048, 24
+    flags = capi.FLAG_AUTO_RESET | capi.FLAG_RANDOM_ACTIONS
+    whole = torch.zeros((FULL_N, 16), dtype=torch.uint8, device='cuda')
+    lib.reset(DEV, stream(), FULL_N, 0, p(whole), None, seed, 0)
+    start = whole.clone()
+    reward = torch.zeros((FULL_N,), dtype=torch.int32, device='cuda')
+    done = torch.zeros((FULL_N,), dtype=torch.uint8, device='cuda')
+    total = torch.zeros((FULL_N,), dtype=torch.int64, device='cuda')
+    episodes = torch.zeros((FULL_N,), dtype=torch.int64, device='cuda')
+    pow2 = torch.tensor([0] + [1 << e for e in range(1, 32)], dtype=torch.int64, device='cuda')
+    for t in range(T):
+        mass_before = pow2[whole.long()].sum(dim=1)
+        lib.step(DEV, stream(), FULL_N, 0, p(whole), None, p(reward), p(done), None, None, seed, t, flags)
+        mass_after = pow2[whole.long()].sum(dim=1)
+        grew = mass_after - mass_before
+        live = done == 0
+        # a valid move adds exactly one tile of value 2 or 4; an invalid one adds nothing
+        assert bool(((grew[live] == 0) | (grew[live] == 2) | (grew[live] == 4)).all())
+        total += reward
+        episodes += done
+    # halves
+    half = FULL_N // 2
+    for lo in (0, half):
+        part = start[lo:lo + half].clone()
+        r2 = torch.zeros((half,), dtype=torch.int32, device='cuda')
+        d2 = torch.zeros((half,), dtype=torch.uint8, device='cuda')
+        for t in range(T):
+            lib.step(DEV, stream(), half, lo, p(part), None, p(r2), p(d2), None, None, seed, t, flags)
+        assert torch.equal(part, whole[lo:lo + half])
+    # fused rollout
+    ro = start.clone()
+    ret = torch.zeros((FULL_N,), dtype=torch.int64, device='cuda')
+    eps = torch.zeros((FULL_N,), dtype=torch.int32, device='cuda')
+    lib.rollout(DEV, stream(), FULL_N, 0, p(ro), seed, 0, T, p(ret), p(eps), None, flags)
+    torch.cuda.synchronize()
+    assert torch.equal(ro, whole)
+    assert torch.equal(ret, total)
+    assert torch.equal(eps.long(), episodes)
+
+
+def test_full_size_checksum_vs_oracle(lib):
+    """2^20 boards x 3 steps: byte-exact against the (OpenMP) oracle."""
+    seed = 77
+    flags = capi.FLAG_AUTO_RESET | capi.FLAG_RANDOM_ACTIONS
+    ref_boards, _ = oracle.reset_batch(FULL_N, seed, 0, threads=16)
+    b = torch.zeros((FULL_N, 16), dtype=torch.uint8, device='cuda')
+    lib.reset(DEV, stream(), FULL_N, 0, p(b), None, seed, 0)
+    reward = torch.zeros((FULL_N,), dtype=torch.int32, device='cuda')
+    done = torch.zeros((FULL_N,), dtype=torch.uint8, device='cuda')
+    # warm the boards into mid-game with the fused rollout on both sides
+    lib.rollout(DEV, stream(), FULL_N, 0, p(b), seed, 0, 100, None, None, None, flags)
+    ref_boards = oracle.rollout_batch(ref_boards, seed, 0, 100, flags=flags, threads=16)['boards']
+    for t in range(100, 103):
+        lib.step(DEV, stream(), FULL_N, 0, p(b), None, p(reward), p(done), None, None, seed, t, flags)
+        ref = oracle.step_batch(ref_boards, None, seed, t, flags=flags, threads=16)
+        ref_boards = ref['boards']
+        torch.cuda.synchronize()
+        assert np.array_equal(b.cpu().numpy(), ref_boards)
+        assert np.array_equal(reward.cpu().numpy(), ref['reward'])
+        assert np.array_equal(done.cpu().numpy(), ref['done'])
