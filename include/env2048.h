@@ -27,14 +27,19 @@
  *
  * RNG contract (build-defined; the reference's PCG64 / threefry bitstreams are not part of its
  * tested behaviour): Philox4x32-10, key = (seed_lo, seed_hi),
- * counter = (env_lo, step_lo, step_hi, stream + 2*env_hi) where env = env_base + i is the GLOBAL
- * environment index, so results do not depend on how a batch is sliced across GPUs.
- *   stream 0 ("step block") words (r0,r1,r2,r3):
- *       spawn cell  k = floor(r0 * n_empty / 2^32)  -> k-th empty cell in row-major order
- *       spawn tile  4 (e=2) iff r1 < 429496729 (= floor(0.1 * 2^32)), else 2 (e=1)
- *       r2 & 3      the on-device random action (ENV2048_FLAG_RANDOM_ACTIONS, env2048_rollout)
- *   stream 1 ("reset block"): (r0,r1) first spawn among 16 empties, (r2,r3) second spawn among
- *       the remaining 15 -- two sequential single spawns on an empty board.
+ * counter = (index_lo, step_lo, step_hi, stream + 2*index_hi).  env = env_base + i is always the
+ * GLOBAL environment index, so results do not depend on how a batch is sliced across GPUs.
+ *   stream 0 ("step words"): index = env >> 2 -- one Philox block serves four neighbouring
+ *       environments; environment env owns word w = block[env & 3]:
+ *           w & 3                      the on-device random action (RANDOM_ACTIONS, rollout)
+ *           m = w & ~3, P = m * n_empty (64-bit)
+ *           spawn cell  k = P >> 32    -> k-th empty cell in row-major order (uniform)
+ *           spawn tile  4 (e=2) iff (P mod 2^32) < 429496729 (= floor(0.1 * 2^32)), else 2 (e=1)
+ *       (P mod 2^32 is the arithmetic-decoding remainder: uniform again and independent of k.)
+ *   stream 1 ("reset block"): index = env, words (r0,r1,r2,r3):
+ *       first spawn  cell r0 >> 28 (of 16 empties),               tile 4 iff r1 < 429496729
+ *       second spawn cell floor(r2 * 15 / 2^32) among the other 15, tile 4 iff r3 < 429496729
+ *       -- two sequential single spawns on an empty board.
  */
 #ifndef ENV2048_H
 #define ENV2048_H
@@ -62,7 +67,7 @@ extern "C" {
 
 /* step / rollout flags */
 #define ENV2048_FLAG_AUTO_RESET 1u     /* a board that became terminal is replaced by a fresh one */
-#define ENV2048_FLAG_RANDOM_ACTIONS 2u /* ignore `actions`; use r2 & 3 of the step block */
+#define ENV2048_FLAG_RANDOM_ACTIONS 2u /* ignore `actions`; use the low two bits of the step word */
 
 ENV2048_EXPORT int env2048_abi_version(void);
 ENV2048_EXPORT const char *env2048_last_error(void);
@@ -71,7 +76,7 @@ ENV2048_EXPORT int env2048_device_count(void);
 
 /*
  * Fresh boards: zeros + two spawned tiles.  Writes boards[i] for i in [0,n) and, if non-NULL,
- * done[i] = 0.  Uses the stream-1 block of (env_base + i, step_index).
+ * done[i] = 0.  Uses the stream-1 (reset) block of (env_base + i, step_index).
  * [replaces: twentyfortyeight/envs/twentyfortyeight.py:84-104 reset;
  *            reinforce/game/core.py:324-343 create_initial_board; reinforce/game/env.py:55-76 reset,
  *            :176-190 batched_reset]
@@ -104,7 +109,7 @@ ENV2048_EXPORT int env2048_step(int device, void *stream, uint64_t n, uint64_t e
 
 /*
  * T consecutive transitions per board, boards held in registers, actions drawn on device
- * (r2 & 3 of each step block): identical to T calls of env2048_step(..., step0 + t,
+ * (low two bits of each step word): identical to T calls of env2048_step(..., step0 + t,
  * flags | RANDOM_ACTIONS).  Per-environment outputs (each may be NULL):
  *     return_sum[i]  int64 sum of rewards      episodes[i]  number of transitions with done = 1
  *     valid_moves[i] number of transitions that changed the board

@@ -55,14 +55,30 @@ ORACLE_API void oracle_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-/* Counter scheme (DESIGN.md "RNG contract"): key = seed, counter = (env_lo, step_lo, step_hi,
- * stream + 2*env_hi); stream 0 = step block, stream 1 = reset block. */
-static void env_block(uint64_t seed, uint64_t env, uint64_t step, uint32_t stream, uint32_t out[4])
+/* Counter scheme (DESIGN.md "RNG contract"): key = seed, counter = (index_lo, step_lo, step_hi,
+ * stream + 2*index_hi).
+ *   stream 0 ("step words"):  index = env >> 2; environment env owns word (env & 3) of the block,
+ *                             so one Philox block serves four neighbouring environments.
+ *   stream 1 ("reset block"): index = env; all four words belong to that environment. */
+static void env_block(uint64_t seed, uint64_t index, uint64_t step, uint32_t stream, uint32_t out[4])
 {
-    uint32_t ctr[4] = { (uint32_t)env, (uint32_t)step, (uint32_t)(step >> 32),
-                        stream + 2u * (uint32_t)(env >> 32) };
+    uint32_t ctr[4] = { (uint32_t)index, (uint32_t)step, (uint32_t)(step >> 32),
+                        stream + 2u * (uint32_t)(index >> 32) };
     uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
     oracle_philox4x32_10(ctr, key, out);
+}
+
+/* The one 32-bit word environment `env` draws at `step`. */
+static uint32_t step_word(uint64_t seed, uint64_t env, uint64_t step)
+{
+    uint32_t blk[4];
+    env_block(seed, env >> 2, step, 0u, blk);
+    return blk[env & 3u];
+}
+
+ORACLE_API uint32_t oracle_step_word(uint64_t seed, uint64_t env, uint64_t step)
+{
+    return step_word(seed, env, step);
 }
 
 ORACLE_API void oracle_env_block(uint64_t seed, uint64_t env, uint64_t step, uint32_t stream, uint32_t out[4])
@@ -229,8 +245,9 @@ ORACLE_API int oracle_fill_cell_kv(uint8_t board[16], int k, uint8_t e)
     return -1;
 }
 
-/* Build contract for turning two Philox words into a spawn:
- * k = floor(r_cell * n_empty / 2^32), exponent 2 iff r_val < SPAWN4_THRESHOLD else 1. */
+/* Build contract for turning Philox words into a spawn.
+ * Two-word form (reset block): k = floor(r_cell * n_empty / 2^32), exponent 2 iff
+ * r_val < SPAWN4_THRESHOLD else 1. */
 static inline int spawn_rank(uint32_t r_cell, int n_empty)
 {
     return (int)(((uint64_t)r_cell * (uint64_t)n_empty) >> 32);
@@ -244,6 +261,18 @@ ORACLE_API void oracle_spawn_from_words(uint32_t r_cell, uint32_t r_val, int n_e
 {
     *k = spawn_rank(r_cell, n_empty);
     *e = spawn_exponent(r_val);
+}
+
+/* One-word form (step word w): the low two bits are the on-device random action; with
+ * m = w & ~3 and the 64-bit product P = m * n_empty, the cell rank is k = P >> 32 (uniform over
+ * the empties) and the residual P mod 2^32 -- uniform again, the arithmetic-decoding remainder --
+ * decides the tile: exponent 2 iff (P mod 2^32) < SPAWN4_THRESHOLD. */
+ORACLE_API void oracle_spawn_from_word(uint32_t w, int n_empty, int *k, int *e, int *action)
+{
+    uint64_t prod = (uint64_t)(w & ~3u) * (uint64_t)n_empty;
+    *k = (int)(prod >> 32);
+    *e = ((uint32_t)prod < SPAWN4_THRESHOLD) ? 2 : 1;
+    *action = (int)(w & 3u);
 }
 
 /* Fresh board: two sequential single spawns on the empty board
@@ -265,7 +294,7 @@ ORACLE_API void oracle_reset_board(uint64_t seed, uint64_t env, uint64_t step, u
  *  With FLAG_AUTO_RESET a terminal board is replaced by a fresh one (done still reports 1).
  *  action is taken mod 4, as rot90 does (gameboard.py:316). */
 static int64_t step_one(uint8_t board[16], int action, uint64_t seed, uint64_t env, uint64_t step,
-                        uint32_t flags, const uint32_t blk[4], int *done_out, int *changed_out)
+                        uint32_t flags, uint32_t word, int *done_out, int *changed_out)
 {
     uint8_t rotated[16];
     int64_t reward = 0;
@@ -276,8 +305,9 @@ static int64_t step_one(uint8_t board[16], int action, uint64_t seed, uint64_t e
         uint8_t updated[16];
         reward = oracle_slide_and_merge(rotated, updated);       /* :319 */
         oracle_rot90(updated, -action, board);                   /* :320 */
-        int n_empty = oracle_count_empty(board);
-        oracle_fill_cell_kv(board, spawn_rank(blk[0], n_empty), spawn_exponent(blk[1])); /* :323 */
+        int k, e, unused;
+        oracle_spawn_from_word(word, oracle_count_empty(board), &k, &e, &unused);
+        oracle_fill_cell_kv(board, k, (uint8_t)e);               /* :323 fill_cells(number_tile=1) */
         changed = 1;
     }                                                            /* :325 else: state, 0 */
     int done = oracle_is_done(board);                            /* twentyfortyeight.py:133 */
@@ -308,11 +338,10 @@ ORACLE_API int oracle_step_batch(uint64_t n, uint64_t env_base, uint8_t *boards,
 #endif
     for (int64_t i = 0; i < (int64_t)n; ++i) {
         uint8_t *b = boards + 16 * (size_t)i;
-        uint32_t blk[4];
-        env_block(seed, env_base + (uint64_t)i, step_index, 0u, blk);
-        int action = (flags & FLAG_RANDOM_ACTIONS) ? (int)(blk[2] & 3u) : (int)actions[i];
+        uint32_t w = step_word(seed, env_base + (uint64_t)i, step_index);
+        int action = (flags & FLAG_RANDOM_ACTIONS) ? (int)(w & 3u) : (int)actions[i];
         int d = 0;
-        int64_t r = step_one(b, action, seed, env_base + (uint64_t)i, step_index, flags, blk, &d, NULL);
+        int64_t r = step_one(b, action, seed, env_base + (uint64_t)i, step_index, flags, w, &d, NULL);
         if (reward) reward[i] = (int32_t)r;
         if (done) done[i] = (uint8_t)d;
         if (legal) legal[i] = oracle_legal_actions_mask(b);
@@ -335,7 +364,7 @@ ORACLE_API int oracle_reset_batch(uint64_t n, uint64_t env_base, uint8_t *boards
     return 0;
 }
 
-/* T consecutive steps with on-device-style random actions (r2 & 3 of each step block). */
+/* T consecutive steps with on-device-style random actions (low two bits of each step word). */
 ORACLE_API int oracle_rollout_batch(uint64_t n, uint64_t env_base, uint8_t *boards, uint64_t seed,
                                     uint64_t step0, uint32_t T, int64_t *return_sum, uint32_t *episodes,
                                     uint32_t *valid_moves, uint32_t flags, int threads)
@@ -349,11 +378,10 @@ ORACLE_API int oracle_rollout_batch(uint64_t n, uint64_t env_base, uint8_t *boar
         int64_t ret = 0;
         uint32_t eps = 0, moves = 0;
         for (uint32_t t = 0; t < T; ++t) {
-            uint32_t blk[4];
             uint64_t step = step0 + t;
-            env_block(seed, env_base + (uint64_t)i, step, 0u, blk);
+            uint32_t w = step_word(seed, env_base + (uint64_t)i, step);
             int d = 0, ch = 0;
-            ret += step_one(b, (int)(blk[2] & 3u), seed, env_base + (uint64_t)i, step, flags, blk, &d, &ch);
+            ret += step_one(b, (int)(w & 3u), seed, env_base + (uint64_t)i, step, flags, w, &d, &ch);
             eps += (uint32_t)d;
             moves += (uint32_t)ch;
         }

@@ -196,12 +196,16 @@ def gen_next_state(rng):
 # ------------------------------------------------------------------------------------------------
 # Reference engine driven by the build's Philox contract (injected spawns)
 # ------------------------------------------------------------------------------------------------
-def ref_spawn(state: np.ndarray, r_cell: int, r_val: int) -> np.ndarray:
-    """One spawn through after_state_lazy/generate_outcome with (k, e) from two Philox words."""
+def ref_spawn(state: np.ndarray, r_cell: int, r_val: int | None = None) -> np.ndarray:
+    """One spawn through after_state_lazy/generate_outcome with (k, e) from Philox words:
+    two words (reset block) or, with r_val None, the one-word step form."""
     base, cells, n_empty = ref_board.after_state_lazy(state)
     if n_empty == 0:
         return state
-    k, e = oracle.spawn_from_words(r_cell, r_val, n_empty)
+    if r_val is None:
+        k, e, _ = oracle.spawn_from_word(r_cell, n_empty)
+    else:
+        k, e = oracle.spawn_from_words(r_cell, r_val, n_empty)
     new_state, _ = ref_board.generate_outcome(base, cells[k], 1 << e, n_empty)
     return new_state
 
@@ -214,13 +218,13 @@ def ref_reset(seed: int, env: int, step: int) -> np.ndarray:
     return state
 
 
-def ref_step(state: np.ndarray, action: int, blk) -> tuple[np.ndarray, int]:
+def ref_step(state: np.ndarray, action: int, word: int) -> tuple[np.ndarray, int]:
     """next_state's control flow (gameboard.py:316-325) with the spawn injected."""
     rotated = np.rot90(state, k=action)
     if ref_move.can_move(rotated):
         reward, updated = ref_board.slide_and_merge(rotated)
         new_state = np.rot90(updated, k=-action)
-        new_state = ref_spawn(new_state, int(blk[0]), int(blk[1]))
+        new_state = ref_spawn(new_state, word)
         return new_state, int(reward)
     return state, 0
 
@@ -228,7 +232,7 @@ def ref_step(state: np.ndarray, action: int, blk) -> tuple[np.ndarray, int]:
 def gen_trajectories():
     sets = {}
     for name, seed, env_base, n_env, T, auto_reset, step0 in [
-        ('auto', 0x2048, 1000, 40, 420, 1, 7),
+        ('auto', 0x2048, 1001, 40, 420, 1, 7),  # odd env_base: Philox groups straddle the batch edge
         ('plain', 0xC0FFEE, (1 << 32) + 5, 16, 420, 0, 0),  # env index above 2^32 exercises env_hi
     ]:
         boards0 = np.zeros((n_env, 16), dtype=np.uint8)
@@ -243,9 +247,9 @@ def gen_trajectories():
             boards0[j] = to_exps(state).reshape(16)
             for t in range(T):
                 step = step0 + t
-                blk = oracle.env_block(seed, env, step, 0)
-                a = int(blk[2]) & 3
-                state, r = ref_step(state, a, blk)
+                word = oracle.step_word(seed, env, step)
+                a = word & 3
+                state, r = ref_step(state, a, word)
                 d = bool(ref_board.is_done(state))
                 if d and auto_reset:
                     state = ref_reset(seed, env, step)

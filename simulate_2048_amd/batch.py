@@ -97,7 +97,7 @@ class BatchedEnv2048:
         """One transition per board, in place; asynchronous on torch's current stream.
 
         ``actions``: uint8 tensor (N,) on the same device, values taken mod 4 (0 left, 1 up,
-        2 right, 3 down); ``None`` draws uniform random actions on device from the step block.
+        2 right, 3 down); ``None`` draws uniform random actions on device (low two bits of each step word).
         Returns ``(boards, reward, done)`` -- views of the persistent buffers.
         """
         flags = self.flags

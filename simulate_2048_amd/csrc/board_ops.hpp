@@ -8,8 +8,37 @@
 // [ref: file:lines] relative to the reference repo root.
 #pragma once
 
-#include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#if defined(ENV2048_HOST_EMULATION)
+// CPU build of the SAME per-board arithmetic, used only by tests/host_emu to unit-test the SWAR
+// logic against the oracle (and under -fsanitize) without a GPU.  Not a product path.
+#define ENV2048_DEV static inline
+namespace env2048 {
+static inline uint32_t emu_perm(uint32_t hi, uint32_t lo, uint32_t sel)
+{
+    const uint64_t src = ((uint64_t)hi << 32) | lo;
+    uint32_t out = 0;
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t s = (sel >> (8 * i)) & 0xFFu;
+        const uint32_t byte = s < 8 ? (uint32_t)((src >> (8 * s)) & 0xFFu) : (s == 0x0Cu ? 0u : 0xFFu);
+        out |= byte << (8 * i);
+    }
+    return out;
+}
+}  // namespace env2048
+#define ENV2048_PERM(hi, lo, sel) env2048::emu_perm(hi, lo, sel)
+#define ENV2048_POPC(x) ((uint32_t)__builtin_popcount(x))
+#define ENV2048_UMULHI(a, b) ((uint32_t)(((uint64_t)(a) * (uint64_t)(b)) >> 32))
+#define ENV2048_FFS(x) (__builtin_ffs((int)(x)))
+#else
+#include <hip/hip_runtime.h>
+#define ENV2048_DEV __device__ __forceinline__
+#define ENV2048_PERM(hi, lo, sel) __builtin_amdgcn_perm(hi, lo, sel)
+#define ENV2048_POPC(x) ((uint32_t)__popc(x))
+#define ENV2048_UMULHI(a, b) __umulhi(a, b)
+#define ENV2048_FFS(x) (__ffs((int)(x)))
+#endif
 
 namespace env2048 {
 
@@ -30,27 +59,27 @@ struct Board {
 };
 
 // v_perm_b32: selector byte 0-3 picks a byte of `lo`, 4-7 a byte of `hi`.
-__device__ __forceinline__ uint32_t byte_perm(uint32_t hi, uint32_t lo, uint32_t sel)
+ENV2048_DEV uint32_t byte_perm(uint32_t hi, uint32_t lo, uint32_t sel)
 {
-    return __builtin_amdgcn_perm(hi, lo, sel);
+    return ENV2048_PERM(hi, lo, sel);
 }
 
 // (a & m) | (b & ~m) -- one v_bfi_b32.
-__device__ __forceinline__ uint32_t bsel(uint32_t m, uint32_t a, uint32_t b)
+ENV2048_DEV uint32_t bsel(uint32_t m, uint32_t a, uint32_t b)
 {
     return (a & m) | (b & ~m);
 }
 
 // 0x7F in every byte of x that is non-zero, 0x00 elsewhere.  Bytes must be <= 0x80 (exponents
 // are <= 31), so the per-byte add never carries into its neighbour.
-__device__ __forceinline__ uint32_t nz7(uint32_t x)
+ENV2048_DEV uint32_t nz7(uint32_t x)
 {
     uint32_t f = (x + K7F) & K80;
     return f - (f >> 7);
 }
 
 // 4x4 byte transpose: rows <-> columns.
-__device__ __forceinline__ void transpose4x4(uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, uint32_t &c0,
+ENV2048_DEV void transpose4x4(uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, uint32_t &c0,
                                              uint32_t &c1, uint32_t &c2, uint32_t &c3)
 {
     uint32_t t0 = byte_perm(r1, r0, 0x05010400u);  // r0[0] r1[0] r0[1] r1[1]
@@ -68,7 +97,7 @@ __device__ __forceinline__ void transpose4x4(uint32_t r0, uint32_t r1, uint32_t 
 // tile VALUES over the four lines).
 // [ref: twentyfortyeight/core/gameboard.py:23-69 merge_column, :72-102 slide_and_merge;
 //       reinforce/game/core.py:32-101 _compact_row/merge_row]
-__device__ __forceinline__ uint32_t slide_merge_planes(uint32_t &a, uint32_t &b, uint32_t &c, uint32_t &d)
+ENV2048_DEV uint32_t slide_merge_planes(uint32_t &a, uint32_t &b, uint32_t &c, uint32_t &d)
 {
     uint32_t na = nz7(a), nb = nz7(b), nc = nz7(c), nd = nz7(d);
 
@@ -113,7 +142,7 @@ __device__ __forceinline__ uint32_t slide_merge_planes(uint32_t &a, uint32_t &b,
 
     // score = sum over merged cells of 2^exponent.  Summing 1 << byte over all eight bytes adds
     // a spurious 1 for every byte without a merge; take those back out.
-    uint32_t n_merged = __popc(x_ab | x_bc) + __popc(x_cd);
+    uint32_t n_merged = ENV2048_POPC(x_ab | x_bc) + ENV2048_POPC(x_cd);
     uint32_t s = n_merged - 8u;
     s += 1u << (v1 & 0xFFu);
     s += 1u << ((v1 >> 8) & 0xFFu);
@@ -131,7 +160,7 @@ __device__ __forceinline__ uint32_t slide_merge_planes(uint32_t &a, uint32_t &b,
 // board so that every move becomes "left"; here up/down use the row dwords as planes directly and
 // left/right use the transposed board, with the plane order reversed for right/down.
 // `changed` == can_move(rot90(board, action)) [ref: twentyfortyeight/core/gamemove.py:132-164].
-__device__ __forceinline__ void afterstate(Board &bd, uint32_t action, uint32_t &score, bool &changed)
+ENV2048_DEV void afterstate(Board &bd, uint32_t action, uint32_t &score, bool &changed)
 {
     uint32_t t0, t1, t2, t3;
     transpose4x4(bd.r0, bd.r1, bd.r2, bd.r3, t0, t1, t2, t3);
@@ -160,8 +189,47 @@ __device__ __forceinline__ void afterstate(Board &bd, uint32_t action, uint32_t 
     bd.r3 = horizontal ? u3 : y3;
 }
 
+// v_perm_b32 selectors that turn the four row dwords into the four planes of a move and back,
+// one 8-dword record per action: {fA, fB, fC, fD, iA, iB, iC, iD}.
+//   forward:  t0 = perm(r1,r0,fA)  t2 = perm(r3,r2,fA)  t1 = perm(r1,r0,fB)  t3 = perm(r3,r2,fB)
+//             p0 = perm(t2,t0,fC)  p2 = perm(t2,t0,fD)  p1 = perm(t3,t1,fC)  p3 = perm(t3,t1,fD)
+//   inverse:  the same network with the i* selectors maps planes q0..q3 back to rows.
+// up/down pass dwords through (identity / reversed order); left/right transpose the 4x4 bytes,
+// right additionally reversing the plane order.  Kernels keep this table in LDS and fetch the
+// record of each lane's action with two ds_read_b128 -- no per-direction branch or select.
+#define ENV2048_DIR_SELECTOR_VALUES                                                                              \
+    /* 0 left  */ 0x06020400u, 0x07030501u, 0x05040100u, 0x07060302u, 0x06020400u, 0x07030501u, 0x05040100u, 0x07060302u, \
+    /* 1 up    */ 0x03020100u, 0x07060504u, 0x03020100u, 0x07060504u, 0x03020100u, 0x07060504u, 0x03020100u, 0x07060504u, \
+    /* 2 right */ 0x05010703u, 0x04000602u, 0x05040100u, 0x07060302u, 0x02060004u, 0x03070105u, 0x01000504u, 0x03020706u, \
+    /* 3 down  */ 0x07060504u, 0x03020100u, 0x07060504u, 0x03020100u, 0x07060504u, 0x03020100u, 0x07060504u, 0x03020100u
+constexpr uint32_t DIR_SELECTORS[32] = {ENV2048_DIR_SELECTOR_VALUES};
+
+struct DirSelectors {
+    uint32_t fA, fB, fC, fD, iA, iB, iC, iD;
+};
+
+// Same result as afterstate(), with the direction handled by per-lane selectors.
+ENV2048_DEV void afterstate_sel(Board &bd, const DirSelectors &s, uint32_t &score, bool &changed)
+{
+    uint32_t t0 = byte_perm(bd.r1, bd.r0, s.fA), t2 = byte_perm(bd.r3, bd.r2, s.fA);
+    uint32_t t1 = byte_perm(bd.r1, bd.r0, s.fB), t3 = byte_perm(bd.r3, bd.r2, s.fB);
+    const uint32_t p0 = byte_perm(t2, t0, s.fC), p2 = byte_perm(t2, t0, s.fD);
+    const uint32_t p1 = byte_perm(t3, t1, s.fC), p3 = byte_perm(t3, t1, s.fD);
+    uint32_t q0 = p0, q1 = p1, q2 = p2, q3 = p3;
+    score = slide_merge_planes(q0, q1, q2, q3);
+    changed = (((q0 ^ p0) | (q1 ^ p1)) | ((q2 ^ p2) | (q3 ^ p3))) != 0u;
+    t0 = byte_perm(q1, q0, s.iA);
+    t2 = byte_perm(q3, q2, s.iA);
+    t1 = byte_perm(q1, q0, s.iB);
+    t3 = byte_perm(q3, q2, s.iB);
+    bd.r0 = byte_perm(t2, t0, s.iC);
+    bd.r2 = byte_perm(t2, t0, s.iD);
+    bd.r1 = byte_perm(t3, t1, s.iC);
+    bd.r3 = byte_perm(t3, t1, s.iD);
+}
+
 // Bit (8*c + 7 - r) set <=> cell (r, c) is EMPTY.
-__device__ __forceinline__ uint32_t empty_mask(const Board &bd)
+ENV2048_DEV uint32_t empty_mask(const Board &bd)
 {
     uint32_t y0 = bd.r0 + K7F, y1 = bd.r1 + K7F, y2 = bd.r2 + K7F, y3 = bd.r3 + K7F;
     uint32_t occ = (y0 & 0x80808080u) | ((y1 >> 1) & 0x40404040u) | ((y2 >> 2) & 0x20202020u) |
@@ -172,12 +240,12 @@ __device__ __forceinline__ uint32_t empty_mask(const Board &bd)
 // Keep only the k-th set bit of an empty_mask, counting cells in row-major order -- the order of
 // argwhere(state == 0) [ref: gameboard.py:275,287; reinforce/game/core.py:206-213].  Four rounds
 // of "is it in the first half of what is left?" (rows 0-1 | row 0/2 | columns 0-1 | column 0/2).
-__device__ __forceinline__ uint32_t kth_empty(uint32_t m, uint32_t k)
+ENV2048_DEV uint32_t kth_empty(uint32_t m, uint32_t k)
 {
 #define ENV2048_HALVE(FIRST)                \
     {                                       \
         uint32_t lo = m & (FIRST);          \
-        uint32_t cnt = __popc(lo);          \
+        uint32_t cnt = ENV2048_POPC(lo);          \
         bool beyond = k >= cnt;             \
         m = beyond ? (m ^ lo) : lo;         \
         k = beyond ? k - cnt : k;           \
@@ -191,7 +259,7 @@ __device__ __forceinline__ uint32_t kth_empty(uint32_t m, uint32_t k)
 }
 
 // OR (1 << shift) into the cell selected by a one-bit empty_mask (no-op for cell_bit == 0).
-__device__ __forceinline__ void place_tile(Board &bd, uint32_t cell_bit, uint32_t shift)
+ENV2048_DEV void place_tile(Board &bd, uint32_t cell_bit, uint32_t shift)
 {
     bd.r0 |= ((cell_bit >> 7) & K01) << shift;
     bd.r1 |= ((cell_bit >> 6) & K01) << shift;
@@ -200,21 +268,21 @@ __device__ __forceinline__ void place_tile(Board &bd, uint32_t cell_bit, uint32_
 }
 
 // Flat row-major index (4*r + c) of the cell a one-bit empty_mask selects.
-__device__ __forceinline__ uint32_t cell_index(uint32_t cell_bit)
+ENV2048_DEV uint32_t cell_index(uint32_t cell_bit)
 {
-    uint32_t pos = (uint32_t)__ffs((int)cell_bit) - 1u;  // 8*c + 7 - r
+    uint32_t pos = (uint32_t)ENV2048_FFS(cell_bit) - 1u;  // 8*c + 7 - r
     return 4u * (7u - (pos & 7u)) + (pos >> 3);
 }
 
-__device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) { return __umulhi(a, b); }
+ENV2048_DEV uint32_t mulhi32(uint32_t a, uint32_t b) { return ENV2048_UMULHI(a, b); }
 
 // Spawn one tile from two Philox words [ref: gameboard.py:247-288 fill_cells with number_tile=1;
 // reinforce/game/core.py:173-231]: uniform over the empty cells, tile 4 with probability 0.1.
 // `enable` false leaves the board untouched (invalid move: no spawn, gameboard.py:325).
-__device__ __forceinline__ uint32_t spawn_tile(Board &bd, uint32_t w_cell, uint32_t w_val, bool enable)
+ENV2048_DEV uint32_t spawn_tile(Board &bd, uint32_t w_cell, uint32_t w_val, bool enable)
 {
     uint32_t empt = empty_mask(bd);
-    uint32_t n_empty = __popc(empt);
+    uint32_t n_empty = ENV2048_POPC(empt);
     uint32_t k = mulhi32(w_cell, n_empty);
     uint32_t bit = kth_empty(empt, k);
     bit = enable ? bit : 0u;
@@ -222,9 +290,24 @@ __device__ __forceinline__ uint32_t spawn_tile(Board &bd, uint32_t w_cell, uint3
     return n_empty - (enable ? 1u : 0u);  // empties left on the board
 }
 
+// Spawn one tile from ONE step word w (RNG contract, include/env2048.h): with m = w & ~3 and the
+// 64-bit product P = m * n_empty, the cell rank is k = P >> 32 and the tile is 4 iff
+// (P mod 2^32) < SPAWN4_THRESHOLD.  Same distribution as fill_cells(number_tile=1)
+// [ref: gameboard.py:247-288]: uniform over the empty cells, P(4) = 0.1.
+ENV2048_DEV uint32_t spawn_tile_word(Board &bd, uint32_t w, bool enable)
+{
+    const uint32_t empt = empty_mask(bd);
+    const uint32_t n_empty = ENV2048_POPC(empt);
+    const uint64_t prod = (uint64_t)(w & ~3u) * (uint64_t)n_empty;
+    uint32_t bit = kth_empty(empt, (uint32_t)(prod >> 32));
+    bit = enable ? bit : 0u;
+    place_tile(bd, bit, ((uint32_t)prod < SPAWN4_THRESHOLD) ? 1u : 0u);
+    return n_empty - (enable ? 1u : 0u);  // empties left on the board
+}
+
 // Fresh board: two sequential single spawns on an empty board, from one reset block
 // [ref: twentyfortyeight/envs/twentyfortyeight.py:100-101; reinforce/game/core.py:339-342].
-__device__ __forceinline__ Board fresh_board(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3)
+ENV2048_DEV Board fresh_board(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3)
 {
     uint32_t cell1 = w0 >> 28;            // floor(w0 * 16 / 2^32)
     uint32_t k2 = mulhi32(w2, 15u);       // rank among the 15 cells still empty
@@ -242,7 +325,7 @@ __device__ __forceinline__ Board fresh_board(uint32_t w0, uint32_t w1, uint32_t 
 
 // True iff no two horizontally or vertically adjacent cells are equal.  Only meaningful as a
 // terminal test together with "board is full" [ref: gameboard.py:346-348 is_done].
-__device__ __forceinline__ bool no_equal_neighbours(const Board &bd)
+ENV2048_DEV bool no_equal_neighbours(const Board &bd)
 {
     // bit 7 of a byte of (x + K7F) is set iff that byte of x is non-zero, i.e. the pair differs
     uint32_t h = ((bd.r0 ^ (bd.r0 >> 8)) + K7F) & ((bd.r1 ^ (bd.r1 >> 8)) + K7F) &
@@ -254,7 +337,7 @@ __device__ __forceinline__ bool no_equal_neighbours(const Board &bd)
 
 // Legal-action bitmask (bit a <=> action a changes the board) and the two "mergeable pair"
 // facts, from adjacency alone [ref: twentyfortyeight/core/gamemove.py:45-83 legal_actions_mask].
-__device__ __forceinline__ uint32_t legal_mask(const Board &bd)
+ENV2048_DEV uint32_t legal_mask(const Board &bd)
 {
     uint32_t f0 = (bd.r0 + K7F) & K80, f1 = (bd.r1 + K7F) & K80;  // non-zero flags
     uint32_t f2 = (bd.r2 + K7F) & K80, f3 = (bd.r3 + K7F) & K80;
@@ -278,16 +361,16 @@ __device__ __forceinline__ uint32_t legal_mask(const Board &bd)
     return legal;
 }
 
-__device__ __forceinline__ uint32_t count_empty(const Board &bd) { return __popc(empty_mask(bd)); }
+ENV2048_DEV uint32_t count_empty(const Board &bd) { return ENV2048_POPC(empty_mask(bd)); }
 
 // Philox4x32-10 (Salmon et al. 2011).  Key schedule is wave-uniform and stays in SGPRs.
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+ENV2048_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                               uint32_t k1, uint32_t &o0, uint32_t &o1, uint32_t &o2, uint32_t &o3)
 {
 #pragma unroll
     for (int round = 0; round < 10; ++round) {
-        uint32_t hi0 = __umulhi(PHILOX_M0, c0), lo0 = PHILOX_M0 * c0;
-        uint32_t hi1 = __umulhi(PHILOX_M1, c2), lo1 = PHILOX_M1 * c2;
+        uint32_t hi0 = ENV2048_UMULHI(PHILOX_M0, c0), lo0 = PHILOX_M0 * c0;
+        uint32_t hi1 = ENV2048_UMULHI(PHILOX_M1, c2), lo1 = PHILOX_M1 * c2;
         c0 = hi1 ^ c1 ^ k0;
         c1 = lo1;
         c2 = hi0 ^ c3 ^ k1;
@@ -301,26 +384,32 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     o3 = c3;
 }
 
-// RNG contract (include/env2048.h): key = seed, counter = (env_lo, step_lo, step_hi,
-// stream + 2*env_hi) with env the GLOBAL environment index.
+// RNG contract (include/env2048.h): key = seed, counter = (index_lo, step_lo, step_hi,
+// stream + 2*index_hi).  Stream 0: index = env >> 2 and environment env owns word (env & 3);
+// stream 1 (reset): index = env.  env is always the GLOBAL environment index.
 struct RngKey {
     uint32_t seed_lo, seed_hi, step_lo, step_hi;
 };
 
-__device__ __forceinline__ void env_block(const RngKey &key, uint64_t env, uint32_t stream, uint32_t &o0,
+constexpr uint32_t STREAM_STEP = 0u;
+constexpr uint32_t STREAM_RESET = 1u;
+
+ENV2048_DEV void env_block(const RngKey &key, uint64_t index, uint32_t stream, uint32_t &o0,
                                           uint32_t &o1, uint32_t &o2, uint32_t &o3)
 {
-    philox4x32_10((uint32_t)env, key.step_lo, key.step_hi, stream + 2u * (uint32_t)(env >> 32), key.seed_lo,
+    philox4x32_10((uint32_t)index, key.step_lo, key.step_hi, stream + 2u * (uint32_t)(index >> 32), key.seed_lo,
                   key.seed_hi, o0, o1, o2, o3);
 }
 
 // One full environment transition of one board [ref: gameboard.py:291-325 next_state +
-// twentyfortyeight.py:132-133; reinforce/game/env.py:103-119].  w* = the step block.
-__device__ __forceinline__ void transition(Board &bd, uint32_t action, uint32_t w_cell, uint32_t w_val,
-                                           uint32_t &reward, bool &changed, bool &done)
+// twentyfortyeight.py:132-133; reinforce/game/env.py:103-119]: slide/merge in the direction the
+// selectors encode, spawn one tile from the step word iff the board changed, terminal test on the
+// post-spawn board.  An unchanged board has score 0 already (nothing merged).
+ENV2048_DEV void transition(Board &bd, const DirSelectors &sel, uint32_t word, uint32_t &reward, bool &changed,
+                            bool &done)
 {
-    afterstate(bd, action & 3u, reward, changed);  // unchanged board => score 0 already
-    uint32_t empties_left = spawn_tile(bd, w_cell, w_val, changed);
+    afterstate_sel(bd, sel, reward, changed);
+    const uint32_t empties_left = spawn_tile_word(bd, word, changed);
     done = (empties_left == 0u) && no_equal_neighbours(bd);
 }
 

@@ -2,8 +2,9 @@
 //
 // Data layout in HBM: `boards` is an array of 16-byte records (one global_load_dwordx4 /
 // global_store_dwordx4 per board, a wave moves 1 KiB contiguous); actions/done/legal are byte
-// arrays, reward int32, obs 16 floats per board.  One board per lane, all arithmetic in VGPRs
-// (board_ops.hpp); no LDS, no MFMA -- this path is integer/indexing work bounded by HBM.
+// arrays, reward int32, obs 16 floats per board.  All board arithmetic happens in VGPRs
+// (board_ops.hpp); LDS only carries the direction-selector table, the redistributed Philox words
+// and the reset queue.  No MFMA -- this path is integer/indexing work bounded by HBM.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -42,6 +43,35 @@ __device__ __forceinline__ void store_obs(float *obs, uint64_t i, const Board &b
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Hot kernels: step and rollout.
+//
+// Work decomposition: a wave owns a TILE of 256 consecutive boards and each lane handles four of
+// them, board j of lane l being tile board 64*j + l -- so every board load/store is one fully
+// coalesced 1 KiB wave access (global_load/store_dwordx4) and reward/done/action accesses are
+// dense too.  A block is 4 waves = 1024 boards.
+//
+// RNG: one Philox4x32-10 block yields the step words of FOUR neighbouring environments
+// (env >> 2 selects the block, env & 3 the word), so a wave needs 64 blocks (65 when its first
+// environment index is not a multiple of 4) for its 256 boards: lane l computes block
+// (env0 >> 2) + l and the words are redistributed through a wave-private LDS strip
+// (ds_write_b128 + 4 x ds_read_b32), which costs no VALU work.
+//
+// Direction handling: the v_perm_b32 selector records of board_ops.hpp live in LDS; a lane
+// fetches the record of its action with two ds_read_b128.
+//
+// Auto-reset: terminal boards are rare (~0.7 % of steps in random play), so instead of every
+// wave paying a second Philox block whenever ANY of its lanes finished a game, finished boards
+// are queued in LDS and the block's first threads rebuild all of them after one barrier.
+// ------------------------------------------------------------------------------------------
+constexpr int WAVES_PER_BLOCK = BLOCK / 64;
+constexpr int BOARDS_PER_LANE = 4;
+constexpr int TILE_BOARDS = 64 * BOARDS_PER_LANE;                  // per wave
+constexpr int BLOCK_BOARDS = TILE_BOARDS * WAVES_PER_BLOCK;       // per block
+constexpr int WORD_STRIP = TILE_BOARDS + 4 + 4;                   // 65 Philox blocks (+ pad to 16 B)
+
+__constant__ uint32_t DIR_TABLE[32] = {ENV2048_DIR_SELECTOR_VALUES};
+
 struct StepArgs {
     uint64_t n;
     uint64_t env_base;
@@ -55,31 +85,147 @@ struct StepArgs {
     uint32_t flags;
 };
 
+__device__ __forceinline__ DirSelectors load_selectors(const uint4 *dir_lds, uint32_t action)
+{
+    const uint4 f = dir_lds[2u * action], i = dir_lds[2u * action + 1u];
+    return DirSelectors{f.x, f.y, f.z, f.w, i.x, i.y, i.z, i.w};
+}
+
+// Compute the step words of the wave tile starting at global environment env0 into `strip`
+// (strip[k] = word of environment (env0 & ~3) + k).  Every lane of the wave must call this.
+__device__ __forceinline__ void fill_word_strip(uint32_t *strip, const RngKey &key, uint64_t env0, uint32_t lane)
+{
+    const uint64_t group0 = env0 >> 2;
+    uint32_t w0, w1, w2, w3;
+    env_block(key, group0 + lane, STREAM_STEP, w0, w1, w2, w3);
+    reinterpret_cast<uint4 *>(strip)[lane] = make_uint4(w0, w1, w2, w3);
+    if (env0 & 3u) {  // wave-uniform: the tile straddles a 65th block
+        env_block(key, group0 + 64u, STREAM_STEP, w0, w1, w2, w3);
+        if (lane == 0u) reinterpret_cast<uint4 *>(strip)[64] = make_uint4(w0, w1, w2, w3);
+    }
+    // The strip is private to this wave and a wave's LDS operations execute in order, so no
+    // s_barrier is needed -- only a compiler-level fence so the cross-lane reads stay behind the writes.
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+#ifndef ENV2048_EXP_RESET_MODE
+#define ENV2048_EXP_RESET_MODE 1  // 0: barrier, then the block's first threads reset; 1: last wave out resets
+#endif
+
+// One wave tile of the step kernel.  FULL: all 256 boards of the tile exist (no bounds checks).
+template <bool EXTRAS, bool FULL>
+__device__ __forceinline__ void step_tile(const StepArgs &a, const uint4 *dir_lds, uint32_t *strip,
+                                          uint32_t *reset_count, uint16_t *reset_slot, uint64_t tile0, uint32_t wave,
+                                          uint32_t lane)
+{
+    const uint64_t env0 = a.env_base + tile0;
+    const bool auto_reset = (a.flags & ENV2048_FLAG_AUTO_RESET) != 0u;
+    const bool random_actions = (a.flags & ENV2048_FLAG_RANDOM_ACTIONS) != 0u;
+
+    // issue the board (and action) loads first: their latency hides behind the Philox rounds
+    Board bd[BOARDS_PER_LANE];
+    uint32_t act[BOARDS_PER_LANE];
+#pragma unroll
+    for (int j = 0; j < BOARDS_PER_LANE; ++j) {
+        const uint64_t i = tile0 + 64u * j + lane;
+        bd[j] = Board{0u, 0u, 0u, 0u};
+        act[j] = 0u;
+        if (FULL || i < a.n) {
+            bd[j] = load_board(a.boards, i);
+            if (!random_actions) act[j] = a.actions[i];
+        }
+    }
+
+    fill_word_strip(strip, a.key, env0, lane);
+    const uint32_t strip_off = (uint32_t)env0 & 3u;
+
+#pragma unroll
+    for (int j = 0; j < BOARDS_PER_LANE; ++j) {
+        const uint64_t i = tile0 + 64u * j + lane;
+        if (!FULL && i >= a.n) continue;
+        const uint32_t word = strip[strip_off + 64u * j + lane];
+        const uint32_t action = (random_actions ? word : act[j]) & 3u;
+        uint32_t reward;
+        bool changed, done;
+        transition(bd[j], load_selectors(dir_lds, action), word, reward, changed, done);
+        if (auto_reset && done) {
+            const uint32_t slot = atomicAdd(reset_count, 1u);
+            reset_slot[slot] = (uint16_t)(wave * TILE_BOARDS + 64u * j + lane);
+        } else {
+            store_board(a.boards, i, bd[j]);
+            if (EXTRAS) {
+                if (a.legal) a.legal[i] = (uint8_t)legal_mask(bd[j]);
+                if (a.obs) store_obs(a.obs, i, bd[j]);
+            }
+        }
+        if (a.reward) a.reward[i] = (int32_t)reward;
+        a.done[i] = done ? 1 : 0;
+    }
+}
+
+// Rebuild the queued (terminal) boards of this block; executed by `nthreads` threads with ids `t`.
+template <bool EXTRAS>
+__device__ __forceinline__ void reset_queued(const StepArgs &a, uint64_t block0, const uint16_t *reset_slot,
+                                             uint32_t n_reset, uint32_t t, uint32_t nthreads)
+{
+    for (uint32_t q = t; q < n_reset; q += nthreads) {
+        const uint64_t i = block0 + reset_slot[q];
+        uint32_t w0, w1, w2, w3;
+        env_block(a.key, a.env_base + i, STREAM_RESET, w0, w1, w2, w3);
+        const Board fresh = fresh_board(w0, w1, w2, w3);
+        store_board(a.boards, i, fresh);
+        if (EXTRAS) {
+            if (a.legal) a.legal[i] = (uint8_t)legal_mask(fresh);
+            if (a.obs) store_obs(a.obs, i, fresh);
+        }
+    }
+}
+
 // EXTRAS: legal and/or obs requested (kept out of the base variant so it stays lean).
 template <bool EXTRAS>
 __global__ __launch_bounds__(BLOCK) void step_kernel(StepArgs a)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= a.n) return;
-    const uint64_t env = a.env_base + i;
-    Board bd = load_board(a.boards, i);
-    uint32_t w0, w1, w2, w3;
-    env_block(a.key, env, 0u, w0, w1, w2, w3);
-    const uint32_t action = (a.flags & ENV2048_FLAG_RANDOM_ACTIONS) ? w2 : (uint32_t)a.actions[i];
-    uint32_t reward;
-    bool changed, done;
-    transition(bd, action, w0, w1, reward, changed, done);
-    if ((a.flags & ENV2048_FLAG_AUTO_RESET) && done) {
-        env_block(a.key, env, 1u, w0, w1, w2, w3);
-        bd = fresh_board(w0, w1, w2, w3);
+    __shared__ uint4 dir_lds[8];
+    __shared__ __attribute__((aligned(16))) uint32_t word_lds[WAVES_PER_BLOCK][WORD_STRIP];
+    __shared__ uint32_t reset_count;
+    __shared__ uint32_t waves_finished;
+    __shared__ uint16_t reset_slot[BLOCK_BOARDS];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid < 8u) dir_lds[tid] = reinterpret_cast<const uint4 *>(DIR_TABLE)[tid];
+    if (tid == 0u) {
+        reset_count = 0u;
+        waves_finished = 0u;
     }
-    store_board(a.boards, i, bd);
-    if (a.reward) a.reward[i] = (int32_t)reward;
-    a.done[i] = done ? 1 : 0;
-    if (EXTRAS) {
-        if (a.legal) a.legal[i] = (uint8_t)legal_mask(bd);
-        if (a.obs) store_obs(a.obs, i, bd);
-    }
+    __syncthreads();
+
+    const uint64_t block0 = (uint64_t)blockIdx.x * BLOCK_BOARDS;  // first board of this block (local index)
+    const uint64_t tile0 = block0 + (uint64_t)wave * TILE_BOARDS;
+    if (block0 + BLOCK_BOARDS <= a.n)  // block-uniform: every block but the last takes the unchecked path
+        step_tile<EXTRAS, true>(a, dir_lds, word_lds[wave], &reset_count, reset_slot, tile0, wave, lane);
+    else
+        step_tile<EXTRAS, false>(a, dir_lds, word_lds[wave], &reset_count, reset_slot, tile0, wave, lane);
+
+    if (!(a.flags & ENV2048_FLAG_AUTO_RESET)) return;
+#if ENV2048_EXP_RESET_MODE == 0
+    __syncthreads();
+    reset_queued<EXTRAS>(a, block0, reset_slot, reset_count, tid, BLOCK);
+#else
+    // No barrier: waves retire as they finish; the LAST wave of the block to get here sees every
+    // queue entry (LDS is coherent within the CU and each wave's queue writes are complete --
+    // lgkmcnt(0) via the fence -- before its arrival count) and rebuilds the terminal boards.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    uint32_t arrived = 0u;
+    if (lane == 0u) arrived = atomicAdd(&waves_finished, 1u);
+    arrived = __builtin_amdgcn_readfirstlane(arrived);
+    if (arrived != WAVES_PER_BLOCK - 1u) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const uint32_t n_reset = *(volatile uint32_t *)&reset_count;
+    reset_queued<EXTRAS>(a, block0, reset_slot, n_reset, lane, 64u);
+#endif
 }
 
 struct ResetArgs {
@@ -95,7 +241,7 @@ __global__ __launch_bounds__(BLOCK) void reset_kernel(ResetArgs a)
     const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= a.n) return;
     uint32_t w0, w1, w2, w3;
-    env_block(a.key, a.env_base + i, 1u, w0, w1, w2, w3);
+    env_block(a.key, a.env_base + i, STREAM_RESET, w0, w1, w2, w3);
     store_board(a.boards, i, fresh_board(w0, w1, w2, w3));
     if (a.done) a.done[i] = 0;
 }
@@ -113,34 +259,80 @@ struct RolloutArgs {
     uint32_t flags;
 };
 
+// T steps with the boards resident in registers; same tile layout and RNG words as step_kernel.
 __global__ __launch_bounds__(BLOCK) void rollout_kernel(RolloutArgs a)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= a.n) return;
-    const uint64_t env = a.env_base + i;
-    Board bd = load_board(a.boards, i);
-    int64_t ret = 0;
-    uint32_t eps = 0, moves = 0;
+    __shared__ uint4 dir_lds[8];
+    __shared__ __attribute__((aligned(16))) uint32_t word_lds[WAVES_PER_BLOCK][WORD_STRIP];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid < 8u) dir_lds[tid] = reinterpret_cast<const uint4 *>(DIR_TABLE)[tid];
+    __syncthreads();
+
+    const uint64_t tile0 = ((uint64_t)blockIdx.x * WAVES_PER_BLOCK + wave) * TILE_BOARDS;
+    const uint64_t env0 = a.env_base + tile0;
+    const bool auto_reset = (a.flags & ENV2048_FLAG_AUTO_RESET) != 0u;
+    uint32_t *strip = word_lds[wave];
+    const uint32_t strip_off = (uint32_t)env0 & 3u;
+
+    Board bd[BOARDS_PER_LANE];
+    bool valid[BOARDS_PER_LANE];
+    int64_t ret[BOARDS_PER_LANE];
+    uint32_t eps[BOARDS_PER_LANE], moves[BOARDS_PER_LANE];
+#pragma unroll
+    for (int j = 0; j < BOARDS_PER_LANE; ++j) {
+        const uint64_t i = tile0 + 64u * j + lane;
+        valid[j] = i < a.n;
+        bd[j] = valid[j] ? load_board(a.boards, i) : Board{0u, 0u, 0u, 0u};
+        ret[j] = 0;
+        eps[j] = 0u;
+        moves[j] = 0u;
+    }
+
     for (uint32_t t = 0; t < a.T; ++t) {
         const uint64_t step = a.step0 + t;
         const RngKey key{a.seed_lo, a.seed_hi, (uint32_t)step, (uint32_t)(step >> 32)};
-        uint32_t w0, w1, w2, w3;
-        env_block(key, env, 0u, w0, w1, w2, w3);
-        uint32_t reward;
-        bool changed, done;
-        transition(bd, w2, w0, w1, reward, changed, done);
-        if ((a.flags & ENV2048_FLAG_AUTO_RESET) && done) {
-            env_block(key, env, 1u, w0, w1, w2, w3);
-            bd = fresh_board(w0, w1, w2, w3);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // last step's strip reads precede this rewrite
+        __builtin_amdgcn_wave_barrier();
+        fill_word_strip(strip, key, env0, lane);
+        uint32_t pending = 0u;  // bit j: my board j finished a game this step
+#pragma unroll
+        for (int j = 0; j < BOARDS_PER_LANE; ++j) {
+            const uint32_t word = strip[strip_off + 64u * j + lane];
+            uint32_t reward;
+            bool changed, done;
+            transition(bd[j], load_selectors(dir_lds, word & 3u), word, reward, changed, done);
+            ret[j] += reward;
+            eps[j] += done ? 1u : 0u;
+            moves[j] += changed ? 1u : 0u;
+            pending |= (done ? 1u : 0u) << j;
         }
-        ret += reward;
-        eps += done ? 1u : 0u;
-        moves += changed ? 1u : 0u;
+        if (auto_reset) {
+            // one reset block per finished board; usually at most one lane of the wave has one
+            while (pending) {
+                const uint32_t j = (uint32_t)__ffs((int)pending) - 1u;
+                pending &= pending - 1u;
+                uint32_t w0, w1, w2, w3;
+                env_block(key, env0 + 64u * j + lane, STREAM_RESET, w0, w1, w2, w3);
+                const Board fresh = fresh_board(w0, w1, w2, w3);
+#pragma unroll
+                for (int jj = 0; jj < BOARDS_PER_LANE; ++jj)
+                    if (j == (uint32_t)jj) bd[jj] = fresh;
+            }
+        }
     }
-    store_board(a.boards, i, bd);
-    if (a.return_sum) a.return_sum[i] = ret;
-    if (a.episodes) a.episodes[i] = eps;
-    if (a.valid_moves) a.valid_moves[i] = moves;
+
+#pragma unroll
+    for (int j = 0; j < BOARDS_PER_LANE; ++j) {
+        if (!valid[j]) continue;
+        const uint64_t i = tile0 + 64u * j + lane;
+        store_board(a.boards, i, bd[j]);
+        if (a.return_sum) a.return_sum[i] = ret[j];
+        if (a.episodes) a.episodes[i] = eps[j];
+        if (a.valid_moves) a.valid_moves[i] = moves[j];
+    }
 }
 
 __global__ __launch_bounds__(BLOCK) void afterstate_kernel(uint64_t n, const uint8_t *boards_in,
@@ -311,6 +503,7 @@ int check_count(uint64_t n)
 }
 
 inline dim3 grid_for(uint64_t n) { return dim3((unsigned)((n + BLOCK - 1) / BLOCK)); }
+inline dim3 tile_grid_for(uint64_t n) { return dim3((unsigned)((n + BLOCK_BOARDS - 1) / BLOCK_BOARDS)); }
 
 int launched(const char *what)
 {
@@ -371,9 +564,9 @@ int env2048_step(int device, void *stream, uint64_t n, uint64_t env_base, uint8_
                RngKey{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)step_index, (uint32_t)(step_index >> 32)},
                flags};
     if (legal || obs)
-        hipLaunchKernelGGL(step_kernel<true>, grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(step_kernel<true>, tile_grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, a);
     else
-        hipLaunchKernelGGL(step_kernel<false>, grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(step_kernel<false>, tile_grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, a);
     return launched("env2048_step launch");
 }
 
@@ -395,7 +588,7 @@ int env2048_rollout(int device, void *stream, uint64_t n, uint64_t env_base, uin
     if (scope.rc) return scope.rc;
     RolloutArgs a{n, env_base, boards, return_sum, episodes, valid_moves, (uint32_t)seed, (uint32_t)(seed >> 32),
                   step0, T, flags};
-    hipLaunchKernelGGL(rollout_kernel, grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(rollout_kernel, tile_grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, a);
     return launched("env2048_rollout launch");
 }
 

@@ -1,0 +1,122 @@
+// tests/host_emu/emu.cpp -- CPU build of simulate_2048_amd/csrc/board_ops.hpp (ENV2048_HOST_EMULATION).
+// TEST HARNESS ONLY: lets the per-board SWAR arithmetic of the HIP kernels be checked against the
+// oracle and run under -fsanitize=address,undefined without a GPU.  Never loaded by the product.
+#define ENV2048_HOST_EMULATION 1
+#include "board_ops.hpp"
+
+#include <cstring>
+
+using namespace env2048;
+
+static Board load(const uint8_t *p)
+{
+    Board b;
+    std::memcpy(&b, p, 16);
+    return b;
+}
+static void store(uint8_t *p, const Board &b) { std::memcpy(p, &b, 16); }
+static DirSelectors selectors(uint32_t action)
+{
+    DirSelectors s;
+    std::memcpy(&s, DIR_SELECTORS + 8 * (action & 3u), sizeof s);
+    return s;
+}
+
+extern "C" {
+
+void emu_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out[0], out[1], out[2], out[3]);
+}
+
+// mode 0: cndmask afterstate(); mode 1: selector-table afterstate_sel()
+void emu_afterstate(uint64_t n, const uint8_t *in, const uint8_t *actions, uint8_t *out, int32_t *reward,
+                    uint8_t *changed, int mode)
+{
+    for (uint64_t i = 0; i < n; ++i) {
+        Board b = load(in + 16 * i);
+        uint32_t score;
+        bool ch;
+        if (mode == 0)
+            afterstate(b, actions[i] & 3u, score, ch);
+        else
+            afterstate_sel(b, selectors(actions[i]), score, ch);
+        store(out + 16 * i, b);
+        reward[i] = (int32_t)score;
+        changed[i] = ch;
+    }
+}
+
+// full transition with caller-provided step words (and the reset block computed here)
+void emu_step(uint64_t n, uint64_t env_base, uint8_t *boards, const uint8_t *actions, const uint32_t *words,
+              int32_t *reward, uint8_t *done, uint8_t *legal, uint64_t seed, uint64_t step, uint32_t flags)
+{
+    const RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)step, (uint32_t)(step >> 32)};
+    for (uint64_t i = 0; i < n; ++i) {
+        Board b = load(boards + 16 * i);
+        const uint32_t w = words[i];
+        const uint32_t action = (flags & 2u) ? (w & 3u) : (actions[i] & 3u);
+        uint32_t r;
+        bool ch, dn;
+        transition(b, selectors(action), w, r, ch, dn);
+        if ((flags & 1u) && dn) {
+            uint32_t w0, w1, w2, w3;
+            env_block(key, env_base + i, STREAM_RESET, w0, w1, w2, w3);
+            b = fresh_board(w0, w1, w2, w3);
+        }
+        store(boards + 16 * i, b);
+        reward[i] = (int32_t)r;
+        done[i] = dn;
+        if (legal) legal[i] = (uint8_t)legal_mask(b);
+    }
+}
+
+void emu_step_words(uint64_t n, uint64_t env_base, uint64_t seed, uint64_t step, uint32_t *words)
+{
+    const RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)step, (uint32_t)(step >> 32)};
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint64_t env = env_base + i;
+        uint32_t w[4];
+        env_block(key, env >> 2, STREAM_STEP, w[0], w[1], w[2], w[3]);
+        words[i] = w[env & 3u];
+    }
+}
+
+void emu_reset(uint64_t n, uint64_t env_base, uint8_t *boards, uint64_t seed, uint64_t step)
+{
+    const RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)step, (uint32_t)(step >> 32)};
+    for (uint64_t i = 0; i < n; ++i) {
+        uint32_t w0, w1, w2, w3;
+        env_block(key, env_base + i, STREAM_RESET, w0, w1, w2, w3);
+        store(boards + 16 * i, fresh_board(w0, w1, w2, w3));
+    }
+}
+
+void emu_status(uint64_t n, const uint8_t *boards, uint8_t *done, uint8_t *legal, uint8_t *n_empty)
+{
+    for (uint64_t i = 0; i < n; ++i) {
+        const Board b = load(boards + 16 * i);
+        const uint32_t e = count_empty(b);
+        done[i] = (e == 0u) && no_equal_neighbours(b);
+        legal[i] = (uint8_t)legal_mask(b);
+        n_empty[i] = (uint8_t)e;
+    }
+}
+
+void emu_spawn(uint64_t n, uint8_t *boards, const uint8_t *k, const uint8_t *e, uint8_t *placed)
+{
+    for (uint64_t i = 0; i < n; ++i) {
+        Board b = load(boards + 16 * i);
+        const uint32_t empt = empty_mask(b);
+        const bool ok = k[i] < ENV2048_POPC(empt);
+        const uint32_t bit = ok ? kth_empty(empt, k[i]) : 0u;
+        b.r0 |= ((bit >> 7) & K01) * e[i];
+        b.r1 |= ((bit >> 6) & K01) * e[i];
+        b.r2 |= ((bit >> 5) & K01) * e[i];
+        b.r3 |= ((bit >> 4) & K01) * e[i];
+        store(boards + 16 * i, b);
+        placed[i] = ok ? (uint8_t)cell_index(bit) : (uint8_t)0xFF;
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,166 @@
+"""
+CPU unit tests of the HIP kernels' per-board arithmetic: simulate_2048_amd/csrc/board_ops.hpp is
+compiled for the host (ENV2048_HOST_EMULATION: v_perm_b32 / popcount / mulhi emulated) with
+-fsanitize=address,undefined and compared bit-for-bit with the oracle and the golden fixtures.
+This is a test harness (tests/host_emu), not a CPU backend: the product never loads it.
+"""
+
+import ctypes
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import REPO
+
+SRC = REPO / 'tests' / 'host_emu' / 'emu.cpp'
+HDR = REPO / 'simulate_2048_amd' / 'csrc' / 'board_ops.hpp'
+OUT = REPO / 'tests' / 'host_emu' / '_build' / 'libemu.so'
+
+
+def u8(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
+
+
+def ptr(a, t):
+    return a.ctypes.data_as(ctypes.POINTER(t))
+
+
+@pytest.fixture(scope='module')
+def emu():
+    OUT.parent.mkdir(exist_ok=True)
+    if not OUT.exists() or OUT.stat().st_mtime < max(SRC.stat().st_mtime, HDR.stat().st_mtime):
+        cmd = ['g++', '-O1', '-g', '-std=c++17', '-fPIC', '-shared', '-fsanitize=undefined', '-fno-sanitize-recover=all',
+               '-Wall', '-Wextra', f'-I{HDR.parent}', str(SRC), '-o', str(OUT)]
+        subprocess.run(cmd, check=True)
+    return ctypes.CDLL(str(OUT))
+
+
+def emu_afterstate(emu, boards, actions, mode):
+    n = boards.shape[0]
+    b = np.ascontiguousarray(boards, dtype=np.uint8)
+    a = np.ascontiguousarray(actions, dtype=np.uint8)
+    out = np.zeros_like(b)
+    reward = np.zeros(n, dtype=np.int32)
+    changed = np.zeros(n, dtype=np.uint8)
+    emu.emu_afterstate(ctypes.c_uint64(n), u8(b), u8(a), u8(out), ptr(reward, ctypes.c_int32), u8(changed), mode)
+    return out, reward, changed
+
+
+def test_philox_kat(emu):
+    out = np.zeros(4, dtype=np.uint32)
+    ctr = np.array([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], dtype=np.uint32)
+    key = np.array([0xA4093822, 0x299F31D0], dtype=np.uint32)
+    emu.emu_philox(ptr(ctr, ctypes.c_uint32), ptr(key, ctypes.c_uint32), ptr(out, ctypes.c_uint32))
+    assert out.tolist() == [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+
+
+@pytest.mark.parametrize('mode', [0, 1])
+def test_afterstate_golden(emu, golden, mode):
+    g = golden['afterstates']
+    n = g['boards'].shape[0]
+    for a in range(4):
+        out, reward, changed = emu_afterstate(emu, g['boards'], np.full(n, a, dtype=np.uint8), mode)
+        np.testing.assert_array_equal(out, g['after'][:, a])
+        np.testing.assert_array_equal(reward, g['reward'][:, a])
+        np.testing.assert_array_equal(changed, g['valid'][:, a])
+
+
+@pytest.mark.parametrize('mode', [0, 1])
+def test_rows_exhaustive(emu, golden, mode):
+    g = golden['rows']
+    base = int(g['max_e']) + 1
+    idx = np.arange(base**4)
+    rows = np.stack([(idx // base**3) % base, (idx // base**2) % base, (idx // base) % base, idx % base], axis=1).astype(np.uint8)
+    n = rows.shape[0]
+    for action in range(4):
+        boards = np.zeros((n, 4, 4), dtype=np.uint8)
+        line = rows if action in (0, 1) else rows[:, ::-1]
+        want = g['merged'] if action in (0, 1) else g['merged'][:, ::-1]
+        if action in (0, 2):
+            boards[:, 3, :] = line
+        else:
+            boards[:, :, 2] = line
+        out, reward, changed = emu_afterstate(emu, boards.reshape(n, 16), np.full(n, action, dtype=np.uint8), mode)
+        got = out.reshape(n, 4, 4)
+        np.testing.assert_array_equal(got[:, 3, :] if action in (0, 2) else got[:, :, 2], want)
+        np.testing.assert_array_equal(reward, g['score'])
+        np.testing.assert_array_equal(changed, g['can_move'])
+
+
+def test_status_and_spawn(emu, golden):
+    g = golden['afterstates']
+    boards = np.ascontiguousarray(g['boards'])
+    n = boards.shape[0]
+    done, legal, n_empty = (np.zeros(n, dtype=np.uint8) for _ in range(3))
+    emu.emu_status(ctypes.c_uint64(n), u8(boards), u8(done), u8(legal), u8(n_empty))
+    np.testing.assert_array_equal(done, g['done'])
+    np.testing.assert_array_equal(legal, g['legal'])
+    np.testing.assert_array_equal(n_empty, (boards == 0).sum(axis=1))
+    rng = np.random.default_rng(0)
+    k = rng.integers(0, 17, size=n).astype(np.uint8)
+    e = rng.integers(1, 3, size=n).astype(np.uint8)
+    ref = oracle.spawn_batch(boards, k, e)
+    b = boards.copy()
+    placed = np.zeros(n, dtype=np.uint8)
+    emu.emu_spawn(ctypes.c_uint64(n), u8(b), u8(k), u8(e), u8(placed))
+    np.testing.assert_array_equal(b, ref['boards'])
+    np.testing.assert_array_equal(placed, ref['placed'])
+
+
+def test_step_words_match_oracle(emu):
+    seed, step = 0x1122334455667788, (1 << 33) + 5
+    for env_base in (0, 1001, (1 << 34) + 3):
+        n = 777
+        words = np.zeros(n, dtype=np.uint32)
+        emu.emu_step_words(ctypes.c_uint64(n), ctypes.c_uint64(env_base), ctypes.c_uint64(seed), ctypes.c_uint64(step),
+                           ptr(words, ctypes.c_uint32))
+        assert words.tolist() == [oracle.step_word(seed, env_base + i, step) for i in range(n)]
+
+
+@pytest.mark.parametrize('name', ['auto', 'plain'])
+def test_trajectories_golden(emu, golden, name):
+    g = golden['trajectories']
+    seed, env_base, step0 = int(g[f'{name}_seed']), int(g[f'{name}_env_base']), int(g[f'{name}_step0'])
+    flags = 1 if int(g[f'{name}_auto_reset']) else 0
+    T, n = g[f'{name}_actions'].shape
+    boards = np.zeros((n, 16), dtype=np.uint8)
+    emu.emu_reset(ctypes.c_uint64(n), ctypes.c_uint64(env_base), u8(boards), ctypes.c_uint64(seed), ctypes.c_uint64(step0))
+    np.testing.assert_array_equal(boards, g[f'{name}_boards0'])
+    words = np.zeros(n, dtype=np.uint32)
+    reward = np.zeros(n, dtype=np.int32)
+    done, legal = np.zeros(n, dtype=np.uint8), np.zeros(n, dtype=np.uint8)
+    for t in range(T):
+        emu.emu_step_words(ctypes.c_uint64(n), ctypes.c_uint64(env_base), ctypes.c_uint64(seed), ctypes.c_uint64(step0 + t),
+                           ptr(words, ctypes.c_uint32))
+        acts = np.ascontiguousarray(g[f'{name}_actions'][t])
+        emu.emu_step(ctypes.c_uint64(n), ctypes.c_uint64(env_base), u8(boards), u8(acts), ptr(words, ctypes.c_uint32),
+                     ptr(reward, ctypes.c_int32), u8(done), u8(legal), ctypes.c_uint64(seed), ctypes.c_uint64(step0 + t), flags | 2)
+        np.testing.assert_array_equal(boards, g[f'{name}_boards'][t], err_msg=f't={t}')
+        np.testing.assert_array_equal(reward, g[f'{name}_reward'][t])
+        np.testing.assert_array_equal(done, g[f'{name}_done'][t])
+        np.testing.assert_array_equal(legal, g[f'{name}_legal'][t])
+
+
+def test_random_boards_vs_oracle(emu):
+    rng = np.random.default_rng(9)
+    n = 40_000
+    boards = np.where(rng.random((n, 16)) < 0.25, 0, rng.integers(0, 18, size=(n, 16))).astype(np.uint8)
+    boards[: n // 2] = np.where(rng.random((n // 2, 16)) < 0.1, 0, rng.integers(1, 4, size=(n // 2, 16)))
+    actions = rng.integers(0, 256, size=n).astype(np.uint8)
+    seed, step, env_base = 5, 6, 7
+    ref = oracle.step_batch(boards, actions, seed, step, env_base=env_base, flags=1, want_legal=True)
+    words = np.zeros(n, dtype=np.uint32)
+    emu.emu_step_words(ctypes.c_uint64(n), ctypes.c_uint64(env_base), ctypes.c_uint64(seed), ctypes.c_uint64(step),
+                       ptr(words, ctypes.c_uint32))
+    b = boards.copy()
+    reward = np.zeros(n, dtype=np.int32)
+    done, legal = np.zeros(n, dtype=np.uint8), np.zeros(n, dtype=np.uint8)
+    emu.emu_step(ctypes.c_uint64(n), ctypes.c_uint64(env_base), u8(b), u8(actions), ptr(words, ctypes.c_uint32),
+                 ptr(reward, ctypes.c_int32), u8(done), u8(legal), ctypes.c_uint64(seed), ctypes.c_uint64(step), 1)
+    np.testing.assert_array_equal(b, ref['boards'])
+    np.testing.assert_array_equal(reward, ref['reward'])
+    np.testing.assert_array_equal(done, ref['done'])
+    np.testing.assert_array_equal(legal, ref['legal'])

@@ -42,10 +42,38 @@ def test_philox_random123_kat(ctr, key, expect):
 
 
 def test_env_block_counter_layout():
-    seed, env, step = 0x0123456789ABCDEF, (3 << 32) | 17, (5 << 32) | 9
+    seed, index, step = 0x0123456789ABCDEF, (3 << 32) | 17, (5 << 32) | 9
     for stream in (0, 1):
         direct = oracle.philox4x32_10([17, 9, 5, stream + 2 * 3], [0x89ABCDEF, 0x01234567])
-        assert oracle.env_block(seed, env, step, stream).tolist() == direct.tolist()
+        assert oracle.env_block(seed, index, step, stream).tolist() == direct.tolist()
+
+
+def test_step_word_sharing():
+    """Environment e draws word (e & 3) of the stream-0 block with index e >> 2."""
+    seed, step = 0xFEEDFACE12345678, (1 << 35) + 4
+    for env in [0, 1, 2, 3, 4, 1001, (7 << 32) + 6, (1 << 34) + 3]:
+        blk = oracle.env_block(seed, env >> 2, step, 0)
+        assert oracle.step_word(seed, env, step) == int(blk[env & 3])
+
+
+def test_spawn_from_word():
+    """k = hi32((w & ~3) * n), tile 4 iff lo32 < floor(0.1 * 2^32), action = w & 3."""
+    T = oracle.SPAWN4_THRESHOLD
+    assert oracle.spawn_from_word(0, 16) == (0, 2, 0)  # lo32 = 0 < T
+    assert oracle.spawn_from_word(0xFFFFFFFF, 16) == (15, 1, 3)
+    assert oracle.spawn_from_word(0x80000002, 3) == (1, 1, 2)  # product 0x1_8000_0000: lo32 = 2^31 >= T
+    for w, n in [(0x12345679, 7), (0xDEADBEEF, 1), (0x0000FFFD, 15), (0xC0000000, 4)]:
+        prod = (w & ~3) * n
+        assert oracle.spawn_from_word(w, n) == (prod >> 32, 2 if (prod & 0xFFFFFFFF) < T else 1, w & 3)
+    # distribution over one million consecutive counters: uniform cells, P(4) = 0.1
+    rng = np.random.default_rng(3)
+    ws = rng.integers(0, 2**32, size=200_000, dtype=np.uint64)
+    prod = (ws & ~np.uint64(3)) * np.uint64(7)
+    k = (prod >> np.uint64(32)).astype(np.int64)
+    four = (prod & np.uint64(0xFFFFFFFF)) < T
+    assert np.bincount(k, minlength=7).min() > 0.95 * 200_000 / 7
+    assert 0.097 < four.mean() < 0.103
+    assert abs(np.corrcoef(k, four)[0, 1]) < 0.01 and abs(np.corrcoef(ws & np.uint64(3), four)[0, 1]) < 0.01
 
 
 def test_spawn_from_words():
