@@ -140,6 +140,17 @@ ENV2048_EXPORT int env2048_spawn(int device, void *stream, uint64_t n, uint8_t *
                   const uint8_t *spawn_e, uint8_t *placed);
 
 /*
+ * Chance half of a move with the outcome drawn on device: `count` sequential single spawns per
+ * board, spawn t of environment env_base + i using the step word of (env, step_index + t)
+ * exactly as env2048_step does (uniform empty cell, tile 4 with probability 0.1).  A full board is
+ * left unchanged.
+ * [replaces: twentyfortyeight/core/gameboard.py:247-288 fill_cells(state, number_tile, seed);
+ *            reinforce/game/core.py:173-231 fill_cells(state, key)]
+ */
+ENV2048_EXPORT int env2048_spawn_random(int device, void *stream, uint64_t n, uint64_t env_base, uint8_t *boards,
+                                        uint64_t seed, uint64_t step_index, uint32_t count);
+
+/*
  * Read-only board status; every output may be NULL.
  *     done / legal / obs as in env2048_step;  max_exp[i] = log2(max tile);  n_empty[i] = #zeros
  * [replaces: twentyfortyeight/core/gameboard.py:328-348 is_done;
@@ -148,6 +159,16 @@ ENV2048_EXPORT int env2048_spawn(int device, void *stream, uint64_t n, uint8_t *
  */
 ENV2048_EXPORT int env2048_status(int device, void *stream, uint64_t n, const uint8_t *boards, uint8_t *done, uint8_t *legal,
                    float *obs, uint8_t *max_exp, uint8_t *n_empty);
+
+/*
+ * One-hot observation: out[(16*i + cell) * width + e] = 1 for the exponent e of that cell (empty
+ * cells light index 0), every other byte 0.  width must be in [1, 255]; exponents >= width are
+ * undefined input.  width = 31 reproduces encode_flatten(state, encodage_size=31) as uint8.
+ * [replaces: twentyfortyeight/utils/binary.py:11-86 encode/encode_flatten;
+ *            twentyfortyeight/envs/twentyfortyeight.py:66-67 observation (encoded=True)]
+ */
+ENV2048_EXPORT int env2048_encode_onehot(int device, void *stream, uint64_t n, const uint8_t *boards, uint32_t width,
+                                         uint8_t *out);
 
 /*
  * Tile values <-> packed exponents, n boards of 16 cells.  pack: value v (0 or a power of two)

@@ -422,6 +422,32 @@ ORACLE_API int oracle_spawn_batch(uint64_t n, uint8_t *boards, const uint8_t *sp
     return 0;
 }
 
+/* `count` sequential random spawns per board from the step words of (env, step_index + t)
+ * [ref: gameboard.py:247-288 fill_cells]; a full board stays unchanged (:277-278). */
+ORACLE_API int oracle_spawn_random_batch(uint64_t n, uint64_t env_base, uint8_t *boards, uint64_t seed,
+                                         uint64_t step_index, uint32_t count)
+{
+    for (uint64_t i = 0; i < n; ++i)
+        for (uint32_t t = 0; t < count; ++t) {
+            uint8_t *b = boards + 16 * i;
+            int n_empty = oracle_count_empty(b);
+            if (n_empty == 0) continue;
+            int k, e, unused;
+            oracle_spawn_from_word(step_word(seed, env_base + i, step_index + t), n_empty, &k, &e, &unused);
+            oracle_fill_cell_kv(b, k, (uint8_t)e);
+        }
+    return 0;
+}
+
+/* [ref: twentyfortyeight/utils/binary.py:11-86 encode_flatten]  eye(width)[log2(cell)], empty -> index 0. */
+ORACLE_API int oracle_encode_onehot(uint64_t n, const uint8_t *boards, uint32_t width, uint8_t *out)
+{
+    memset(out, 0, (size_t)n * 16 * width);
+    for (uint64_t c = 0; c < 16 * n; ++c)
+        if (boards[c] < width) out[c * width + boards[c]] = 1;
+    return 0;
+}
+
 /* Board status: done / legal bitmask / f32 obs / max exponent / empty count. */
 ORACLE_API int oracle_status_batch(uint64_t n, const uint8_t *boards, uint8_t *done, uint8_t *legal,
                                    float *obs, uint8_t *max_exp, uint8_t *n_empty)

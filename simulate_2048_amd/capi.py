@@ -41,7 +41,9 @@ PROTOTYPES = {
     'env2048_rollout': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _u64, _u64, _u32, _ptr, _ptr, _ptr, _u32]),
     'env2048_afterstate': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr, _ptr]),
     'env2048_spawn': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr]),
+    'env2048_spawn_random': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _u64, _u64, _u32]),
     'env2048_status': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    'env2048_encode_onehot': (_c_int, [_c_int, _ptr, _u64, _ptr, _u32, _ptr]),
     'env2048_pack_i32': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr]),
     'env2048_unpack_i32': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr]),
     'env2048_pack_i64': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr]),
@@ -113,6 +115,12 @@ class Library:
 
     def spawn(self, device, stream, n, boards, spawn_k, spawn_e, placed) -> None:
         self._check(self._dll.env2048_spawn(device, stream, n, boards, spawn_k, spawn_e, placed))
+
+    def spawn_random(self, device, stream, n, env_base, boards, seed, step_index, count) -> None:
+        self._check(self._dll.env2048_spawn_random(device, stream, n, env_base, boards, seed, step_index, count))
+
+    def encode_onehot(self, device, stream, n, boards, width, out) -> None:
+        self._check(self._dll.env2048_encode_onehot(device, stream, n, boards, width, out))
 
     def status(self, device, stream, n, boards, done, legal, obs, max_exp, n_empty) -> None:
         self._check(self._dll.env2048_status(device, stream, n, boards, done, legal, obs, max_exp, n_empty))

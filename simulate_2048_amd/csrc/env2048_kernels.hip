@@ -370,6 +370,39 @@ __global__ __launch_bounds__(BLOCK) void spawn_kernel(uint64_t n, uint8_t *board
     if (placed) placed[i] = ok ? (uint8_t)cell_index(bit) : (uint8_t)0xFF;
 }
 
+// `count` sequential random spawns per board from the environment's step words (not a hot path:
+// one board per lane, every lane computes its own Philox block).
+__global__ __launch_bounds__(BLOCK) void spawn_random_kernel(uint64_t n, uint64_t env_base, uint8_t *boards,
+                                                             uint32_t seed_lo, uint32_t seed_hi, uint64_t step_index,
+                                                             uint32_t count)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t env = env_base + i;
+    Board bd = load_board(boards, i);
+    for (uint32_t t = 0; t < count; ++t) {
+        const uint64_t step = step_index + t;
+        const RngKey key{seed_lo, seed_hi, (uint32_t)step, (uint32_t)(step >> 32)};
+        uint32_t w[4];
+        env_block(key, env >> 2, STREAM_STEP, w[0], w[1], w[2], w[3]);
+        const uint32_t sel = (uint32_t)env & 3u;
+        const uint32_t word = sel == 0u ? w[0] : sel == 1u ? w[1] : sel == 2u ? w[2] : w[3];
+        const bool has_room = count_empty(bd) != 0u;
+        spawn_tile_word(bd, word, has_room);
+    }
+    store_board(boards, i, bd);
+}
+
+// one thread per cell: `width` bytes, a single 1 at the cell's exponent
+__global__ __launch_bounds__(BLOCK) void onehot_kernel(uint64_t n_cells, const uint8_t *boards, uint32_t width, uint8_t *out)
+{
+    const uint64_t c = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (c >= n_cells) return;
+    const uint32_t e = boards[c];
+    uint8_t *o = out + c * width;
+    for (uint32_t k = 0; k < width; ++k) o[k] = (k == e) ? 1 : 0;
+}
+
 __global__ __launch_bounds__(BLOCK) void status_kernel(uint64_t n, const uint8_t *boards, uint8_t *done,
                                                        uint8_t *legal, float *obs, uint8_t *max_exp,
                                                        uint8_t *n_empty)
@@ -622,6 +655,34 @@ int env2048_spawn(int device, void *stream, uint64_t n, uint8_t *boards, const u
     hipLaunchKernelGGL(spawn_kernel, grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, n, boards, spawn_k, spawn_e,
                        placed);
     return launched("env2048_spawn launch");
+}
+
+int env2048_spawn_random(int device, void *stream, uint64_t n, uint64_t env_base, uint8_t *boards, uint64_t seed,
+                         uint64_t step_index, uint32_t count)
+{
+    if (n == 0 || count == 0) return ENV2048_OK;
+    if (!boards) return fail(ENV2048_ERR_INVALID_ARG, "env2048_spawn_random: boards is NULL");
+    if (misaligned(boards, 16)) return fail(ENV2048_ERR_ALIGNMENT, "env2048_spawn_random: boards must be 16-byte aligned");
+    if (count > 16) return fail(ENV2048_ERR_INVALID_ARG, "env2048_spawn_random: count %u exceeds the 16 cells of a board", count);
+    if (int rc = check_range(n, env_base)) return rc;
+    if (int rc = check_count(n)) return rc;
+    DeviceScope scope(device);
+    if (scope.rc) return scope.rc;
+    hipLaunchKernelGGL(spawn_random_kernel, grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, n, env_base, boards,
+                       (uint32_t)seed, (uint32_t)(seed >> 32), step_index, count);
+    return launched("env2048_spawn_random launch");
+}
+
+int env2048_encode_onehot(int device, void *stream, uint64_t n, const uint8_t *boards, uint32_t width, uint8_t *out)
+{
+    if (n == 0) return ENV2048_OK;
+    if (!boards || !out) return fail(ENV2048_ERR_INVALID_ARG, "env2048_encode_onehot: NULL argument");
+    if (width == 0 || width > 255) return fail(ENV2048_ERR_INVALID_ARG, "env2048_encode_onehot: width %u not in [1, 255]", width);
+    if (int rc = check_count(16 * n)) return rc;
+    DeviceScope scope(device);
+    if (scope.rc) return scope.rc;
+    hipLaunchKernelGGL(onehot_kernel, grid_for(16 * n), dim3(BLOCK), 0, (hipStream_t)stream, 16 * n, boards, width, out);
+    return launched("env2048_encode_onehot launch");
 }
 
 int env2048_status(int device, void *stream, uint64_t n, const uint8_t *boards, uint8_t *done, uint8_t *legal,

@@ -1,0 +1,168 @@
+"""
+Functional environment API with the interface of ``reinforce/game/env.py`` (reference lines cited
+per function): ``GameState``, ``reset``/``step``, the ``batched_*`` forms and the OOP
+``Environment`` wrapper.  State fields are ``torch`` tensors on the GPU.
+
+The batched forms are what ``reinforce/training/self_play.py:300,316-317,354`` calls once per
+move; each is one pack + one fused step kernel + one unpack here.  For throughput work use
+``simulate_2048_amd.BatchedEnv2048``, which keeps boards packed and skips the conversions.
+"""
+
+from __future__ import annotations
+
+from typing import NamedTuple
+
+import torch
+
+from ... import ops, runtime
+from .core import _board_tensor
+
+
+class GameState(NamedTuple):
+    """[ref env.py:33-52] board (4,4) int32, step_count int32, done bool, total_reward float32
+    (each with a leading N in the batched forms)."""
+
+    board: torch.Tensor
+    step_count: torch.Tensor
+    done: torch.Tensor
+    total_reward: torch.Tensor
+
+
+def _keys_to_seed(keys) -> int:
+    t = torch.as_tensor(keys)
+    return runtime.seed_to_u64(t.reshape(-1, 2)[0] if t.numel() >= 2 else t)
+
+
+def _max_tile_values(packed: torch.Tensor) -> torch.Tensor:
+    e = ops.status(packed, done=False, legal=False, max_exp=True)['max_exp'].to(torch.int32)
+    return torch.where(e > 0, torch.ones_like(e) << e, torch.zeros_like(e))
+
+
+def batched_reset(keys) -> GameState:
+    """[ref env.py:176-190] fresh games for every key row: keys (N, 2) -> GameState with leading N."""
+    rt = runtime.current()
+    n = int(torch.as_tensor(keys).reshape(-1, 2).shape[0])
+    packed = ops.reset(n, _keys_to_seed(keys))
+    return GameState(
+        board=ops.unpack(packed, dtype=torch.int32).reshape(n, 4, 4),
+        step_count=torch.zeros((n,), dtype=torch.int32, device=rt.device),
+        done=torch.zeros((n,), dtype=torch.bool, device=rt.device),
+        total_reward=torch.zeros((n,), dtype=torch.float32, device=rt.device),
+    )
+
+
+def batched_step(states: GameState, actions, keys):
+    """[ref env.py:193-211] one move per environment -> (GameState, reward (N,) f32, done (N,) bool, info).
+
+    Finished games are frozen exactly like the reference's done-guard (env.py:103-104): state
+    unchanged, reward 0.0, done True, step_count not advanced.
+    """
+    rt = runtime.current()
+    boards_in = _board_tensor(states.board).reshape(-1, 4, 4)
+    n = boards_in.shape[0]
+    done_in = torch.as_tensor(states.done).to(device=rt.device, dtype=torch.bool).reshape(n)
+    packed = ops.pack(boards_in.reshape(n, 16))
+    out = ops.step(packed, torch.as_tensor(actions).reshape(n), _keys_to_seed(keys), 0)
+    new_boards = ops.unpack(packed, dtype=torch.int32).reshape(n, 4, 4)
+    reward = out['reward'].to(torch.float32)
+    # ##>: env.py:111 -- done = is_done(new_board), the JAX is_done: "no legal action".
+    game_done = ops.status(packed, done=False, legal=True)['legal'] == 0
+    guard = done_in.view(n, 1, 1)
+    board = torch.where(guard, boards_in, new_boards)
+    reward = torch.where(done_in, torch.zeros_like(reward), reward)
+    done = done_in | game_done
+    step_count = torch.as_tensor(states.step_count).to(device=rt.device, dtype=torch.int32).reshape(n)
+    step_count = torch.where(done_in, step_count, step_count + 1)
+    total = torch.as_tensor(states.total_reward).to(device=rt.device, dtype=torch.float32).reshape(n) + reward
+    new_state = GameState(board=board, step_count=step_count, done=done, total_reward=total)
+    info = {
+        'max_tile': board.reshape(n, 16).max(dim=1).values,
+        'step_count': step_count,
+        'total_reward': total,
+    }
+    return new_state, reward, done, info
+
+
+def batched_get_observation(states: GameState) -> torch.Tensor:
+    """[ref env.py:214-228] (N, 16) float32 log2/16 observations."""
+    boards = _board_tensor(states.board).reshape(-1, 16)
+    return ops.status(ops.pack(boards), done=False, legal=False, obs=True)['obs']
+
+
+def batched_get_legal_actions(states: GameState) -> torch.Tensor:
+    """[ref env.py:231-245] (N, 4) bool legal-action masks."""
+    boards = _board_tensor(states.board).reshape(-1, 16)
+    bits = ops.status(ops.pack(boards), done=False, legal=True)['legal'].to(torch.int32)
+    return ((bits.unsqueeze(1) >> torch.arange(4, device=bits.device, dtype=torch.int32)) & 1).to(torch.bool)
+
+
+def _squeeze(state: GameState) -> GameState:
+    return GameState(state.board[0], state.step_count[0], state.done[0], state.total_reward[0])
+
+
+def _unsqueeze(state: GameState) -> GameState:
+    rt = runtime.current()
+    return GameState(
+        _board_tensor(state.board).reshape(1, 4, 4),
+        torch.as_tensor(state.step_count).to(device=rt.device, dtype=torch.int32).reshape(1),
+        torch.as_tensor(state.done).to(device=rt.device, dtype=torch.bool).reshape(1),
+        torch.as_tensor(state.total_reward).to(device=rt.device, dtype=torch.float32).reshape(1),
+    )
+
+
+def reset(key) -> GameState:
+    """[ref env.py:55-76] new game: board with two tiles, step_count 0, done False, total_reward 0."""
+    return _squeeze(batched_reset(torch.as_tensor(key).reshape(1, 2) if torch.as_tensor(key).numel() == 2 else [[0, int(key)]]))
+
+
+def step(state: GameState, action, key):
+    """[ref env.py:79-133] -> (GameState, reward f32, done bool, info dict)."""
+    new_state, reward, done, info = batched_step(_unsqueeze(state), [int(action)], key)
+    return _squeeze(new_state), reward[0], done[0], {k: v[0] for k, v in info.items()}
+
+
+def get_observation(state: GameState) -> torch.Tensor:
+    """[ref env.py:136-151] (16,) float32."""
+    return batched_get_observation(_unsqueeze(state))[0]
+
+
+def get_legal_actions(state: GameState) -> torch.Tensor:
+    """[ref env.py:154-169] (4,) bool."""
+    return batched_get_legal_actions(_unsqueeze(state))[0]
+
+
+class Environment:
+    """[ref env.py:248-304] stateful convenience wrapper; splits its own key per call."""
+
+    def __init__(self, seed: int = 0):
+        self.key = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self._draws = 0
+        self.state = self.reset_env()
+
+    def _subkey(self):
+        # ##>: stand-in for jax.random.split: a fresh 64-bit key per call, derived from (seed, draw index)
+        self._draws += 1
+        mixed = (self.key * 0x9E3779B97F4A7C15 + self._draws * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+        return [mixed >> 32, mixed & 0xFFFFFFFF]
+
+    def reset_env(self) -> GameState:
+        self.state = reset(self._subkey())
+        return self.state
+
+    def step_env(self, action: int):
+        self.state, reward, done, info = step(self.state, action, self._subkey())
+        return self.state, float(reward), bool(done), info
+
+    def observation(self) -> torch.Tensor:
+        return get_observation(self.state)
+
+    def legal_actions(self) -> torch.Tensor:
+        return get_legal_actions(self.state)
+
+    @property
+    def board(self) -> torch.Tensor:
+        return self.state.board
+
+    @property
+    def done(self) -> bool:
+        return bool(self.state.done)

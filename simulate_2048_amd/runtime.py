@@ -1,0 +1,82 @@
+"""
+Process-wide runtime used by the drop-in API mirrors: which C-ABI library and which device the
+single-board / functional shims run on.
+
+Default = the HIP library on the current HIP device; creating it without a usable GPU raises (no
+CPU fallback).  ``use(lib, device)`` swaps it temporarily -- the test-suite uses that to run the
+host-side logic of the shims against an oracle-backed stand-in on CPU tensors.
+"""
+
+from __future__ import annotations
+
+import contextlib
+import itertools
+import os
+
+import torch
+
+from . import capi
+
+
+class Runtime:
+    def __init__(self, lib, device):
+        self.lib = lib
+        self.device = torch.device(device)
+
+    def handles(self):
+        """(device ordinal, hipStream_t of torch's current stream) for a C-ABI call."""
+        if self.device.type != 'cuda':
+            return -1, None
+        index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        return index, torch.cuda.current_stream(self.device).cuda_stream
+
+    def synchronize(self) -> None:
+        if self.device.type == 'cuda':
+            torch.cuda.synchronize(self.device)
+
+
+_current: Runtime | None = None
+
+
+def current() -> Runtime:
+    global _current
+    if _current is None:
+        lib = capi.library()
+        if lib.device_count() <= 0 or not torch.cuda.is_available():
+            raise RuntimeError('simulate_2048_amd needs a HIP device: there is no CPU fallback')
+        _current = Runtime(lib, torch.device('cuda', torch.cuda.current_device()))
+    return _current
+
+
+@contextlib.contextmanager
+def use(lib, device):
+    """Temporarily run the API mirrors on another library/device pair."""
+    global _current
+    saved = _current
+    _current = Runtime(lib, device)
+    try:
+        yield _current
+    finally:
+        _current = saved
+
+
+# Unseeded calls of the reference draw from a module-level OS-entropy generator
+# (twentyfortyeight/core/gameboard.py:20) and are not reproducible; here they walk a Philox stream
+# keyed by OS entropy.
+_entropy_seed = int.from_bytes(os.urandom(8), 'little')
+_entropy_counter = itertools.count()
+
+
+def entropy_stream() -> tuple[int, int]:
+    """(seed, step_index) for one unseeded draw."""
+    return _entropy_seed, next(_entropy_counter)
+
+
+def seed_to_u64(seed) -> int:
+    """Reference seeds (Python ints for NumPy, 2 x uint32 PRNGKeys for JAX) -> 64-bit Philox key."""
+    if hasattr(seed, '__len__') or isinstance(seed, torch.Tensor):
+        flat = [int(x) for x in torch.as_tensor(seed).reshape(-1)[:2].tolist()]
+        if len(flat) == 1:
+            flat = [0, flat[0]]
+        return ((flat[0] & 0xFFFFFFFF) << 32) | (flat[1] & 0xFFFFFFFF)
+    return int(seed) & 0xFFFFFFFFFFFFFFFF

@@ -1,0 +1,111 @@
+"""
+Core 2048 board functions.  Mirror of ``twentyfortyeight/core/gameboard.py``: same names, argument
+meaning, return shapes/dtypes and error behaviour; the arithmetic runs in the HIP kernels
+(afterstate / spawn / status / step) through the C-ABI.  Reference lines are cited per function.
+
+Differences that cannot be avoided: boards must be 4x4; the random stream is
+Philox (``seed`` selects a reproducible stream, ``None`` an OS-entropy one) instead of NumPy PCG64.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+from numpy import argwhere, ndarray
+
+from ... import ops
+from ._device import host, rng_for, to_device, to_numpy
+
+# ##>: Tile spawn probabilities (90% for 2, 10% for 4) [ref gameboard.py:13].
+TILE_SPAWN_PROBS: dict[int, float] = {2: 0.9, 4: 0.1}
+
+
+def merge_column(column: ndarray) -> tuple[int, ndarray]:
+    """[ref gameboard.py:23-69] drop zeros, merge equal neighbours once, left to right.
+
+    Returns (score, merged column WITHOUT padding) like the reference.
+    """
+    column = np.asarray(column)
+    if column.ndim != 1 or column.shape[0] != 4:
+        raise ValueError(f'merge_column: the MI355X engine handles columns of length 4, got shape {column.shape}')
+    board = np.zeros((4, 4), dtype=np.int64)
+    board[0] = column
+    after, reward, _ = ops.afterstate(to_device(board), [0])
+    row = to_numpy(after, column.dtype)[0]
+    return int(host(reward)[0]), row[row != 0]
+
+
+def slide_and_merge(board: ndarray) -> tuple[float, ndarray]:
+    """[ref gameboard.py:72-102] slide every row left and merge; score is a float like the reference."""
+    board = np.asarray(board)
+    after, reward, _ = ops.afterstate(to_device(board), [0])
+    return 0.0 + float(host(reward)[0]), to_numpy(after, board.dtype)
+
+
+def latent_state(state: ndarray, action: int) -> tuple[ndarray, float]:
+    """[ref gameboard.py:105-129] afterstate of `action` (0 left, 1 up, 2 right, 3 down), no new tile."""
+    state = np.asarray(state)
+    after, reward, _ = ops.afterstate(to_device(state), [int(action) & 3])
+    return to_numpy(after, state.dtype), 0.0 + float(host(reward)[0])
+
+
+def after_state(state: ndarray) -> list[tuple[ndarray, float]]:
+    """[ref gameboard.py:132-171] every (cell, value) spawn outcome with its probability."""
+    state = np.asarray(state)
+    num_empty_cells = int((state == 0).sum())
+    if num_empty_cells == 0:
+        return [(state, 1.0)]
+    # ##>: One device board per outcome: cell rank k (row-major) x value {2, 4}, same order as the reference.
+    ranks = np.repeat(np.arange(num_empty_cells, dtype=np.uint8), 2)
+    exps = np.tile(np.array([1, 2], dtype=np.uint8), num_empty_cells)
+    boards = to_device(state).repeat(2 * num_empty_cells, 1)
+    ops.spawn(boards, ranks, exps)
+    values = host(ops.unpack(boards)).reshape(-1, 4, 4).astype(state.dtype, copy=False)
+    return [(values[i], TILE_SPAWN_PROBS[2 if i % 2 == 0 else 4] / num_empty_cells) for i in range(values.shape[0])]
+
+
+def after_state_lazy(state: ndarray) -> tuple[ndarray, list[tuple[int, int]], int]:
+    """[ref gameboard.py:174-202] (state reference, empty cells row-major, their count); nothing computed."""
+    empty_cells = argwhere(state == 0)
+    return state, [(int(c[0]), int(c[1])) for c in empty_cells], len(empty_cells)
+
+
+def generate_outcome(state: ndarray, cell: tuple[int, int], value: int, num_empty: int) -> tuple[ndarray, float]:
+    """[ref gameboard.py:205-244] copy of `state` with `value` at `cell`, probability P(value)/num_empty."""
+    if num_empty <= 0:
+        raise ValueError(f'num_empty must be > 0, got {num_empty}')
+    new_state = state.copy()
+    new_state[cell] = value
+    return new_state, TILE_SPAWN_PROBS[value] / num_empty
+
+
+def fill_cells(state: ndarray, number_tile: int, seed: int | None = None) -> ndarray:
+    """[ref gameboard.py:247-288] add `number_tile` tiles (2 w.p. 0.9, 4 w.p. 0.1) to random empty
+    cells.  **Mutates `state` in place** and returns it, like the reference."""
+    num_available = int((state == 0).sum())
+    if num_available == 0:
+        return state
+    number_tile = min(int(number_tile), num_available)
+    boards = to_device(state)
+    stream_seed, step = rng_for(seed)
+    ops.spawn_random(boards, stream_seed, step, number_tile)
+    state[...] = to_numpy(boards, state.dtype)
+    return state
+
+
+def next_state(state: ndarray, action: int, seed: int | None = None) -> tuple[ndarray, float]:
+    """[ref gameboard.py:291-325] full transition: move, then one new tile iff the board changed.
+
+    An invalid move returns the SAME `state` object and the int 0, like the reference (:325).
+    """
+    boards = to_device(state)
+    stream_seed, step = rng_for(seed)
+    out = ops.step(boards, [int(action) & 3], stream_seed, step)
+    after = to_numpy(boards, np.asarray(state).dtype)
+    if np.array_equal(after, state):
+        return state, 0
+    return after, 0.0 + float(host(out['reward'])[0])
+
+
+def is_done(state: ndarray) -> bool:
+    """[ref gameboard.py:328-348] no empty cell and no equal horizontal / vertical neighbours."""
+    return bool(host(ops.status(to_device(state), done=True, legal=False)['done'])[0])

@@ -1,0 +1,23 @@
+"""One-hot (log2) observation encoding.  Mirror of ``twentyfortyeight/utils/binary.py``."""
+
+from __future__ import annotations
+
+import numpy as np
+from numpy import int64, ndarray
+
+from ... import ops
+
+
+def encode(state: ndarray, encodage_size: int) -> ndarray:
+    """[ref binary.py:11-50] eye(encodage_size)[log2(state)] (0 stays index 0): shape (state.size, size)."""
+    flat = np.asarray(state).reshape(-1).astype(np.int64)
+    if flat.size % 16:
+        raise ValueError(f'encode: the MI355X engine encodes whole 4x4 boards (16 cells), got {flat.size} cells')
+    packed = ops.pack(flat.reshape(-1, 16))
+    out = ops.onehot(packed, int(encodage_size)).cpu().numpy()
+    return out.reshape(flat.size, int(encodage_size)).astype(int64)
+
+
+def encode_flatten(state: ndarray, encodage_size: int) -> ndarray:
+    """[ref binary.py:53-86] flatten, then encode, then ravel: length state.size * encodage_size."""
+    return encode(np.asarray(state).ravel(), encodage_size).ravel()

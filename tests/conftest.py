@@ -7,6 +7,8 @@ import numpy as np
 import pytest
 
 REPO = Path(__file__).resolve().parent.parent
+if str(REPO / 'tests') not in sys.path:
+    sys.path.insert(0, str(REPO / 'tests'))
 if str(REPO) not in sys.path:
     sys.path.insert(0, str(REPO))
 
@@ -46,3 +48,18 @@ def pytest_sessionstart(session):
     import oracle
 
     oracle.build()
+
+
+@pytest.fixture(params=['host-logic', pytest.param('hip', marks=pytest.mark.gpu)])
+def api_runtime(request):
+    """Run an API-mirror test twice: with the oracle-backed stand-in library on CPU tensors (checks
+    the host-side logic in a container without a GPU) and with the real HIP library on the GPU."""
+    from simulate_2048_amd import runtime
+
+    if request.param == 'hip':
+        yield runtime.current()
+    else:
+        from oracle_backend import OracleLibrary
+
+        with runtime.use(OracleLibrary(), 'cpu') as rt:
+            yield rt

@@ -1,0 +1,127 @@
+"""
+TEST-ONLY stand-in for ``simulate_2048_amd.capi.Library``: the same method signatures, but the
+pointers are HOST pointers (CPU torch tensors / NumPy arrays) and the work is done by the CPU
+oracle.  It exists so that the host-side logic of the package (buffer management, API mirrors,
+sharding) can be exercised by ``-m "not gpu"`` tests in a container without a GPU.  The product
+never imports it: ``simulate_2048_amd`` refuses CPU devices unless a library object is injected
+explicitly, and only tests do that.
+"""
+
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+import oracle
+
+
+def _view(ptr, count, dtype):
+    if ptr is None or count == 0:
+        return None
+    nbytes = count * np.dtype(dtype).itemsize
+    buf = (ctypes.c_uint8 * nbytes).from_address(int(ptr))
+    return np.frombuffer(buf, dtype=dtype, count=count)
+
+
+class OracleLibrary:
+    """Drop-in for capi.Library over host memory. `device`/`stream` arguments are ignored."""
+
+    def __init__(self):
+        self.calls = []  # (name, n) log, handy for asserting launch counts in host-logic tests
+
+    def abi_version(self):
+        return 1
+
+    def device_count(self):
+        return 1
+
+    def last_error(self):
+        return ''
+
+    def reset(self, device, stream, n, env_base, boards, done, seed, step_index):
+        self.calls.append(('reset', n))
+        b, _ = oracle.reset_batch(n, seed, step_index, env_base=env_base)
+        _view(boards, n * 16, np.uint8)[:] = b.reshape(-1)
+        if done is not None:
+            _view(done, n, np.uint8)[:] = 0
+
+    def step(self, device, stream, n, env_base, boards, actions, reward, done, legal, obs, seed, step_index, flags):
+        self.calls.append(('step', n))
+        b = _view(boards, n * 16, np.uint8)
+        a = None if actions is None else _view(actions, n, np.uint8).copy()
+        res = oracle.step_batch(b.reshape(n, 16), a, seed, step_index, env_base=env_base, flags=flags,
+                                want_legal=legal is not None, want_obs=obs is not None)
+        b[:] = res['boards'].reshape(-1)
+        if reward is not None:
+            _view(reward, n, np.int32)[:] = res['reward']
+        _view(done, n, np.uint8)[:] = res['done']
+        if legal is not None:
+            _view(legal, n, np.uint8)[:] = res['legal']
+        if obs is not None:
+            _view(obs, n * 16, np.float32)[:] = res['obs'].reshape(-1)
+
+    def rollout(self, device, stream, n, env_base, boards, seed, step0, T, return_sum, episodes, valid_moves, flags):
+        self.calls.append(('rollout', n))
+        b = _view(boards, n * 16, np.uint8)
+        res = oracle.rollout_batch(b.reshape(n, 16), seed, step0, T, env_base=env_base, flags=flags)
+        b[:] = res['boards'].reshape(-1)
+        if return_sum is not None:
+            _view(return_sum, n, np.int64)[:] = res['return_sum']
+        if episodes is not None:
+            _view(episodes, n, np.uint32)[:] = res['episodes']
+        if valid_moves is not None:
+            _view(valid_moves, n, np.uint32)[:] = res['valid_moves']
+
+    def afterstate(self, device, stream, n, boards_in, actions, boards_out, reward, changed):
+        self.calls.append(('afterstate', n))
+        res = oracle.afterstate_batch(_view(boards_in, n * 16, np.uint8).reshape(n, 16).copy(), _view(actions, n, np.uint8).copy())
+        _view(boards_out, n * 16, np.uint8)[:] = res['boards'].reshape(-1)
+        if reward is not None:
+            _view(reward, n, np.int32)[:] = res['reward']
+        if changed is not None:
+            _view(changed, n, np.uint8)[:] = res['changed']
+
+    def spawn(self, device, stream, n, boards, spawn_k, spawn_e, placed):
+        self.calls.append(('spawn', n))
+        b = _view(boards, n * 16, np.uint8)
+        res = oracle.spawn_batch(b.reshape(n, 16), _view(spawn_k, n, np.uint8).copy(), _view(spawn_e, n, np.uint8).copy())
+        b[:] = res['boards'].reshape(-1)
+        if placed is not None:
+            _view(placed, n, np.uint8)[:] = res['placed']
+
+    def spawn_random(self, device, stream, n, env_base, boards, seed, step_index, count):
+        self.calls.append(('spawn_random', n))
+        b = _view(boards, n * 16, np.uint8)
+        b[:] = oracle.spawn_random_batch(b.reshape(n, 16), seed, step_index, count, env_base=env_base).reshape(-1)
+
+    def status(self, device, stream, n, boards, done, legal, obs, max_exp, n_empty):
+        self.calls.append(('status', n))
+        res = oracle.status_batch(_view(boards, n * 16, np.uint8).reshape(n, 16).copy())
+        for ptr, key, dtype, width in ((done, 'done', np.uint8, 1), (legal, 'legal', np.uint8, 1), (obs, 'obs', np.float32, 16),
+                                       (max_exp, 'max_exp', np.uint8, 1), (n_empty, 'n_empty', np.uint8, 1)):
+            if ptr is not None:
+                _view(ptr, n * width, dtype)[:] = res[key].reshape(-1)
+
+    def encode_onehot(self, device, stream, n, boards, width, out):
+        self.calls.append(('encode_onehot', n))
+        res = oracle.encode_onehot(_view(boards, n * 16, np.uint8).reshape(n, 16).copy(), width)
+        _view(out, n * 16 * width, np.uint8)[:] = res.reshape(-1)
+
+    def _pack(self, n, values, boards, dtype):
+        _view(boards, n * 16, np.uint8)[:] = oracle.pack_values(_view(values, n * 16, dtype)).reshape(-1)
+
+    def _unpack(self, n, boards, values, dtype):
+        _view(values, n * 16, dtype)[:] = oracle.unpack_values(_view(boards, n * 16, np.uint8)).astype(dtype)
+
+    def pack_i32(self, device, stream, n, values, boards):
+        self._pack(n, values, boards, np.int32)
+
+    def unpack_i32(self, device, stream, n, boards, values):
+        self._unpack(n, boards, values, np.int32)
+
+    def pack_i64(self, device, stream, n, values, boards):
+        self._pack(n, values, boards, np.int64)
+
+    def unpack_i64(self, device, stream, n, boards, values):
+        self._unpack(n, boards, values, np.int64)

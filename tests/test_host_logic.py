@@ -1,0 +1,190 @@
+"""
+Host-side logic that needs no GPU: the C-ABI surface of the built library, loud failure without a
+device, BatchedEnv2048 buffer/step bookkeeping (through the oracle-backed stand-in), sharding
+arithmetic and a 2-process gloo run of the sharded path.
+"""
+
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import REPO
+from oracle_backend import OracleLibrary
+from simulate_2048_amd import BatchedEnv2048, capi
+from simulate_2048_amd.sharding import shard_range
+
+
+def test_library_exports_every_declared_symbol():
+    header = (REPO / 'include' / 'env2048.h').read_text()
+    declared = set(re.findall(r'\b(env2048_[a-z0-9_]+)\s*\(', header))
+    assert declared == set(capi.PROTOTYPES), declared ^ set(capi.PROTOTYPES)
+    dll = ctypes.CDLL(str(capi.LIB_PATH))
+    for name in declared:
+        assert hasattr(dll, name), name
+    assert capi.Library().abi_version() == capi.ABI_VERSION
+    assert f'#define ENV2048_ABI_VERSION {capi.ABI_VERSION}' in header
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='checks the behaviour on a machine WITHOUT a GPU')
+def test_product_fails_loudly_without_gpu():
+    lib = capi.Library()
+    with pytest.raises(capi.Env2048Error) as e:
+        lib.device_count()
+    assert e.value.code == capi.ERR_DEVICE
+    buf = np.zeros(64, dtype=np.uint8)
+    ptr = (buf.ctypes.data + 15) // 16 * 16
+    with pytest.raises(capi.Env2048Error) as e:  # valid arguments, no device -> ERR_DEVICE, never a CPU result
+        lib.step(0, None, 1, 0, ptr, ptr + 16, None, ptr + 32, None, None, 0, 0, 0)
+    assert e.value.code == capi.ERR_DEVICE and 'no CPU fallback' in str(e.value)
+    with pytest.raises(capi.Env2048Error) as e:  # argument errors are reported before the device is touched
+        lib.step(0, None, 1, 0, None, None, None, None, None, None, 0, 0, 0)
+    assert e.value.code == capi.ERR_INVALID_ARG
+    with pytest.raises(capi.Env2048Error) as e:
+        lib.step(0, None, 1, 0, ptr + 1, ptr + 16, None, ptr + 32, None, None, 0, 0, 0)
+    assert e.value.code == capi.ERR_ALIGNMENT
+    with pytest.raises(RuntimeError):
+        BatchedEnv2048(8, device='cuda')  # no HIP device
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        BatchedEnv2048(8, device='cpu')  # CPU devices are refused outright
+    from simulate_2048_amd import runtime
+
+    with pytest.raises((RuntimeError, capi.Env2048Error)):
+        runtime.current()
+    lib.step(0, None, 0, 0, None, None, None, None, None, None, 0, 0, 0)  # n = 0 stays a no-op
+
+
+def test_missing_library_raises(tmp_path):
+    with pytest.raises(FileNotFoundError, match='no CPU fallback'):
+        capi.Library(tmp_path / 'libenv2048.so')
+
+
+def test_product_package_never_imports_the_oracle():
+    code = 'import sys, simulate_2048_amd, simulate_2048_amd.twentyfortyeight.envs.twentyfortyeight, ' \
+           'simulate_2048_amd.reinforce.game.env, simulate_2048_amd.sharding; ' \
+           'assert not any(m == "oracle" or m.startswith("oracle.") for m in sys.modules), "oracle imported"'
+    subprocess.run([sys.executable, '-c', code], check=True, cwd=REPO)
+    for path in (REPO / 'simulate_2048_amd').rglob('*.py'):
+        text = path.read_text()
+        assert not re.search(r'^\s*(import oracle|from oracle)', text, flags=re.M), path
+
+
+def test_batched_env_bookkeeping():
+    lib = OracleLibrary()
+    env = BatchedEnv2048(300, seed=9, device='cpu', env_base=40, auto_reset=True, with_legal=True, with_obs=True, lib=lib)
+    boards = env.reset()
+    ref, _ = oracle.reset_batch(300, 9, 0, env_base=40)
+    np.testing.assert_array_equal(boards.numpy(), ref)
+    np.testing.assert_array_equal(env.legal.numpy(), oracle.status_batch(ref)['legal'])
+    rng = np.random.default_rng(0)
+    for t in range(30):
+        actions = torch.from_numpy(rng.integers(0, 4, size=300).astype(np.int64))  # wrong dtype on purpose: converted
+        b, r, d = env.step(actions)
+        res = oracle.step_batch(ref, actions.numpy().astype(np.uint8), 9, t, env_base=40, flags=1, want_legal=True, want_obs=True)
+        ref = res['boards']
+        np.testing.assert_array_equal(b.numpy(), ref)
+        np.testing.assert_array_equal(r.numpy(), res['reward'])
+        np.testing.assert_array_equal(env.obs.numpy(), res['obs'])
+    assert env.step_index == 30 and b.data_ptr() == env.boards.data_ptr()  # persistent buffers, in place
+    env.step(None)  # on-device random actions
+    ref = oracle.step_batch(ref, None, 9, 30, env_base=40, flags=3)['boards']
+    np.testing.assert_array_equal(env.boards.numpy(), ref)
+    out = env.rollout(50)
+    ro = oracle.rollout_batch(ref, 9, 31, 50, env_base=40, flags=3)
+    np.testing.assert_array_equal(env.boards.numpy(), ro['boards'])
+    np.testing.assert_array_equal(out['return_sum'].numpy(), ro['return_sum'])
+    assert env.step_index == 81
+    with pytest.raises(ValueError):
+        env.step(torch.zeros(5, dtype=torch.uint8))
+    st = env.status()
+    np.testing.assert_array_equal(st['n_empty'].numpy(), (ro['boards'] == 0).sum(axis=1))
+    assert [c[0] for c in lib.calls[:3]] == ['reset', 'status', 'step']
+
+
+def test_shard_range_covers_everything_once():
+    for total in (0, 1, 5, 1024, (1 << 20) + 3, 8 << 20):
+        for world in (1, 2, 3, 4, 8):
+            slices = [shard_range(total, r, world) for r in range(world)]
+            assert sum(c for _, c in slices) == total
+            pos = 0
+            for base, count in slices:
+                assert base == pos or count == 0
+                assert base % 4 == 0 or count == 0
+                pos += count
+    assert shard_range(8 << 20, 3, 8) == (3 << 20, 1 << 20)  # BASELINE config 4: 8 x 2^20
+    with pytest.raises(ValueError):
+        shard_range(10, 2, 2)
+
+
+def test_sharded_run_equals_single_run():
+    """Slices with env_base = slice start reproduce the unsliced batch exactly (host logic, 3 'ranks')."""
+    total, seed, T = 1000, 77, 25
+    whole = BatchedEnv2048(total, seed, device='cpu', auto_reset=True, lib=OracleLibrary())
+    whole.reset()
+    parts = []
+    for r in range(3):
+        base, count = shard_range(total, r, 3)
+        e = BatchedEnv2048(count, seed, device='cpu', env_base=base, auto_reset=True, lib=OracleLibrary())
+        e.reset()
+        parts.append(e)
+    for _ in range(T):
+        whole.step(None)
+        for e in parts:
+            e.step(None)
+    np.testing.assert_array_equal(torch.cat([e.boards for e in parts]).numpy(), whole.boards.numpy())
+
+
+WORKER = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["REPO"]); sys.path.insert(0, os.path.join(os.environ["REPO"], "tests"))
+from oracle_backend import OracleLibrary
+from simulate_2048_amd.sharding import make_sharded_env, global_stats, rank_info
+dist.init_process_group("gloo")
+rank, world, _ = rank_info()
+env = make_sharded_env(2048 + 4, 123, device="cpu", auto_reset=True, lib=OracleLibrary())
+env.reset()
+total_reward = 0
+episodes = 0
+for t in range(40):
+    _, r, d = env.step(None)
+    total_reward += int(r.sum()); episodes += int(d.sum())
+dist.barrier()
+stats = global_stats({"reward": total_reward, "episodes": episodes, "envs": env.num_envs})
+gathered = [None] * world
+dist.all_gather_object(gathered, (env.env_base, env.boards.numpy()))
+if rank == 0:
+    gathered.sort(key=lambda x: x[0])
+    np.save(os.environ["OUT"], np.concatenate([b for _, b in gathered]))
+    print("STATS", int(stats["reward"]), int(stats["episodes"]), int(stats["envs"]))
+dist.destroy_process_group()
+'''
+
+
+def test_two_process_gloo_sharding(tmp_path):
+    """world_size 2 over gloo: each rank steps its slice, no collective in the loop; the gathered
+    boards equal the single-process run and the reduced statistics add up."""
+    out = tmp_path / 'boards.npy'
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER)
+    env = dict(os.environ, REPO=str(REPO), OUT=str(out), OMP_NUM_THREADS='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+           '--master-port', '29531', str(script)]
+    proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    total = 2048 + 4
+    ref, _ = oracle.reset_batch(total, 123, 0)
+    reward = episodes = 0
+    for t in range(40):
+        res = oracle.step_batch(ref, None, 123, t, flags=3)
+        ref = res['boards']
+        reward += int(res['reward'].sum())
+        episodes += int(res['done'].sum())
+    np.testing.assert_array_equal(np.load(out), ref)
+    stats = re.search(r'STATS (\d+) (\d+) (\d+)', proc.stdout)
+    assert stats and [int(x) for x in stats.groups()] == [reward, episodes, total]
