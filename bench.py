@@ -58,7 +58,7 @@ def cpu_baseline(boards_np, seconds: float):
 
     import oracle
 
-    threads = max(1, min(os.cpu_count() or 1, len(os.sched_getaffinity(0))))
+    threads = usable_cores()
     if not oracle.openmp_enabled():
         threads = 1
     n = boards_np.shape[0]
@@ -84,6 +84,19 @@ def cpu_baseline(boards_np, seconds: float):
         'sample': f'{steps} steps x {n} boards (same mid-game boards, auto-reset, host uint8 actions) in {elapsed:.1f} s; '
                   f'oracle/env2048_oracle.c, gcc -O2 -fopenmp; reference NumPy engine itself: ~1.0e4 steps/s/core (BASELINE.md)',
     }
+
+
+def usable_cores() -> int:
+    """CPU threads this process may really use: affinity mask, capped by the cgroup CPU quota and by
+    the 16-core share a one-GPU box gets (an oversubscribed OpenMP team is slower, not faster)."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = Path('/sys/fs/cgroup/cpu.max').read_text().split()
+        if quota != 'max':
+            cores = min(cores, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(cores, int(os.environ.get('ENV2048_CPU_THREADS', '16'))))
 
 
 def load_traffic(boards: int):
