@@ -140,18 +140,18 @@ ENV2048_DEV uint32_t slide_merge_planes(uint32_t &a, uint32_t &b, uint32_t &c, u
     c = bsel(s2, d1, c1);
     d = d1 & ~s2;
 
-    // score = sum over merged cells of 2^exponent.  Summing 1 << byte over all eight bytes adds
-    // a spurious 1 for every byte without a merge; take those back out.
-    uint32_t n_merged = ENV2048_POPC(x_ab | x_bc) + ENV2048_POPC(x_cd);
-    uint32_t s = n_merged - 8u;
-    s += 1u << (v1 & 0xFFu);
-    s += 1u << ((v1 >> 8) & 0xFFu);
-    s += 1u << ((v1 >> 16) & 0xFFu);
-    s += 1u << (v1 >> 24);
-    s += 1u << (v2 & 0xFFu);
-    s += 1u << ((v2 >> 8) & 0xFFu);
-    s += 1u << ((v2 >> 16) & 0xFFu);
-    s += 1u << (v2 >> 24);
+    // score = sum over merged cells of 2^exponent: shift the 0/1 merge flag of each byte lane by
+    // that lane's merged exponent (one SDWA v_lshlrev per byte: both operands byte-selected), so
+    // lanes without a merge contribute 0.
+    const uint32_t f1 = x_ab | x_bc, f2 = x_cd;
+    uint32_t s = (f1 & 0xFFu) << (v1 & 0xFFu);
+    s += ((f1 >> 8) & 0xFFu) << ((v1 >> 8) & 0xFFu);
+    s += ((f1 >> 16) & 0xFFu) << ((v1 >> 16) & 0xFFu);
+    s += (f1 >> 24) << (v1 >> 24);
+    s += (f2 & 0xFFu) << (v2 & 0xFFu);
+    s += ((f2 >> 8) & 0xFFu) << ((v2 >> 8) & 0xFFu);
+    s += ((f2 >> 16) & 0xFFu) << ((v2 >> 16) & 0xFFu);
+    s += (f2 >> 24) << (v2 >> 24);
     return s;
 }
 
@@ -410,7 +410,9 @@ ENV2048_DEV void transition(Board &bd, const DirSelectors &sel, uint32_t word, u
 {
     afterstate_sel(bd, sel, reward, changed);
     const uint32_t empties_left = spawn_tile_word(bd, word, changed);
-    done = (empties_left == 0u) && no_equal_neighbours(bd);
+    // evaluated unconditionally (bitwise &, no short-circuit): some lane of nearly every wave has a
+    // full board, so a branch here saves nothing and only splits the scheduling region
+    done = (empties_left == 0u) & no_equal_neighbours(bd);
 }
 
 }  // namespace env2048

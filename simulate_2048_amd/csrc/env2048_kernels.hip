@@ -9,6 +9,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "env2048.h"
 #include "board_ops.hpp"
@@ -17,7 +18,10 @@ using namespace env2048;
 
 namespace {
 
-constexpr int BLOCK = 256;
+#ifndef ENV2048_BLOCK
+#define ENV2048_BLOCK 512
+#endif
+constexpr int BLOCK = ENV2048_BLOCK;
 
 __device__ __forceinline__ Board load_board(const uint8_t *boards, uint64_t i)
 {
@@ -65,7 +69,10 @@ __device__ __forceinline__ void store_obs(float *obs, uint64_t i, const Board &b
 // are queued in LDS and the block's first threads rebuild all of them after one barrier.
 // ------------------------------------------------------------------------------------------
 constexpr int WAVES_PER_BLOCK = BLOCK / 64;
-constexpr int BOARDS_PER_LANE = 4;
+#ifndef ENV2048_BOARDS_PER_LANE
+#define ENV2048_BOARDS_PER_LANE 4
+#endif
+constexpr int BOARDS_PER_LANE = ENV2048_BOARDS_PER_LANE;
 constexpr int TILE_BOARDS = 64 * BOARDS_PER_LANE;                  // per wave
 constexpr int BLOCK_BOARDS = TILE_BOARDS * WAVES_PER_BLOCK;       // per block
 constexpr int WORD_STRIP = TILE_BOARDS + 4 + 4;                   // 65 Philox blocks (+ pad to 16 B)
@@ -96,12 +103,17 @@ __device__ __forceinline__ DirSelectors load_selectors(const uint4 *dir_lds, uin
 __device__ __forceinline__ void fill_word_strip(uint32_t *strip, const RngKey &key, uint64_t env0, uint32_t lane)
 {
     const uint64_t group0 = env0 >> 2;
+    constexpr uint32_t GROUPS = TILE_BOARDS / 4;  // Philox blocks an aligned tile needs
     uint32_t w0, w1, w2, w3;
     env_block(key, group0 + lane, STREAM_STEP, w0, w1, w2, w3);
-    reinterpret_cast<uint4 *>(strip)[lane] = make_uint4(w0, w1, w2, w3);
-    if (env0 & 3u) {  // wave-uniform: the tile straddles a 65th block
-        env_block(key, group0 + 64u, STREAM_STEP, w0, w1, w2, w3);
-        if (lane == 0u) reinterpret_cast<uint4 *>(strip)[64] = make_uint4(w0, w1, w2, w3);
+    if (GROUPS == 64u) {
+        reinterpret_cast<uint4 *>(strip)[lane] = make_uint4(w0, w1, w2, w3);
+        if (env0 & 3u) {  // wave-uniform: the tile straddles a 65th block
+            env_block(key, group0 + 64u, STREAM_STEP, w0, w1, w2, w3);
+            if (lane == 0u) reinterpret_cast<uint4 *>(strip)[64] = make_uint4(w0, w1, w2, w3);
+        }
+    } else if (lane <= GROUPS) {  // spare lanes: the straddling block costs nothing extra
+        reinterpret_cast<uint4 *>(strip)[lane] = make_uint4(w0, w1, w2, w3);
     }
     // The strip is private to this wave and a wave's LDS operations execute in order, so no
     // s_barrier is needed -- only a compiler-level fence so the cross-lane reads stay behind the writes.
@@ -109,59 +121,16 @@ __device__ __forceinline__ void fill_word_strip(uint32_t *strip, const RngKey &k
     __builtin_amdgcn_wave_barrier();
 }
 
-#ifndef ENV2048_EXP_RESET_MODE
-#define ENV2048_EXP_RESET_MODE 1  // 0: barrier, then the block's first threads reset; 1: last wave out resets
-#endif
+// s_waitcnt vmcnt(0) only (expcnt / lgkmcnt left at their maxima): gfx9 encoding.
+#define ENV2048_WAIT_ALL_VMEM() __builtin_amdgcn_s_waitcnt(0x0F70)
 
-// One wave tile of the step kernel.  FULL: all 256 boards of the tile exist (no bounds checks).
-template <bool EXTRAS, bool FULL>
-__device__ __forceinline__ void step_tile(const StepArgs &a, const uint4 *dir_lds, uint32_t *strip,
-                                          uint32_t *reset_count, uint16_t *reset_slot, uint64_t tile0, uint32_t wave,
-                                          uint32_t lane)
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() would also drain vmcnt, i.e.
+// wait for the board loads that are deliberately still in flight across it.
+__device__ __forceinline__ void lds_barrier()
 {
-    const uint64_t env0 = a.env_base + tile0;
-    const bool auto_reset = (a.flags & ENV2048_FLAG_AUTO_RESET) != 0u;
-    const bool random_actions = (a.flags & ENV2048_FLAG_RANDOM_ACTIONS) != 0u;
-
-    // issue the board (and action) loads first: their latency hides behind the Philox rounds
-    Board bd[BOARDS_PER_LANE];
-    uint32_t act[BOARDS_PER_LANE];
-#pragma unroll
-    for (int j = 0; j < BOARDS_PER_LANE; ++j) {
-        const uint64_t i = tile0 + 64u * j + lane;
-        bd[j] = Board{0u, 0u, 0u, 0u};
-        act[j] = 0u;
-        if (FULL || i < a.n) {
-            bd[j] = load_board(a.boards, i);
-            if (!random_actions) act[j] = a.actions[i];
-        }
-    }
-
-    fill_word_strip(strip, a.key, env0, lane);
-    const uint32_t strip_off = (uint32_t)env0 & 3u;
-
-#pragma unroll
-    for (int j = 0; j < BOARDS_PER_LANE; ++j) {
-        const uint64_t i = tile0 + 64u * j + lane;
-        if (!FULL && i >= a.n) continue;
-        const uint32_t word = strip[strip_off + 64u * j + lane];
-        const uint32_t action = (random_actions ? word : act[j]) & 3u;
-        uint32_t reward;
-        bool changed, done;
-        transition(bd[j], load_selectors(dir_lds, action), word, reward, changed, done);
-        if (auto_reset && done) {
-            const uint32_t slot = atomicAdd(reset_count, 1u);
-            reset_slot[slot] = (uint16_t)(wave * TILE_BOARDS + 64u * j + lane);
-        } else {
-            store_board(a.boards, i, bd[j]);
-            if (EXTRAS) {
-                if (a.legal) a.legal[i] = (uint8_t)legal_mask(bd[j]);
-                if (a.obs) store_obs(a.obs, i, bd[j]);
-            }
-        }
-        if (a.reward) a.reward[i] = (int32_t)reward;
-        a.done[i] = done ? 1 : 0;
-    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
 // Rebuild the queued (terminal) boards of this block; executed by `nthreads` threads with ids `t`.
@@ -182,8 +151,145 @@ __device__ __forceinline__ void reset_queued(const StepArgs &a, uint64_t block0,
     }
 }
 
-// EXTRAS: legal and/or obs requested (kept out of the base variant so it stays lean).
-template <bool EXTRAS>
+// The step kernel.  Order of events in a wave (it matters: vmcnt counts loads AND stores in issue
+// order, so a wait for a load that is placed after a store also waits for that store's ack):
+//   1. issue the selector-table load (8 lanes) and the 4 board + 4 action loads of the tile
+//   2. 64 (65) Philox blocks while those are in flight; words -> wave-private LDS strip
+//   3. selector table -> LDS; LDS-only workgroup barrier
+//   4. ONE wait for all loads, then the four transitions with stores issued as results appear and
+//      no further memory waits
+//   5. queue terminal boards; the last wave of the block to finish rebuilds them
+// EXTRAS: legal and/or obs requested.  FULL: every board of the block exists (no bounds checks);
+// RANDOM: actions come from the step words instead of memory.
+template <bool EXTRAS, bool FULL, bool RANDOM>
+__device__ __forceinline__ void step_block(const StepArgs &a, uint4 *dir_lds, uint32_t (*word_lds)[WORD_STRIP],
+                                           uint32_t *reset_count, uint32_t *waves_finished, uint16_t *reset_slot)
+{
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint64_t block0 = (uint64_t)blockIdx.x * BLOCK_BOARDS;  // first board of this block (local index)
+    const uint64_t tile0 = block0 + (uint64_t)wave * TILE_BOARDS;
+    const uint64_t env0 = a.env_base + tile0;
+    const bool auto_reset = (a.flags & ENV2048_FLAG_AUTO_RESET) != 0u;
+
+#if defined(ENV2048_EXP_PRIO) && ENV2048_EXP_PRIO == 1  // grid quartiles: earlier blocks first
+    { const uint32_t p = 3u - min(3u, blockIdx.x * 4u / gridDim.x); if (p == 3u) __builtin_amdgcn_s_setprio(3); else if (p == 2u) __builtin_amdgcn_s_setprio(2); else if (p == 1u) __builtin_amdgcn_s_setprio(1); }
+#elif defined(ENV2048_EXP_PRIO) && ENV2048_EXP_PRIO == 2  // co-resident blocks of a CU differ in bits 8..9
+    { const uint32_t p = 3u - ((blockIdx.x >> 8) & 3u); if (p == 3u) __builtin_amdgcn_s_setprio(3); else if (p == 2u) __builtin_amdgcn_s_setprio(2); else if (p == 1u) __builtin_amdgcn_s_setprio(1); }
+#elif defined(ENV2048_EXP_PRIO) && ENV2048_EXP_PRIO == 3  // bits 5..6
+    { const uint32_t p = 3u - ((blockIdx.x >> 5) & 3u); if (p == 3u) __builtin_amdgcn_s_setprio(3); else if (p == 2u) __builtin_amdgcn_s_setprio(2); else if (p == 1u) __builtin_amdgcn_s_setprio(1); }
+#elif defined(ENV2048_EXP_PRIO) && ENV2048_EXP_PRIO == 4  // low bits
+    { const uint32_t p = 3u - (blockIdx.x & 3u); if (p == 3u) __builtin_amdgcn_s_setprio(3); else if (p == 2u) __builtin_amdgcn_s_setprio(2); else if (p == 1u) __builtin_amdgcn_s_setprio(1); }
+#endif
+#if defined(ENV2048_EXP_STAGGER) && ENV2048_EXP_STAGGER > 0  // odd blocks start late (units of 64 cycles)
+    if (blockIdx.x & 1u) {
+        for (int k = 0; k < ENV2048_EXP_STAGGER / 100; ++k) __builtin_amdgcn_s_sleep(100);
+        __builtin_amdgcn_s_sleep(ENV2048_EXP_STAGGER % 100);
+    }
+#endif
+#ifdef ENV2048_EXP_STAMPS  // diagnostic build: wave timeline stamps into the (otherwise unused) obs buffer
+    uint64_t stamp0 = __builtin_amdgcn_s_memtime(), stamp1 = 0, stamp2 = 0;
+#endif
+    // 1. loads
+    uint4 table_row = make_uint4(0u, 0u, 0u, 0u);
+    if (tid < 8u) table_row = reinterpret_cast<const uint4 *>(DIR_TABLE)[tid];
+    Board bd[BOARDS_PER_LANE];
+    uint32_t act[BOARDS_PER_LANE];
+#pragma unroll
+    for (int j = 0; j < BOARDS_PER_LANE; ++j) {
+        const uint64_t i = tile0 + 64u * j + lane;
+        bd[j] = Board{0u, 0u, 0u, 0u};
+        act[j] = 0u;
+        if (FULL || i < a.n) {
+            bd[j] = load_board(a.boards, i);
+            if (!RANDOM) act[j] = a.actions[i];
+        }
+    }
+
+    // 2. step words
+    uint32_t *strip = word_lds[wave];
+    const uint32_t strip_off = (uint32_t)env0 & 3u;
+    uint32_t word[BOARDS_PER_LANE];
+#if defined(ENV2048_EXP_ABLATE) && (ENV2048_EXP_ABLATE & 2)  // timing-only build: no Philox
+#pragma unroll
+    for (int j = 0; j < BOARDS_PER_LANE; ++j) word[j] = (lane * 2654435761u) ^ (a.key.step_lo * 40503u + j);
+#else
+    fill_word_strip(strip, a.key, env0, lane);
+#pragma unroll
+    for (int j = 0; j < BOARDS_PER_LANE; ++j) word[j] = strip[strip_off + 64u * j + lane];
+#endif
+
+    // 3. selector table (its load was issued first, so it has long arrived) + bookkeeping words
+    if (tid < 8u) dir_lds[tid] = table_row;
+    if (tid == 0u) {
+        *reset_count = 0u;
+        *waves_finished = 0u;
+    }
+    lds_barrier();
+
+    // 4. all loads home, then compute/store without touching vmcnt again
+    ENV2048_WAIT_ALL_VMEM();
+#ifdef ENV2048_EXP_STAMPS
+    stamp1 = __builtin_amdgcn_s_memtime();
+#endif
+    // fetch the selector records of all boards now: one LDS round trip instead of one per board
+    DirSelectors sel[BOARDS_PER_LANE];
+#pragma unroll
+    for (int j = 0; j < BOARDS_PER_LANE; ++j) sel[j] = load_selectors(dir_lds, (RANDOM ? word[j] : act[j]) & 3u);
+#pragma unroll
+    for (int j = 0; j < BOARDS_PER_LANE; ++j) {
+        const uint64_t i = tile0 + 64u * j + lane;
+        if (!FULL && i >= a.n) continue;
+        uint32_t reward;
+        bool changed, done;
+#if defined(ENV2048_EXP_ABLATE) && (ENV2048_EXP_ABLATE & 1)  // timing-only build: no game logic
+        reward = sel[j].fA + word[j];
+        changed = false;
+        done = (bd[j].r0 & 0x10000000u) != 0u;
+        bd[j].r1 ^= sel[j].iD;
+#else
+        transition(bd[j], sel[j], word[j], reward, changed, done);
+#endif
+        if (auto_reset && done) {
+            const uint32_t slot = atomicAdd(reset_count, 1u);
+            reset_slot[slot] = (uint16_t)(wave * TILE_BOARDS + 64u * j + lane);
+        } else {
+            store_board(a.boards, i, bd[j]);
+            if (EXTRAS) {
+                if (a.legal) a.legal[i] = (uint8_t)legal_mask(bd[j]);
+                if (a.obs) store_obs(a.obs, i, bd[j]);
+            }
+        }
+        if (a.reward) a.reward[i] = (int32_t)reward;
+        a.done[i] = done ? 1 : 0;
+    }
+
+#ifdef ENV2048_EXP_STAMPS
+    stamp2 = __builtin_amdgcn_s_memtime();
+    if (lane == 0u && a.obs) {
+        uint64_t *out = reinterpret_cast<uint64_t *>(a.obs) + 4 * ((uint64_t)blockIdx.x * WAVES_PER_BLOCK + wave);
+        out[0] = stamp0;
+        out[1] = stamp1;
+        out[2] = stamp2;
+        out[3] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
+    // 5. No second barrier: waves retire as they finish; the LAST wave of the block to get here sees
+    // every queue entry (LDS is coherent within the CU; each wave's queue writes are complete before
+    // its arrival count) and rebuilds the terminal boards.
+    if (!auto_reset) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    uint32_t arrived = 0u;
+    if (lane == 0u) arrived = atomicAdd(waves_finished, 1u);
+    arrived = __builtin_amdgcn_readfirstlane(arrived);
+    if (arrived != WAVES_PER_BLOCK - 1u) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    const uint32_t n_reset = atomicAdd(reset_count, 0u);  // LDS read-through (a volatile load would go flat + vmcnt(0))
+    reset_queued<EXTRAS>(a, block0, reset_slot, n_reset, lane, 64u);
+}
+
+template <bool EXTRAS, bool RANDOM>
 __global__ __launch_bounds__(BLOCK) void step_kernel(StepArgs a)
 {
     __shared__ uint4 dir_lds[8];
@@ -191,41 +297,11 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(StepArgs a)
     __shared__ uint32_t reset_count;
     __shared__ uint32_t waves_finished;
     __shared__ uint16_t reset_slot[BLOCK_BOARDS];
-
-    const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (tid < 8u) dir_lds[tid] = reinterpret_cast<const uint4 *>(DIR_TABLE)[tid];
-    if (tid == 0u) {
-        reset_count = 0u;
-        waves_finished = 0u;
-    }
-    __syncthreads();
-
-    const uint64_t block0 = (uint64_t)blockIdx.x * BLOCK_BOARDS;  // first board of this block (local index)
-    const uint64_t tile0 = block0 + (uint64_t)wave * TILE_BOARDS;
+    const uint64_t block0 = (uint64_t)blockIdx.x * BLOCK_BOARDS;
     if (block0 + BLOCK_BOARDS <= a.n)  // block-uniform: every block but the last takes the unchecked path
-        step_tile<EXTRAS, true>(a, dir_lds, word_lds[wave], &reset_count, reset_slot, tile0, wave, lane);
+        step_block<EXTRAS, true, RANDOM>(a, dir_lds, word_lds, &reset_count, &waves_finished, reset_slot);
     else
-        step_tile<EXTRAS, false>(a, dir_lds, word_lds[wave], &reset_count, reset_slot, tile0, wave, lane);
-
-    if (!(a.flags & ENV2048_FLAG_AUTO_RESET)) return;
-#if ENV2048_EXP_RESET_MODE == 0
-    __syncthreads();
-    reset_queued<EXTRAS>(a, block0, reset_slot, reset_count, tid, BLOCK);
-#else
-    // No barrier: waves retire as they finish; the LAST wave of the block to get here sees every
-    // queue entry (LDS is coherent within the CU and each wave's queue writes are complete --
-    // lgkmcnt(0) via the fence -- before its arrival count) and rebuilds the terminal boards.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    uint32_t arrived = 0u;
-    if (lane == 0u) arrived = atomicAdd(&waves_finished, 1u);
-    arrived = __builtin_amdgcn_readfirstlane(arrived);
-    if (arrived != WAVES_PER_BLOCK - 1u) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    const uint32_t n_reset = *(volatile uint32_t *)&reset_count;
-    reset_queued<EXTRAS>(a, block0, reset_slot, n_reset, lane, 64u);
-#endif
+        step_block<EXTRAS, false, RANDOM>(a, dir_lds, word_lds, &reset_count, &waves_finished, reset_slot);
 }
 
 struct ResetArgs {
@@ -596,10 +672,22 @@ int env2048_step(int device, void *stream, uint64_t n, uint64_t env_base, uint8_
     StepArgs a{n, env_base, boards, actions, reward, done, legal, obs,
                RngKey{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)step_index, (uint32_t)(step_index >> 32)},
                flags};
-    if (legal || obs)
-        hipLaunchKernelGGL(step_kernel<true>, tile_grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, a);
+    static const unsigned exp_dyn_lds = getenv("ENV2048_EXP_DYN_LDS") ? (unsigned)atoi(getenv("ENV2048_EXP_DYN_LDS")) : 0u;
+#ifdef ENV2048_EXP_STAMPS
+    const bool extras = false;
+#else
+    const bool extras = legal || obs;
+#endif
+    const bool random_actions = (flags & ENV2048_FLAG_RANDOM_ACTIONS) != 0u;
+    const dim3 grid = tile_grid_for(n), block(BLOCK);
+    if (extras && random_actions)
+        hipLaunchKernelGGL((step_kernel<true, true>), grid, block, exp_dyn_lds, (hipStream_t)stream, a);
+    else if (extras)
+        hipLaunchKernelGGL((step_kernel<true, false>), grid, block, exp_dyn_lds, (hipStream_t)stream, a);
+    else if (random_actions)
+        hipLaunchKernelGGL((step_kernel<false, true>), grid, block, exp_dyn_lds, (hipStream_t)stream, a);
     else
-        hipLaunchKernelGGL(step_kernel<false>, tile_grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((step_kernel<false, false>), grid, block, exp_dyn_lds, (hipStream_t)stream, a);
     return launched("env2048_step launch");
 }
 

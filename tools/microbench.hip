@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <functional>
 #include <random>
+#include <chrono>
 #include <dlfcn.h>
 
 #include "env2048.h"
@@ -250,6 +251,8 @@ int main(int argc, char **argv)
     std::vector<uint4> saved(n);
     CHECK(hipMemcpy(saved.data(), boards, n * 16, hipMemcpyDeviceToHost));
 
+    typedef int (*step_fn_t)(int, void *, uint64_t, uint64_t, uint8_t *, const uint8_t *, int32_t *, uint8_t *, uint8_t *, float *,
+                             uint64_t, uint64_t, uint32_t);
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
@@ -321,8 +324,7 @@ int main(int argc, char **argv)
     run("tile4_shared", [&](int t) { hipLaunchKernelGGL((k_four<1, true>), dim3(g4), dim3(256), 0, s, mk4(t)); });
     run("tile4_shared_lds", [&](int t) { hipLaunchKernelGGL((k_four<3, true>), dim3(g4), dim3(256), 0, s, mk4(t)); });
 
-    typedef int (*step_fn_t)(int, void *, uint64_t, uint64_t, uint8_t *, const uint8_t *, int32_t *, uint8_t *, uint8_t *, float *,
-                             uint64_t, uint64_t, uint32_t);
+    typedef int (*step_fn_t_fwd)(int);
     for (int ai = 3; ai < argc; ++ai) {  // extra experiment builds of the library: time their env2048_step
         void *h = dlopen(argv[ai], RTLD_NOW | RTLD_LOCAL);
         if (!h) {
@@ -331,8 +333,14 @@ int main(int argc, char **argv)
         }
         step_fn_t fn = (step_fn_t)dlsym(h, "env2048_step");
         std::string name = std::string("EXP ") + argv[ai];
-        run(name.c_str(), [&](int t) {
-            fn(0, s, n, 0, (uint8_t *)boards, actions + (uint64_t)(t & 7) * n, reward, done, nullptr, nullptr, 0x2048, t, 1);
+        typedef const char *(*err_fn_t)(void);
+        err_fn_t err = (err_fn_t)dlsym(h, "env2048_last_error");
+        run(name.c_str(), [=](int t) {
+            int rc = fn(0, s, n, 0, (uint8_t *)boards, actions + (uint64_t)(t & 7) * n, reward, done, nullptr, nullptr, 0x2048, t, 1);
+            if (rc) {
+                fprintf(stderr, "env2048_step failed: %d %s\n", rc, err());
+                exit(2);
+            }
         });
     }
     run("LIB env2048_step", [&](int t) {
@@ -347,6 +355,64 @@ int main(int argc, char **argv)
     run("LIB rollout T=16 (/16)", [&](int t) {
         env2048_rollout(0, s, n, 0, (uint8_t *)boards, 0x2048, 16 * t, 16, nullptr, nullptr, nullptr, 3);
     });
+
+    if (getenv("MB_STAMPS")) {  // wave timeline from the diagnostic build (tools/libexp_stamps.so)
+        void *h = dlopen(getenv("MB_STAMPS"), RTLD_NOW | RTLD_LOCAL);
+        if (!h) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 1; }
+        step_fn_t fn = (step_fn_t)dlsym(h, "env2048_step");
+        const uint64_t n_waves = n / 256;
+        uint64_t *stamps;
+        CHECK(hipMalloc(&stamps, n_waves * 32));
+        for (int t = 0; t < 200; ++t)
+            fn(0, s, n, 0, (uint8_t *)boards, actions + (uint64_t)(t & 7) * n, reward, done, nullptr, (float *)stamps, 0x2048, t, 1);
+        CHECK(hipStreamSynchronize(s));
+        std::vector<uint64_t> hst(n_waves * 4);
+        CHECK(hipMemcpy(hst.data(), stamps, n_waves * 32, hipMemcpyDeviceToHost));
+        uint64_t t0 = ~0ull, r0 = ~0ull, r1 = 0;
+        for (uint64_t w = 0; w < n_waves; ++w) { t0 = std::min(t0, hst[4 * w]); r0 = std::min(r0, hst[4 * w + 3]); r1 = std::max(r1, hst[4 * w + 3]); }
+        std::vector<double> start, loaded, end, wait, comp;
+        for (uint64_t w = 0; w < n_waves; ++w) {
+            start.push_back((double)(hst[4 * w] - t0));
+            loaded.push_back((double)(hst[4 * w + 1] - t0));
+            end.push_back((double)(hst[4 * w + 2] - t0));
+            wait.push_back((double)(hst[4 * w + 1] - hst[4 * w]));
+            comp.push_back((double)(hst[4 * w + 2] - hst[4 * w + 1]));
+        }
+        auto pct = [](std::vector<double> v, double p) { std::sort(v.begin(), v.end()); return v[(size_t)(p * (v.size() - 1))]; };
+        printf("stamps in shader cycles (s_memtime); realtime span of end stamps: %.2f us (100 MHz ticks)\n", (r1 - r0) / 100.0);
+        for (auto pr : {std::make_pair("wave start", &start), std::make_pair("loads home", &loaded), std::make_pair("wave end", &end),
+                        std::make_pair("start->loads", &wait), std::make_pair("loads->end", &comp)})
+            printf("  %-14s p0 %8.0f  p10 %8.0f  p50 %8.0f  p90 %8.0f  p100 %8.0f\n", pr.first, pct(*pr.second, 0), pct(*pr.second, .1),
+                   pct(*pr.second, .5), pct(*pr.second, .9), pct(*pr.second, 1));
+        return 0;
+    }
+
+    // Multi-stream: the batch cut into S contiguous slices, slice k always on stream k (no cross-stream
+    // dependency between consecutive steps); timed with the host clock around a full sync.
+    for (int S : {1, 2, 4, 8}) {
+        std::vector<hipStream_t> ss(S);
+        for (auto &x : ss) CHECK(hipStreamCreate(&x));
+        const uint64_t per = n / S;
+        CHECK(hipMemcpy(boards, saved.data(), n * 16, hipMemcpyHostToDevice));
+        auto go = [&](int t) {
+            for (int k = 0; k < S; ++k)
+                env2048_step(0, ss[k], per, k * per, (uint8_t *)boards + 16 * k * per, actions + (uint64_t)(t & 7) * n + k * per,
+                             reward + k * per, done + k * per, nullptr, nullptr, 0x2048, t, 1);
+        };
+        double best = 1e30;
+        for (int r = 0; r < 5; ++r) {
+            for (int t = 0; t < 50; ++t) go(t);
+            CHECK(hipDeviceSynchronize());
+            auto t0 = std::chrono::steady_clock::now();
+            for (int t = 0; t < launches; ++t) go(100 + t);
+            CHECK(hipDeviceSynchronize());
+            double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / launches;
+            best = std::min(best, us);
+        }
+        printf("STREAMS %d x %llu boards: %8.2f us/step  %7.2f Gsteps/s  %7.1f GB/s(38B)\n", S, (unsigned long long)per, best,
+               n / best * 1e-3, 38.0 * n / best * 1e-3);
+        for (auto &x : ss) CHECK(hipStreamDestroy(x));
+    }
 
     const char *only = getenv("MB_ONLY");  // comma-free substring filter, e.g. MB_ONLY=EXP
     if (only) {
