@@ -9,7 +9,6 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
-#include <stdlib.h>
 
 #include "env2048.h"
 #include "board_ops.hpp"
@@ -44,6 +43,31 @@ __device__ __forceinline__ void store_obs(float *obs, uint64_t i, const Board &b
         uint32_t x = rows[r];
         o[r] = make_float4((float)(x & 0xFFu) * 0.0625f, (float)((x >> 8) & 0xFFu) * 0.0625f,
                            (float)((x >> 16) & 0xFFu) * 0.0625f, (float)(x >> 24) * 0.0625f);
+    }
+}
+
+// Coalesced f32 observation of 64 consecutive boards held one per lane: every lane drops its 16
+// packed bytes into a wave-private 1 KiB LDS strip, reads back ONE dword (row l&3 of board l>>2 of
+// each quarter) and converts it, so that each of the four store instructions writes 1 KiB of
+// contiguous floats instead of 64 float4 that are 64 B apart.  `skip` lanes publish a sentinel (no
+// real row is 0xFFFFFFFF) and nothing is stored for their boards (they are rebuilt later by the
+// reset pass, possibly by another wave).  first = index of lane 0's board; boards >= n are skipped.
+__device__ __forceinline__ void store_obs_coalesced(float *obs, uint32_t *strip, uint64_t first, uint64_t n, uint32_t lane,
+                                                    const Board &bd, bool skip)
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // earlier reads of the strip are done
+    __builtin_amdgcn_wave_barrier();
+    reinterpret_cast<uint4 *>(strip)[lane] = skip ? make_uint4(~0u, ~0u, ~0u, ~0u) : make_uint4(bd.r0, bd.r1, bd.r2, bd.r3);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float4 *out = reinterpret_cast<float4 *>(obs) + 4 * first;
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; ++k) {
+        const uint32_t x = strip[64u * k + lane];
+        const uint64_t board = first + 16u * k + (lane >> 2);
+        if (x != ~0u && board < n)
+            out[64u * k + lane] = make_float4((float)(x & 0xFFu) * 0.0625f, (float)((x >> 8) & 0xFFu) * 0.0625f,
+                                              (float)((x >> 16) & 0xFFu) * 0.0625f, (float)(x >> 24) * 0.0625f);
     }
 }
 
@@ -173,21 +197,6 @@ __device__ __forceinline__ void step_block(const StepArgs &a, uint4 *dir_lds, ui
     const uint64_t env0 = a.env_base + tile0;
     const bool auto_reset = (a.flags & ENV2048_FLAG_AUTO_RESET) != 0u;
 
-#if defined(ENV2048_EXP_PRIO) && ENV2048_EXP_PRIO == 1  // grid quartiles: earlier blocks first
-    { const uint32_t p = 3u - min(3u, blockIdx.x * 4u / gridDim.x); if (p == 3u) __builtin_amdgcn_s_setprio(3); else if (p == 2u) __builtin_amdgcn_s_setprio(2); else if (p == 1u) __builtin_amdgcn_s_setprio(1); }
-#elif defined(ENV2048_EXP_PRIO) && ENV2048_EXP_PRIO == 2  // co-resident blocks of a CU differ in bits 8..9
-    { const uint32_t p = 3u - ((blockIdx.x >> 8) & 3u); if (p == 3u) __builtin_amdgcn_s_setprio(3); else if (p == 2u) __builtin_amdgcn_s_setprio(2); else if (p == 1u) __builtin_amdgcn_s_setprio(1); }
-#elif defined(ENV2048_EXP_PRIO) && ENV2048_EXP_PRIO == 3  // bits 5..6
-    { const uint32_t p = 3u - ((blockIdx.x >> 5) & 3u); if (p == 3u) __builtin_amdgcn_s_setprio(3); else if (p == 2u) __builtin_amdgcn_s_setprio(2); else if (p == 1u) __builtin_amdgcn_s_setprio(1); }
-#elif defined(ENV2048_EXP_PRIO) && ENV2048_EXP_PRIO == 4  // low bits
-    { const uint32_t p = 3u - (blockIdx.x & 3u); if (p == 3u) __builtin_amdgcn_s_setprio(3); else if (p == 2u) __builtin_amdgcn_s_setprio(2); else if (p == 1u) __builtin_amdgcn_s_setprio(1); }
-#endif
-#if defined(ENV2048_EXP_STAGGER) && ENV2048_EXP_STAGGER > 0  // odd blocks start late (units of 64 cycles)
-    if (blockIdx.x & 1u) {
-        for (int k = 0; k < ENV2048_EXP_STAGGER / 100; ++k) __builtin_amdgcn_s_sleep(100);
-        __builtin_amdgcn_s_sleep(ENV2048_EXP_STAGGER % 100);
-    }
-#endif
 #ifdef ENV2048_EXP_STAMPS  // diagnostic build: wave timeline stamps into the (otherwise unused) obs buffer
     uint64_t stamp0 = __builtin_amdgcn_s_memtime(), stamp1 = 0, stamp2 = 0;
 #endif
@@ -251,16 +260,17 @@ __device__ __forceinline__ void step_block(const StepArgs &a, uint4 *dir_lds, ui
 #else
         transition(bd[j], sel[j], word[j], reward, changed, done);
 #endif
-        if (auto_reset && done) {
+        const bool pending_reset = auto_reset && done;
+        if (pending_reset) {
             const uint32_t slot = atomicAdd(reset_count, 1u);
             reset_slot[slot] = (uint16_t)(wave * TILE_BOARDS + 64u * j + lane);
         } else {
             store_board(a.boards, i, bd[j]);
-            if (EXTRAS) {
-                if (a.legal) a.legal[i] = (uint8_t)legal_mask(bd[j]);
-                if (a.obs) store_obs(a.obs, i, bd[j]);
-            }
+            if (EXTRAS && a.legal) a.legal[i] = (uint8_t)legal_mask(bd[j]);
         }
+        if (EXTRAS && FULL && a.obs)  // (the step words were copied to registers: the strip is free)
+            store_obs_coalesced(a.obs, strip, tile0 + 64u * j, a.n, lane, bd[j], pending_reset);
+        if (EXTRAS && !FULL && a.obs && !pending_reset) store_obs(a.obs, i, bd[j]);
         if (a.reward) a.reward[i] = (int32_t)reward;
         a.done[i] = done ? 1 : 0;
     }
@@ -479,17 +489,21 @@ __global__ __launch_bounds__(BLOCK) void onehot_kernel(uint64_t n_cells, const u
     for (uint32_t k = 0; k < width; ++k) o[k] = (k == e) ? 1 : 0;
 }
 
-__global__ __launch_bounds__(BLOCK) void status_kernel(uint64_t n, const uint8_t *boards, uint8_t *done,
-                                                       uint8_t *legal, float *obs, uint8_t *max_exp,
-                                                       uint8_t *n_empty)
+__global__ __launch_bounds__(256) void status_kernel(uint64_t n, const uint8_t *boards, uint8_t *done,
+                                                     uint8_t *legal, float *obs, uint8_t *max_exp,
+                                                     uint8_t *n_empty)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const Board bd = load_board(boards, i);
+    __shared__ __attribute__((aligned(16))) uint32_t strip_lds[4][256];
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool valid = i < n;
+    const Board bd = valid ? load_board(boards, i) : Board{0u, 0u, 0u, 0u};
+    if (obs) store_obs_coalesced(obs, strip_lds[wave], i - lane, n, lane, bd, !valid);  // whole wave takes part
+    if (!valid) return;
     const uint32_t empties = count_empty(bd);
     if (done) done[i] = (empties == 0u && no_equal_neighbours(bd)) ? 1 : 0;
     if (legal) legal[i] = (uint8_t)legal_mask(bd);
-    if (obs) store_obs(obs, i, bd);
     if (n_empty) n_empty[i] = (uint8_t)empties;
     if (max_exp) {
         const uint32_t rows[4] = {bd.r0, bd.r1, bd.r2, bd.r3};
@@ -672,7 +686,6 @@ int env2048_step(int device, void *stream, uint64_t n, uint64_t env_base, uint8_
     StepArgs a{n, env_base, boards, actions, reward, done, legal, obs,
                RngKey{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)step_index, (uint32_t)(step_index >> 32)},
                flags};
-    static const unsigned exp_dyn_lds = getenv("ENV2048_EXP_DYN_LDS") ? (unsigned)atoi(getenv("ENV2048_EXP_DYN_LDS")) : 0u;
 #ifdef ENV2048_EXP_STAMPS
     const bool extras = false;
 #else
@@ -681,13 +694,13 @@ int env2048_step(int device, void *stream, uint64_t n, uint64_t env_base, uint8_
     const bool random_actions = (flags & ENV2048_FLAG_RANDOM_ACTIONS) != 0u;
     const dim3 grid = tile_grid_for(n), block(BLOCK);
     if (extras && random_actions)
-        hipLaunchKernelGGL((step_kernel<true, true>), grid, block, exp_dyn_lds, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((step_kernel<true, true>), grid, block, 0, (hipStream_t)stream, a);
     else if (extras)
-        hipLaunchKernelGGL((step_kernel<true, false>), grid, block, exp_dyn_lds, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((step_kernel<true, false>), grid, block, 0, (hipStream_t)stream, a);
     else if (random_actions)
-        hipLaunchKernelGGL((step_kernel<false, true>), grid, block, exp_dyn_lds, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((step_kernel<false, true>), grid, block, 0, (hipStream_t)stream, a);
     else
-        hipLaunchKernelGGL((step_kernel<false, false>), grid, block, exp_dyn_lds, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((step_kernel<false, false>), grid, block, 0, (hipStream_t)stream, a);
     return launched("env2048_step launch");
 }
 
@@ -783,7 +796,7 @@ int env2048_status(int device, void *stream, uint64_t n, const uint8_t *boards, 
     if (int rc = check_count(n)) return rc;
     DeviceScope scope(device);
     if (scope.rc) return scope.rc;
-    hipLaunchKernelGGL(status_kernel, grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, n, boards, done, legal, obs,
+    hipLaunchKernelGGL(status_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, boards, done, legal, obs,
                        max_exp, n_empty);
     return launched("env2048_status launch");
 }

@@ -352,6 +352,23 @@ int main(int argc, char **argv)
     run("LIB step random", [&](int t) {
         env2048_step(0, s, n, 0, (uint8_t *)boards, nullptr, reward, done, nullptr, nullptr, 0x2048, t, 3);
     });
+    {
+        static uint8_t *legal_buf = nullptr;
+        static float *obs_buf = nullptr;
+        CHECK(hipMalloc(&legal_buf, n));
+        CHECK(hipMalloc(&obs_buf, n * 64));
+        uint8_t *lb = legal_buf;
+        float *ob = obs_buf;
+        run("LIB step +legal", [=](int t) {
+            env2048_step(0, s, n, 0, (uint8_t *)boards, actions + (uint64_t)(t & 7) * n, reward, done, lb, nullptr, 0x2048, t, 1);
+        });
+        run("LIB step +legal+obs", [=](int t) {
+            env2048_step(0, s, n, 0, (uint8_t *)boards, actions + (uint64_t)(t & 7) * n, reward, done, lb, ob, 0x2048, t, 1);
+        });
+        run("LIB status legal+obs", [=](int t) {
+            env2048_status(0, s, n, (uint8_t *)boards, nullptr, lb, ob, nullptr, nullptr);
+        });
+    }
     run("LIB rollout T=16 (/16)", [&](int t) {
         env2048_rollout(0, s, n, 0, (uint8_t *)boards, 0x2048, 16 * t, 16, nullptr, nullptr, nullptr, 3);
     });
