@@ -48,6 +48,8 @@ def parse_args():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='target duration of the CPU baseline sample')
     ap.add_argument('--extras', action='store_true', help='also emit legal mask + f32 obs (not the headline)')
+    ap.add_argument('--dist-backend', default='nccl', help="'nccl' (= RCCL, one GPU per rank); 'gloo' only to rehearse the "
+                    'multi-rank logic on a single-GPU box (all ranks then share device 0)')
     return ap.parse_args()
 
 
@@ -128,13 +130,20 @@ def main():
         sys.exit(f'WORLD_SIZE={world} does not match --gpus {args.gpus}')
     if not torch.cuda.is_available():
         sys.exit('bench.py needs a HIP device: the product path has no CPU fallback')
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    rehearsal = world > 1 and args.dist_backend != 'nccl'
+    device_index = 0 if rehearsal else local_rank
+    if device_index >= torch.cuda.device_count():
+        sys.exit(f'rank {rank}: local rank {local_rank} has no GPU (visible devices: {torch.cuda.device_count()})')
+    torch.cuda.set_device(device_index)
+    device = torch.device('cuda', device_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group('nccl', device_id=device)
+        if args.dist_backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(args.dist_backend)
 
     n = args.boards
     K, W = args.steps, args.warmup
@@ -163,7 +172,7 @@ def main():
     env_base = rank * n
 
     def launch(step_index: int, stream_handle):
-        rc = step_fn(local_rank, stream_handle, n, env_base, fixed['boards'], action_ptrs[step_index & 7], fixed['reward'],
+        rc = step_fn(device_index, stream_handle, n, env_base, fixed['boards'], action_ptrs[step_index & 7], fixed['reward'],
                      fixed['done'], fixed['legal'], fixed['obs'], SEED, step_index, capi.FLAG_AUTO_RESET)
         if rc != 0:
             raise capi.Env2048Error(rc, lib.last_error())
@@ -208,7 +217,7 @@ def main():
     event_ms = ev0.elapsed_time(ev1)
 
     if dist is not None:
-        tt = torch.tensor([wall, event_ms], dtype=torch.float64, device=device)
+        tt = torch.tensor([wall, event_ms], dtype=torch.float64, device=device if args.dist_backend == 'nccl' else 'cpu')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall, event_ms = float(tt[0]), float(tt[1])
 

@@ -200,13 +200,13 @@ __device__ __forceinline__ void step_block(const StepArgs &a, uint4 *dir_lds, ui
 #ifdef ENV2048_EXP_STAMPS  // diagnostic build: wave timeline stamps into the (otherwise unused) obs buffer
     uint64_t stamp0 = __builtin_amdgcn_s_memtime(), stamp1 = 0, stamp2 = 0;
 #endif
-    // 1. loads
+    // 1. loads of the FIRST half of the tile (boards 0,1) -- and the selector table
     uint4 table_row = make_uint4(0u, 0u, 0u, 0u);
     if (tid < 8u) table_row = reinterpret_cast<const uint4 *>(DIR_TABLE)[tid];
     Board bd[BOARDS_PER_LANE];
     uint32_t act[BOARDS_PER_LANE];
-#pragma unroll
-    for (int j = 0; j < BOARDS_PER_LANE; ++j) {
+    constexpr int HALF = BOARDS_PER_LANE / 2 > 0 ? BOARDS_PER_LANE / 2 : 1;
+    auto issue_loads = [&](int j) {
         const uint64_t i = tile0 + 64u * j + lane;
         bd[j] = Board{0u, 0u, 0u, 0u};
         act[j] = 0u;
@@ -214,9 +214,11 @@ __device__ __forceinline__ void step_block(const StepArgs &a, uint4 *dir_lds, ui
             bd[j] = load_board(a.boards, i);
             if (!RANDOM) act[j] = a.actions[i];
         }
-    }
+    };
+#pragma unroll
+    for (int j = 0; j < HALF; ++j) issue_loads(j);
 
-    // 2. step words
+    // 2. step words (pure ALU + LDS) ...
     uint32_t *strip = word_lds[wave];
     const uint32_t strip_off = (uint32_t)env0 & 3u;
     uint32_t word[BOARDS_PER_LANE];
@@ -229,6 +231,12 @@ __device__ __forceinline__ void step_block(const StepArgs &a, uint4 *dir_lds, ui
     for (int j = 0; j < BOARDS_PER_LANE; ++j) word[j] = strip[strip_off + 64u * j + lane];
 #endif
 
+    // ... and only now the loads of the SECOND half: by now every wave of the chip has queued its
+    // first half, so the memory system delivers the tile board-major and the first half is home
+    // after half of the load burst instead of all of it.
+#pragma unroll
+    for (int j = HALF; j < BOARDS_PER_LANE; ++j) issue_loads(j);
+
     // 3. selector table (its load was issued first, so it has long arrived) + bookkeeping words
     if (tid < 8u) dir_lds[tid] = table_row;
     if (tid == 0u) {
@@ -237,44 +245,71 @@ __device__ __forceinline__ void step_block(const StepArgs &a, uint4 *dir_lds, ui
     }
     lds_barrier();
 
-    // 4. all loads home, then compute/store without touching vmcnt again
-    ENV2048_WAIT_ALL_VMEM();
+    // 4. first half home (exact count: vmcnt counts in issue order and no store has been issued
+    //    yet; in the bounds-checked path loads may be skipped, so wait for everything there)
+    if (FULL && BOARDS_PER_LANE >= 2)
+        __builtin_amdgcn_s_waitcnt(0x0F70 | ((RANDOM ? 1 : 2) * (BOARDS_PER_LANE - HALF)));  // vmcnt(#second-half loads)
+    else
+        ENV2048_WAIT_ALL_VMEM();
 #ifdef ENV2048_EXP_STAMPS
     stamp1 = __builtin_amdgcn_s_memtime();
 #endif
     // fetch the selector records of all boards now: one LDS round trip instead of one per board
     DirSelectors sel[BOARDS_PER_LANE];
 #pragma unroll
-    for (int j = 0; j < BOARDS_PER_LANE; ++j) sel[j] = load_selectors(dir_lds, (RANDOM ? word[j] : act[j]) & 3u);
-#pragma unroll
-    for (int j = 0; j < BOARDS_PER_LANE; ++j) {
-        const uint64_t i = tile0 + 64u * j + lane;
-        if (!FULL && i >= a.n) continue;
-        uint32_t reward;
-        bool changed, done;
+    for (int j = 0; j < HALF; ++j) sel[j] = load_selectors(dir_lds, (RANDOM ? word[j] : act[j]) & 3u);
+
+    uint32_t reward[BOARDS_PER_LANE];
+    bool done[BOARDS_PER_LANE];
+    auto compute = [&](int j) {
+        bool changed;
 #if defined(ENV2048_EXP_ABLATE) && (ENV2048_EXP_ABLATE & 1)  // timing-only build: no game logic
-        reward = sel[j].fA + word[j];
+        reward[j] = sel[j].fA + word[j];
         changed = false;
-        done = (bd[j].r0 & 0x10000000u) != 0u;
+        done[j] = (bd[j].r0 & 0x10000000u) != 0u;
         bd[j].r1 ^= sel[j].iD;
 #else
-        transition(bd[j], sel[j], word[j], reward, changed, done);
+        transition(bd[j], sel[j], word[j], reward[j], changed, done[j]);
 #endif
-        const bool pending_reset = auto_reset && done;
-        if (pending_reset) {
-            const uint32_t slot = atomicAdd(reset_count, 1u);
-            reset_slot[slot] = (uint16_t)(wave * TILE_BOARDS + 64u * j + lane);
-        } else {
-            store_board(a.boards, i, bd[j]);
-            if (EXTRAS && a.legal) a.legal[i] = (uint8_t)legal_mask(bd[j]);
+    };
+    auto emit = [&](int j) {
+        const uint64_t i = tile0 + 64u * j + lane;
+        if (FULL || i < a.n) {
+            const bool pending_reset = auto_reset && done[j];
+            if (pending_reset) {
+                const uint32_t slot = atomicAdd(reset_count, 1u);
+                reset_slot[slot] = (uint16_t)(wave * TILE_BOARDS + 64u * j + lane);
+            } else {
+                store_board(a.boards, i, bd[j]);
+                if (EXTRAS && a.legal) a.legal[i] = (uint8_t)legal_mask(bd[j]);
+                if (EXTRAS && !FULL && a.obs) store_obs(a.obs, i, bd[j]);
+            }
+#if defined(ENV2048_EXP_ABLATE) && (ENV2048_EXP_ABLATE & 4)  // timing-only build: no reward/done stores
+            asm volatile("" ::"v"(reward[j]), "v"((uint32_t)done[j]));
+#else
+            // write-once outputs: streaming (nt) stores keep them from displacing the boards in cache
+            if (a.reward) __builtin_nontemporal_store((int32_t)reward[j], &a.reward[i]);
+            __builtin_nontemporal_store((uint8_t)(done[j] ? 1 : 0), &a.done[i]);
+#endif
         }
         if (EXTRAS && FULL && a.obs)  // (the step words were copied to registers: the strip is free)
-            store_obs_coalesced(a.obs, strip, tile0 + 64u * j, a.n, lane, bd[j], pending_reset);
-        if (EXTRAS && !FULL && a.obs && !pending_reset) store_obs(a.obs, i, bd[j]);
-        if (a.reward) a.reward[i] = (int32_t)reward;
-        a.done[i] = done ? 1 : 0;
-    }
+            store_obs_coalesced(a.obs, strip, tile0 + 64u * j, a.n, lane, bd[j], auto_reset && done[j]);
+    };
 
+    // first half: compute only -- its stores wait until the second half's loads are home, so that
+    // no vmcnt wait ever has a store (whose ack takes a memory round trip) in front of it
+#pragma unroll
+    for (int j = 0; j < HALF; ++j) compute(j);
+    ENV2048_WAIT_ALL_VMEM();
+#pragma unroll
+    for (int j = HALF; j < BOARDS_PER_LANE; ++j) sel[j] = load_selectors(dir_lds, (RANDOM ? word[j] : act[j]) & 3u);
+#pragma unroll
+    for (int j = 0; j < HALF; ++j) emit(j);
+#pragma unroll
+    for (int j = HALF; j < BOARDS_PER_LANE; ++j) {
+        compute(j);
+        emit(j);
+    }
 #ifdef ENV2048_EXP_STAMPS
     stamp2 = __builtin_amdgcn_s_memtime();
     if (lane == 0u && a.obs) {
@@ -285,6 +320,7 @@ __device__ __forceinline__ void step_block(const StepArgs &a, uint4 *dir_lds, ui
         out[3] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
+
     // 5. No second barrier: waves retire as they finish; the LAST wave of the block to get here sees
     // every queue entry (LDS is coherent within the CU; each wave's queue writes are complete before
     // its arrival count) and rebuilds the terminal boards.
