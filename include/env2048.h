@@ -151,6 +151,19 @@ ENV2048_EXPORT int env2048_spawn_random(int device, void *stream, uint64_t n, ui
                                         uint64_t seed, uint64_t step_index, uint32_t count);
 
 /*
+ * All chance outcomes of an afterstate: for every board the 32 slots s = 2*k + v (k = rank of an
+ * empty cell in row-major order, v = 0 for tile 2, 1 for tile 4) hold the board with that tile
+ * placed and its probability P(tile) / n_empty (0.9 / 0.1); slots with k >= n_empty hold a zero
+ * board and probability 0.  A full board yields slot 0 = the board itself with probability 1,
+ * like the reference.  out_boards: n x 32 x 16 bytes, out_prob: n x 32 floats, out_count (may be
+ * NULL): number of valid slots per board (2 * n_empty, or 1 for a full board).
+ * [replaces: twentyfortyeight/core/gameboard.py:132-171 after_state (same enumeration order),
+ *            :174-244 after_state_lazy + generate_outcome]
+ */
+ENV2048_EXPORT int env2048_chance_outcomes(int device, void *stream, uint64_t n, const uint8_t *boards, uint8_t *out_boards,
+                                           float *out_prob, uint8_t *out_count);
+
+/*
  * Read-only board status; every output may be NULL.
  *     done / legal / obs as in env2048_step;  max_exp[i] = log2(max tile);  n_empty[i] = #zeros
  * [replaces: twentyfortyeight/core/gameboard.py:328-348 is_done;

@@ -439,6 +439,33 @@ ORACLE_API int oracle_spawn_random_batch(uint64_t n, uint64_t env_base, uint8_t 
     return 0;
 }
 
+/* [ref: gameboard.py:132-171 after_state]  every (empty cell row-major, value 2 then 4) outcome with
+ * probability P(value)/n_empty, in the reference's enumeration order; 32 slots per board. */
+ORACLE_API int oracle_chance_outcomes(uint64_t n, const uint8_t *boards, uint8_t *out_boards, float *out_prob,
+                                      uint8_t *out_count)
+{
+    memset(out_boards, 0, (size_t)n * 32 * 16);
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint8_t *b = boards + 16 * i;
+        int n_empty = oracle_count_empty(b);
+        for (int s = 0; s < 32; ++s) out_prob[32 * i + s] = 0.0f;
+        if (n_empty == 0) {                                      /* :156-157 */
+            memcpy(out_boards + (32 * i) * 16, b, 16);
+            out_prob[32 * i] = 1.0f;
+        } else {
+            for (int k = 0; k < n_empty; ++k)                    /* :161 for cell in empty_cells */
+                for (int v = 0; v < 2; ++v) {                    /* :162 for new_value in [2, 4] */
+                    uint8_t *o = out_boards + (32 * i + 2 * k + v) * 16;
+                    memcpy(o, b, 16);
+                    oracle_fill_cell_kv(o, k, (uint8_t)(v + 1));
+                    out_prob[32 * i + 2 * k + v] = (v ? 0.1f : 0.9f) / (float)n_empty;   /* :166 */
+                }
+        }
+        if (out_count) out_count[i] = (uint8_t)(n_empty ? 2 * n_empty : 1);
+    }
+    return 0;
+}
+
 /* [ref: twentyfortyeight/utils/binary.py:11-86 encode_flatten]  eye(width)[log2(cell)], empty -> index 0. */
 ORACLE_API int oracle_encode_onehot(uint64_t n, const uint8_t *boards, uint32_t width, uint8_t *out)
 {

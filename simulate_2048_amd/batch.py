@@ -93,12 +93,14 @@ class BatchedEnv2048:
             self.lib.status(dev, stream, self.num_envs, _p(self.boards), None, _p(self.legal), _p(self.obs), None, None)
         return self.boards
 
-    def step(self, actions: torch.Tensor | None = None):
+    def step(self, actions: torch.Tensor | None = None, *, out_reward=None, out_done=None, out_legal=None, out_obs=None):
         """One transition per board, in place; asynchronous on torch's current stream.
 
         ``actions``: uint8 tensor (N,) on the same device, values taken mod 4 (0 left, 1 up,
         2 right, 3 down); ``None`` draws uniform random actions on device (low two bits of each step word).
-        Returns ``(boards, reward, done)`` -- views of the persistent buffers.
+        ``out_*``: optional caller-owned tensors the kernel writes INSTEAD of the persistent buffers
+        (e.g. slices of a ``[T, N]`` trajectory buffer -- see ``trajectory.TrajectoryBuffer``).
+        Returns ``(boards, reward, done)`` -- views of the buffers that were written.
         """
         flags = self.flags
         if actions is None:
@@ -108,11 +110,21 @@ class BatchedEnv2048:
                 actions = actions.to(device=self.boards.device, dtype=torch.uint8).contiguous()
             if actions.numel() != self.num_envs:
                 raise ValueError(f'expected {self.num_envs} actions, got {actions.numel()}')
+        reward = self.reward if out_reward is None else self._check_out(out_reward, torch.int32, (self.num_envs,))
+        done = self.done if out_done is None else self._check_out(out_done, torch.uint8, (self.num_envs,))
+        legal = self.legal if out_legal is None else self._check_out(out_legal, torch.uint8, (self.num_envs,))
+        obs = self.obs if out_obs is None else self._check_out(out_obs, torch.float32, (self.num_envs, 16))
         dev, stream = _stream_handle(self.device)
-        self.lib.step(dev, stream, self.num_envs, self.env_base, _p(self.boards), _p(actions), _p(self.reward),
-                      _p(self.done), _p(self.legal), _p(self.obs), self.seed, self.step_index, flags)
+        self.lib.step(dev, stream, self.num_envs, self.env_base, _p(self.boards), _p(actions), _p(reward),
+                      _p(done), _p(legal), _p(obs), self.seed, self.step_index, flags)
         self.step_index += 1
-        return self.boards, self.reward, self.done
+        return self.boards, reward, done
+
+    def _check_out(self, t: torch.Tensor, dtype, shape) -> torch.Tensor:
+        if t.dtype != dtype or tuple(t.shape) != tuple(shape) or t.device != self.boards.device or not t.is_contiguous():
+            raise ValueError(f'output buffer must be a contiguous {dtype} tensor of shape {tuple(shape)} on {self.boards.device}, '
+                             f'got {t.dtype} {tuple(t.shape)} on {t.device}')
+        return t
 
     def rollout(self, num_steps: int):
         """``num_steps`` transitions with on-device random actions in ONE kernel (boards stay in

@@ -42,6 +42,7 @@ PROTOTYPES = {
     'env2048_afterstate': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr, _ptr]),
     'env2048_spawn': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr]),
     'env2048_spawn_random': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _u64, _u64, _u32]),
+    'env2048_chance_outcomes': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr]),
     'env2048_status': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
     'env2048_encode_onehot': (_c_int, [_c_int, _ptr, _u64, _ptr, _u32, _ptr]),
     'env2048_pack_i32': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr]),
@@ -118,6 +119,9 @@ class Library:
 
     def spawn_random(self, device, stream, n, env_base, boards, seed, step_index, count) -> None:
         self._check(self._dll.env2048_spawn_random(device, stream, n, env_base, boards, seed, step_index, count))
+
+    def chance_outcomes(self, device, stream, n, boards, out_boards, out_prob, out_count) -> None:
+        self._check(self._dll.env2048_chance_outcomes(device, stream, n, boards, out_boards, out_prob, out_count))
 
     def encode_onehot(self, device, stream, n, boards, width, out) -> None:
         self._check(self._dll.env2048_encode_onehot(device, stream, n, boards, width, out))

@@ -515,6 +515,33 @@ __global__ __launch_bounds__(BLOCK) void spawn_random_kernel(uint64_t n, uint64_
     store_board(boards, i, bd);
 }
 
+// one thread per (board, outcome slot): 32 consecutive lanes write the 512 B of one board's outcomes
+__global__ __launch_bounds__(BLOCK) void chance_outcomes_kernel(uint64_t n, const uint8_t *boards, uint8_t *out_boards,
+                                                                float *out_prob, uint8_t *out_count)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const uint64_t i = t >> 5;
+    if (i >= n) return;
+    const uint32_t slot = (uint32_t)t & 31u;
+    Board bd = load_board(boards, i);
+    const uint32_t empt = empty_mask(bd);
+    const uint32_t n_empty = ENV2048_POPC(empt);
+    const uint32_t k = slot >> 1;
+    float prob = 0.0f;
+    if (n_empty == 0u) {
+        prob = slot == 0u ? 1.0f : 0.0f;  // [ref gameboard.py:156-157] full board: itself, probability 1
+        if (slot != 0u) bd = Board{0u, 0u, 0u, 0u};
+    } else if (k < n_empty) {
+        place_tile(bd, kth_empty(empt, k), slot & 1u);
+        prob = ((slot & 1u) ? 0.1f : 0.9f) / (float)n_empty;
+    } else {
+        bd = Board{0u, 0u, 0u, 0u};
+    }
+    store_board(out_boards, t, bd);
+    out_prob[t] = prob;
+    if (out_count && slot == 0u) out_count[i] = (uint8_t)(n_empty ? 2u * n_empty : 1u);
+}
+
 // one thread per cell: `width` bytes, a single 1 at the cell's exponent
 __global__ __launch_bounds__(BLOCK) void onehot_kernel(uint64_t n_cells, const uint8_t *boards, uint32_t width, uint8_t *out)
 {
@@ -808,6 +835,22 @@ int env2048_spawn_random(int device, void *stream, uint64_t n, uint64_t env_base
     hipLaunchKernelGGL(spawn_random_kernel, grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, n, env_base, boards,
                        (uint32_t)seed, (uint32_t)(seed >> 32), step_index, count);
     return launched("env2048_spawn_random launch");
+}
+
+int env2048_chance_outcomes(int device, void *stream, uint64_t n, const uint8_t *boards, uint8_t *out_boards, float *out_prob,
+                            uint8_t *out_count)
+{
+    if (n == 0) return ENV2048_OK;
+    if (!boards || !out_boards || !out_prob)
+        return fail(ENV2048_ERR_INVALID_ARG, "env2048_chance_outcomes: boards, out_boards and out_prob are required");
+    if (misaligned(boards, 16) || misaligned(out_boards, 16) || misaligned(out_prob, 4))
+        return fail(ENV2048_ERR_ALIGNMENT, "env2048_chance_outcomes: misaligned buffer");
+    if (int rc = check_count(32 * n)) return rc;
+    DeviceScope scope(device);
+    if (scope.rc) return scope.rc;
+    hipLaunchKernelGGL(chance_outcomes_kernel, grid_for(32 * n), dim3(BLOCK), 0, (hipStream_t)stream, n, boards, out_boards,
+                       out_prob, out_count);
+    return launched("env2048_chance_outcomes launch");
 }
 
 int env2048_encode_onehot(int device, void *stream, uint64_t n, const uint8_t *boards, uint32_t width, uint8_t *out)

@@ -98,6 +98,18 @@ def status(boards: torch.Tensor, *, done=True, legal=True, obs=False, max_exp=Fa
     return out
 
 
+def chance_outcomes(boards: torch.Tensor, rt=None):
+    """All spawn outcomes of every afterstate: (outcome boards (n,32,16) uint8, prob (n,32) f32, count (n,) uint8)."""
+    rt = rt or runtime.current()
+    n = boards.shape[0]
+    out = torch.empty((n, 32, 16), dtype=torch.uint8, device=rt.device)
+    prob = torch.empty((n, 32), dtype=torch.float32, device=rt.device)
+    count = torch.empty((n,), dtype=torch.uint8, device=rt.device)
+    dev, stream = rt.handles()
+    rt.lib.chance_outcomes(dev, stream, n, _p(boards), _p(out), _p(prob), _p(count))
+    return out, prob, count
+
+
 def onehot(boards: torch.Tensor, width: int = 31, rt=None) -> torch.Tensor:
     rt = rt or runtime.current()
     n = boards.shape[0]

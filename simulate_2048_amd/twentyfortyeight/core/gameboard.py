@@ -49,18 +49,17 @@ def latent_state(state: ndarray, action: int) -> tuple[ndarray, float]:
 
 
 def after_state(state: ndarray) -> list[tuple[ndarray, float]]:
-    """[ref gameboard.py:132-171] every (cell, value) spawn outcome with its probability."""
+    """[ref gameboard.py:132-171] every (cell, value) spawn outcome with its probability, enumerated
+    on device in the reference's order (empty cells row-major, value 2 then 4)."""
     state = np.asarray(state)
     num_empty_cells = int((state == 0).sum())
     if num_empty_cells == 0:
         return [(state, 1.0)]
-    # ##>: One device board per outcome: cell rank k (row-major) x value {2, 4}, same order as the reference.
-    ranks = np.repeat(np.arange(num_empty_cells, dtype=np.uint8), 2)
-    exps = np.tile(np.array([1, 2], dtype=np.uint8), num_empty_cells)
-    boards = to_device(state).repeat(2 * num_empty_cells, 1)
-    ops.spawn(boards, ranks, exps)
-    values = host(ops.unpack(boards)).reshape(-1, 4, 4).astype(state.dtype, copy=False)
-    return [(values[i], TILE_SPAWN_PROBS[2 if i % 2 == 0 else 4] / num_empty_cells) for i in range(values.shape[0])]
+    boards, _, count = ops.chance_outcomes(to_device(state))
+    count = int(host(count)[0])
+    values = host(ops.unpack(boards.reshape(32, 16)[:count])).reshape(-1, 4, 4).astype(state.dtype, copy=False)
+    # ##>: probabilities in float64 exactly as the reference computes them (TILE_SPAWN_PROBS[v] / n)
+    return [(values[i], TILE_SPAWN_PROBS[2 if i % 2 == 0 else 4] / num_empty_cells) for i in range(count)]
 
 
 def after_state_lazy(state: ndarray) -> tuple[ndarray, list[tuple[int, int]], int]:

@@ -103,6 +103,14 @@ class OracleLibrary:
             if ptr is not None:
                 _view(ptr, n * width, dtype)[:] = res[key].reshape(-1)
 
+    def chance_outcomes(self, device, stream, n, boards, out_boards, out_prob, out_count):
+        self.calls.append(('chance_outcomes', n))
+        res = oracle.chance_outcomes(_view(boards, n * 16, np.uint8).reshape(n, 16).copy())
+        _view(out_boards, n * 32 * 16, np.uint8)[:] = res['boards'].reshape(-1)
+        _view(out_prob, n * 32, np.float32)[:] = res['prob'].reshape(-1)
+        if out_count is not None:
+            _view(out_count, n, np.uint8)[:] = res['count']
+
     def encode_onehot(self, device, stream, n, boards, width, out):
         self.calls.append(('encode_onehot', n))
         res = oracle.encode_onehot(_view(boards, n * 16, np.uint8).reshape(n, 16).copy(), width)

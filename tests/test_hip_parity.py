@@ -376,3 +376,64 @@ def test_full_size_checksum_vs_oracle(lib):
         assert np.array_equal(b.cpu().numpy(), ref_boards)
         assert np.array_equal(reward.cpu().numpy(), ref['reward'])
         assert np.array_equal(done.cpu().numpy(), ref['done'])
+
+
+# ---------------------------------------------------------------------------- entry points added for the API mirrors
+def test_chance_outcomes_match_oracle(lib, golden):
+    boards = golden['afterstates']['boards']
+    n = boards.shape[0]
+    b = cu(boards)
+    out = torch.zeros((n, 32, 16), dtype=torch.uint8, device='cuda')
+    prob = torch.zeros((n, 32), dtype=torch.float32, device='cuda')
+    count = torch.zeros((n,), dtype=torch.uint8, device='cuda')
+    lib.chance_outcomes(DEV, stream(), n, p(b), p(out), p(prob), p(count))
+    torch.cuda.synchronize()
+    ref = oracle.chance_outcomes(boards)
+    np.testing.assert_array_equal(out.cpu().numpy(), ref['boards'])
+    np.testing.assert_array_equal(prob.cpu().numpy(), ref['prob'])  # same f32 division on both sides
+    np.testing.assert_array_equal(count.cpu().numpy(), ref['count'])
+    sums = prob.sum(dim=1).cpu().numpy()
+    np.testing.assert_allclose(sums, 1.0, atol=1e-6)
+
+
+def test_spawn_random_and_onehot_match_oracle(lib, golden):
+    boards = golden['afterstates']['boards']
+    n = boards.shape[0]
+    for count, env_base in ((1, 0), (2, 1001), (3, (1 << 33) + 2)):
+        b = cu(boards)
+        lib.spawn_random(DEV, stream(), n, env_base, p(b), 99, 7, count)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(b.cpu().numpy(), oracle.spawn_random_batch(boards, 99, 7, count, env_base=env_base))
+    small = np.minimum(boards, 30)
+    b = cu(small)
+    out = torch.zeros((n, 16 * 31), dtype=torch.uint8, device='cuda')
+    lib.encode_onehot(DEV, stream(), n, p(b), 31, p(out))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(out.cpu().numpy(), oracle.encode_onehot(small, 31))
+    g = golden['transforms']
+    b = cu(g['boards'])
+    out = torch.zeros((g['boards'].shape[0], 16 * 31), dtype=torch.uint8, device='cuda')
+    lib.encode_onehot(DEV, stream(), g['boards'].shape[0], p(b), 31, p(out))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(out.cpu().numpy(), g['onehot31'])  # the reference's encode_flatten(..., 31)
+
+
+def test_trajectory_buffer_on_gpu(lib):
+    from simulate_2048_amd import BatchedEnv2048
+    from simulate_2048_amd.trajectory import TrajectoryBuffer
+
+    n, T, seed = 5000, 20, 17
+    env = BatchedEnv2048(n, seed, device='cuda:0', auto_reset=True)
+    env.reset()
+    traj = TrajectoryBuffer(env, T, record_boards=True)
+    traj.begin()
+    ref, _ = oracle.reset_batch(n, seed, 0)
+    for t in range(T):
+        traj.step(None)
+        res = oracle.step_batch(ref, None, seed, t, flags=3, want_legal=True, want_obs=True)
+        ref = res['boards']
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(traj.boards[T].cpu().numpy(), ref)
+    np.testing.assert_array_equal(traj.legal[T].cpu().numpy(), res['legal'])
+    np.testing.assert_array_equal(traj.obs[T].cpu().numpy(), res['obs'])
+    np.testing.assert_array_equal(traj.reward[T - 1].cpu().numpy(), res['reward'])

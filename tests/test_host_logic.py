@@ -188,3 +188,33 @@ def test_two_process_gloo_sharding(tmp_path):
     np.testing.assert_array_equal(np.load(out), ref)
     stats = re.search(r'STATS (\d+) (\d+) (\d+)', proc.stdout)
     assert stats and [int(x) for x in stats.groups()] == [reward, episodes, total]
+
+
+def test_trajectory_buffer_records_in_place():
+    """N4: reward/done/legal/obs rows are written by the step call itself; row t+1 describes the board after step t."""
+    from simulate_2048_amd.trajectory import TrajectoryBuffer
+
+    n, T, seed = 200, 12, 31
+    env = BatchedEnv2048(n, seed, device='cpu', auto_reset=True, lib=OracleLibrary())
+    env.reset()
+    traj = TrajectoryBuffer(env, T, record_boards=True)
+    traj.begin()
+    rng = np.random.default_rng(4)
+    ref, _ = oracle.reset_batch(n, seed, 0)
+    np.testing.assert_array_equal(traj.legal[0].numpy(), oracle.status_batch(ref)['legal'])
+    for t in range(T):
+        acts = rng.integers(0, 4, size=n).astype(np.uint8)
+        traj.actions[t].copy_(torch.from_numpy(acts))
+        traj.step(traj.actions[t])  # the row itself: no copy
+        res = oracle.step_batch(ref, acts, seed, t, flags=1, want_legal=True, want_obs=True)
+        ref = res['boards']
+        np.testing.assert_array_equal(traj.reward[t].numpy(), res['reward'])
+        np.testing.assert_array_equal(traj.done[t].numpy(), res['done'])
+        np.testing.assert_array_equal(traj.legal[t + 1].numpy(), res['legal'])
+        np.testing.assert_array_equal(traj.obs[t + 1].numpy(), res['obs'])
+        np.testing.assert_array_equal(traj.boards[t + 1].numpy(), ref)
+    assert traj.t == T and int(traj.returns().sum()) == int(traj.reward.sum())
+    with pytest.raises(IndexError):
+        traj.step(None)
+    with pytest.raises(ValueError):
+        env.step(None, out_reward=torch.zeros(n, dtype=torch.int64))
