@@ -108,6 +108,22 @@ ENV2048_EXPORT int env2048_step(int device, void *stream, uint64_t n, uint64_t e
                  uint64_t seed, uint64_t step_index, uint32_t flags);
 
 /*
+ * The reinforce/game form of one transition, fused: boards are int32 tile VALUES (n x 16, in
+ * place) as in GameState.board; semantics are those of reinforce/game/env.py:79-133 --
+ *     if done_io[i]:  nothing changes, reward[i] = 0, done stays 1           (done-guard, :103-104)
+ *     else:           board = next_state(board, action) with the step word of (env_base+i, step_index),
+ *                     reward[i] = float32 score (0 for an invalid move), step_count[i] += 1 (also on
+ *                     invalid moves, :116), total_reward[i] += reward[i],
+ *                     done_io[i] = "no action changes the board" (the JAX is_done, core.py:320-321)
+ *     max_tile[i] = largest tile value of the board written back (info dict, :127-131)
+ * actions are int32 (taken mod 4).  step_count, total_reward, max_tile may be NULL.
+ * [replaces: reinforce/game/env.py:79-133 step, :193-211 batched_step]
+ */
+ENV2048_EXPORT int env2048_step_state_i32(int device, void *stream, uint64_t n, uint64_t env_base, int32_t *boards,
+                                          const int32_t *actions, int32_t *step_count, uint8_t *done_io, float *total_reward,
+                                          float *reward, int32_t *max_tile, uint64_t seed, uint64_t step_index);
+
+/*
  * T consecutive transitions per board, boards held in registers, actions drawn on device
  * (low two bits of each step word): identical to T calls of env2048_step(..., step0 + t,
  * flags | RANDOM_ACTIONS).  Per-environment outputs (each may be NULL):

@@ -392,6 +392,40 @@ ORACLE_API int oracle_rollout_batch(uint64_t n, uint64_t env_base, uint8_t *boar
     return 0;
 }
 
+/* [ref: reinforce/game/env.py:79-133 step]  the JAX-shaped transition on int32 value boards:
+ * done-guard (:103-104), next_state (:108), is_done = no legal action (:111 -> core.py:320-321),
+ * step_count + 1 also on invalid moves (:116), total_reward += reward (:118), info.max_tile (:128). */
+ORACLE_API int oracle_step_state_i32(uint64_t n, uint64_t env_base, int32_t *boards, const int32_t *actions,
+                                     int32_t *step_count, uint8_t *done_io, float *total_reward, float *reward,
+                                     int32_t *max_tile, uint64_t seed, uint64_t step_index)
+{
+    for (uint64_t i = 0; i < n; ++i) {
+        int32_t *v = boards + 16 * i;
+        uint8_t b[16];
+        for (int c = 0; c < 16; ++c) {
+            int e = 0;
+            for (int32_t x = v[c]; x > 1; x >>= 1) ++e;
+            b[c] = (uint8_t)(v[c] > 0 ? e : 0);
+        }
+        float r = 0.0f;
+        if (!done_io[i]) {                                                   /* :124 lax.cond(state.done, ...) */
+            int d = 0, ch = 0;
+            uint32_t w = step_word(seed, env_base + i, step_index);
+            r = (float)step_one(b, (int)((uint32_t)actions[i] & 3u), seed, env_base + i, step_index, 0u, w, &d, &ch);
+            for (int c = 0; c < 16; ++c) v[c] = b[c] ? (int32_t)1 << b[c] : 0;
+            done_io[i] = (uint8_t)(oracle_legal_actions_mask(b) == 0);      /* :111 */
+            if (step_count) step_count[i] += 1;                             /* :116 */
+            if (total_reward) total_reward[i] += r;                         /* :118 */
+        }
+        reward[i] = r;
+        if (max_tile) {
+            int m = oracle_max_exponent(b);
+            max_tile[i] = m ? (int32_t)1 << m : 0;                          /* :128 */
+        }
+    }
+    return 0;
+}
+
 /* Afterstate only [ref: gameboard.py:105-129 latent_state; reinforce/game/core.py:129-170]:
  * out = slide/merge of in under action; reward = score (NOT zeroed for invalid moves: an
  * invalid move merges nothing, so it is 0 anyway); changed = (out != in)

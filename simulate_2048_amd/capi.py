@@ -38,6 +38,7 @@ PROTOTYPES = {
     'env2048_device_count': (_c_int, []),
     'env2048_reset': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _ptr, _u64, _u64]),
     'env2048_step': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _u64, _u64, _u32]),
+    'env2048_step_state_i32': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _u64, _u64]),
     'env2048_rollout': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _u64, _u64, _u32, _ptr, _ptr, _ptr, _u32]),
     'env2048_afterstate': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr, _ptr]),
     'env2048_spawn': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr]),
@@ -105,6 +106,11 @@ class Library:
              flags) -> None:
         self._check(self._dll.env2048_step(device, stream, n, env_base, boards, actions, reward, done, legal, obs,
                                            seed, step_index, flags))
+
+    def step_state_i32(self, device, stream, n, env_base, boards, actions, step_count, done_io, total_reward, reward, max_tile,
+                       seed, step_index) -> None:
+        self._check(self._dll.env2048_step_state_i32(device, stream, n, env_base, boards, actions, step_count, done_io,
+                                                     total_reward, reward, max_tile, seed, step_index))
 
     def rollout(self, device, stream, n, env_base, boards, seed, step0, T, return_sum, episodes, valid_moves,
                 flags) -> None:

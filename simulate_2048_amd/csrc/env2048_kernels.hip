@@ -457,6 +457,64 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(RolloutArgs a)
     }
 }
 
+// reinforce/game step on int32 value boards, everything of env.py:79-133 in one launch (one board
+// per lane; a compatibility path for the JAX-shaped API, not the throughput path).
+__device__ __forceinline__ uint32_t pack4(int4 v)
+{
+    auto e = [](int x) -> uint32_t { return x > 0 ? (uint32_t)(31 - __clz(x)) : 0u; };
+    return e(v.x) | (e(v.y) << 8) | (e(v.z) << 16) | (e(v.w) << 24);
+}
+__device__ __forceinline__ int4 unpack4(uint32_t r)
+{
+    auto v = [](uint32_t e) -> int { return e ? (int)(1u << (e & 31u)) : 0; };
+    return make_int4(v(r & 0xFFu), v((r >> 8) & 0xFFu), v((r >> 16) & 0xFFu), v(r >> 24));
+}
+
+__global__ __launch_bounds__(BLOCK) void step_state_i32_kernel(uint64_t n, uint64_t env_base, int32_t *boards,
+                                                               const int32_t *actions, int32_t *step_count, uint8_t *done_io,
+                                                               float *total_reward, float *reward_out, int32_t *max_tile,
+                                                               RngKey key)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    int4 *rows = reinterpret_cast<int4 *>(boards) + 4 * i;
+    Board bd{pack4(rows[0]), pack4(rows[1]), pack4(rows[2]), pack4(rows[3])};
+    const bool was_done = done_io[i] != 0;
+    const uint64_t env = env_base + i;
+    uint32_t w[4];
+    env_block(key, env >> 2, STREAM_STEP, w[0], w[1], w[2], w[3]);
+    const uint32_t sel = (uint32_t)env & 3u;
+    const uint32_t word = sel == 0u ? w[0] : sel == 1u ? w[1] : sel == 2u ? w[2] : w[3];
+    float reward = 0.0f;
+    if (!was_done) {
+        uint32_t score;
+        bool changed;
+        afterstate(bd, (uint32_t)actions[i] & 3u, score, changed);
+        spawn_tile_word(bd, word, changed);
+        reward = (float)score;  // exact: a step's score is < 2^24
+        rows[0] = unpack4(bd.r0);
+        rows[1] = unpack4(bd.r1);
+        rows[2] = unpack4(bd.r2);
+        rows[3] = unpack4(bd.r3);
+        done_io[i] = legal_mask(bd) == 0u ? 1 : 0;
+        if (step_count) step_count[i] += 1;
+        if (total_reward) total_reward[i] += reward;
+    }
+    reward_out[i] = reward;
+    if (max_tile) {
+        const uint32_t rws[4] = {bd.r0, bd.r1, bd.r2, bd.r3};
+        uint32_t m = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            m = max(m, rws[r] & 0xFFu);
+            m = max(m, (rws[r] >> 8) & 0xFFu);
+            m = max(m, (rws[r] >> 16) & 0xFFu);
+            m = max(m, rws[r] >> 24);
+        }
+        max_tile[i] = m ? (int32_t)(1u << (m & 31u)) : 0;
+    }
+}
+
 __global__ __launch_bounds__(BLOCK) void afterstate_kernel(uint64_t n, const uint8_t *boards_in,
                                                            const uint8_t *actions, uint8_t *boards_out,
                                                            int32_t *reward, uint8_t *changed_out)
@@ -542,14 +600,33 @@ __global__ __launch_bounds__(BLOCK) void chance_outcomes_kernel(uint64_t n, cons
     if (out_count && slot == 0u) out_count[i] = (uint8_t)(n_empty ? 2u * n_empty : 1u);
 }
 
-// one thread per cell: `width` bytes, a single 1 at the cell's exponent
-__global__ __launch_bounds__(BLOCK) void onehot_kernel(uint64_t n_cells, const uint8_t *boards, uint32_t width, uint8_t *out)
+// One block per 64 boards; a thread writes whole output DWORDs (coalesced 4-byte stores): byte g of a
+// board's 16*width-byte record belongs to cell g / width and is 1 iff g % width equals that cell's
+// exponent.  All index arithmetic is 32-bit on block-local offsets (16 * width is a multiple of 4).
+__global__ __launch_bounds__(BLOCK) void onehot_kernel(uint64_t n, const uint8_t *boards, uint32_t width, uint32_t *out)
 {
-    const uint64_t c = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (c >= n_cells) return;
-    const uint32_t e = boards[c];
-    uint8_t *o = out + c * width;
-    for (uint32_t k = 0; k < width; ++k) o[k] = (k == e) ? 1 : 0;
+    __shared__ uint8_t cells[64 * 16];
+    const uint64_t board0 = (uint64_t)blockIdx.x * 64;
+    const uint32_t n_boards = (uint32_t)min((uint64_t)64, n - board0);
+    for (uint32_t c = threadIdx.x; c < n_boards * 16u; c += BLOCK) cells[c] = boards[board0 * 16 + c];
+    __syncthreads();
+    const uint32_t dwords = n_boards * 4u * width;  // 16 * width bytes per board
+    uint32_t *dst = out + board0 * 4u * width;
+    for (uint32_t d = threadIdx.x; d < dwords; d += BLOCK) {
+        const uint32_t g0 = 4u * d;
+        uint32_t cell = g0 / width;
+        uint32_t pos = g0 - cell * width;
+        uint32_t word = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            word |= (pos == cells[cell & 1023u] ? 1u : 0u) << (8 * b);
+            if (++pos == width) {
+                pos = 0;
+                ++cell;
+            }
+        }
+        dst[d] = word;
+    }
 }
 
 __global__ __launch_bounds__(256) void status_kernel(uint64_t n, const uint8_t *boards, uint8_t *done,
@@ -767,6 +844,27 @@ int env2048_step(int device, void *stream, uint64_t n, uint64_t env_base, uint8_
     return launched("env2048_step launch");
 }
 
+int env2048_step_state_i32(int device, void *stream, uint64_t n, uint64_t env_base, int32_t *boards, const int32_t *actions,
+                           int32_t *step_count, uint8_t *done_io, float *total_reward, float *reward, int32_t *max_tile,
+                           uint64_t seed, uint64_t step_index)
+{
+    if (n == 0) return ENV2048_OK;
+    if (!boards || !actions || !done_io || !reward)
+        return fail(ENV2048_ERR_INVALID_ARG, "env2048_step_state_i32: boards, actions, done_io and reward are required");
+    if (misaligned(boards, 16)) return fail(ENV2048_ERR_ALIGNMENT, "env2048_step_state_i32: boards must be 16-byte aligned");
+    if (misaligned(actions, 4) || misaligned(step_count, 4) || misaligned(total_reward, 4) || misaligned(reward, 4) ||
+        misaligned(max_tile, 4))
+        return fail(ENV2048_ERR_ALIGNMENT, "env2048_step_state_i32: misaligned 4-byte array");
+    if (int rc = check_range(n, env_base)) return rc;
+    if (int rc = check_count(n)) return rc;
+    DeviceScope scope(device);
+    if (scope.rc) return scope.rc;
+    const RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)step_index, (uint32_t)(step_index >> 32)};
+    hipLaunchKernelGGL(step_state_i32_kernel, grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, n, env_base, boards, actions,
+                       step_count, done_io, total_reward, reward, max_tile, key);
+    return launched("env2048_step_state_i32 launch");
+}
+
 int env2048_rollout(int device, void *stream, uint64_t n, uint64_t env_base, uint8_t *boards, uint64_t seed,
                     uint64_t step0, uint32_t T, int64_t *return_sum, uint32_t *episodes, uint32_t *valid_moves,
                     uint32_t flags)
@@ -858,10 +956,12 @@ int env2048_encode_onehot(int device, void *stream, uint64_t n, const uint8_t *b
     if (n == 0) return ENV2048_OK;
     if (!boards || !out) return fail(ENV2048_ERR_INVALID_ARG, "env2048_encode_onehot: NULL argument");
     if (width == 0 || width > 255) return fail(ENV2048_ERR_INVALID_ARG, "env2048_encode_onehot: width %u not in [1, 255]", width);
-    if (int rc = check_count(16 * n)) return rc;
+    if (misaligned(out, 4)) return fail(ENV2048_ERR_ALIGNMENT, "env2048_encode_onehot: out must be 4-byte aligned");
+    if (int rc = check_count(n)) return rc;
     DeviceScope scope(device);
     if (scope.rc) return scope.rc;
-    hipLaunchKernelGGL(onehot_kernel, grid_for(16 * n), dim3(BLOCK), 0, (hipStream_t)stream, 16 * n, boards, width, out);
+    hipLaunchKernelGGL(onehot_kernel, dim3((unsigned)((n + 63) / 64)), dim3(BLOCK), 0, (hipStream_t)stream, n, boards, width,
+                       reinterpret_cast<uint32_t *>(out));
     return launched("env2048_encode_onehot launch");
 }
 

@@ -54,32 +54,25 @@ def batched_reset(keys) -> GameState:
 def batched_step(states: GameState, actions, keys):
     """[ref env.py:193-211] one move per environment -> (GameState, reward (N,) f32, done (N,) bool, info).
 
-    Finished games are frozen exactly like the reference's done-guard (env.py:103-104): state
-    unchanged, reward 0.0, done True, step_count not advanced.
+    One fused kernel (env2048_step_state_i32).  Finished games are frozen exactly like the
+    reference's done-guard (env.py:103-104): state unchanged, reward 0.0, done True, step_count not
+    advanced.  The input state is not modified (functional API): its fields are copied first.
     """
     rt = runtime.current()
-    boards_in = _board_tensor(states.board).reshape(-1, 4, 4)
-    n = boards_in.shape[0]
-    done_in = torch.as_tensor(states.done).to(device=rt.device, dtype=torch.bool).reshape(n)
-    packed = ops.pack(boards_in.reshape(n, 16))
-    out = ops.step(packed, torch.as_tensor(actions).reshape(n), _keys_to_seed(keys), 0)
-    new_boards = ops.unpack(packed, dtype=torch.int32).reshape(n, 4, 4)
-    reward = out['reward'].to(torch.float32)
-    # ##>: env.py:111 -- done = is_done(new_board), the JAX is_done: "no legal action".
-    game_done = ops.status(packed, done=False, legal=True)['legal'] == 0
-    guard = done_in.view(n, 1, 1)
-    board = torch.where(guard, boards_in, new_boards)
-    reward = torch.where(done_in, torch.zeros_like(reward), reward)
-    done = done_in | game_done
-    step_count = torch.as_tensor(states.step_count).to(device=rt.device, dtype=torch.int32).reshape(n)
-    step_count = torch.where(done_in, step_count, step_count + 1)
-    total = torch.as_tensor(states.total_reward).to(device=rt.device, dtype=torch.float32).reshape(n) + reward
+    board = _board_tensor(states.board).reshape(-1, 4, 4).clone()
+    n = board.shape[0]
+    step_count = torch.as_tensor(states.step_count).to(device=rt.device, dtype=torch.int32).reshape(n).clone()
+    done_u8 = torch.as_tensor(states.done).to(device=rt.device).reshape(n).to(torch.uint8).contiguous()
+    total = torch.as_tensor(states.total_reward).to(device=rt.device, dtype=torch.float32).reshape(n).clone()
+    acts = torch.as_tensor(actions).reshape(n).to(device=rt.device, dtype=torch.int32).contiguous()
+    reward = torch.empty((n,), dtype=torch.float32, device=rt.device)
+    max_tile = torch.empty((n,), dtype=torch.int32, device=rt.device)
+    dev, stream = rt.handles()
+    rt.lib.step_state_i32(dev, stream, n, 0, board.data_ptr(), acts.data_ptr(), step_count.data_ptr(), done_u8.data_ptr(),
+                          total.data_ptr(), reward.data_ptr(), max_tile.data_ptr(), _keys_to_seed(keys), 0)
+    done = done_u8.to(torch.bool)
     new_state = GameState(board=board, step_count=step_count, done=done, total_reward=total)
-    info = {
-        'max_tile': board.reshape(n, 16).max(dim=1).values,
-        'step_count': step_count,
-        'total_reward': total,
-    }
+    info = {'max_tile': max_tile, 'step_count': step_count, 'total_reward': total}
     return new_state, reward, done, info
 
 

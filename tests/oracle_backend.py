@@ -61,6 +61,25 @@ class OracleLibrary:
         if obs is not None:
             _view(obs, n * 16, np.float32)[:] = res['obs'].reshape(-1)
 
+    def step_state_i32(self, device, stream, n, env_base, boards, actions, step_count, done_io, total_reward, reward, max_tile,
+                       seed, step_index):
+        self.calls.append(('step_state_i32', n))
+        zeros_i = np.zeros(n, dtype=np.int32)
+        zeros_f = np.zeros(n, dtype=np.float32)
+        res = oracle.step_state_i32(_view(boards, n * 16, np.int32).reshape(n, 16), _view(actions, n, np.int32),
+                                    zeros_i if step_count is None else _view(step_count, n, np.int32), _view(done_io, n, np.uint8),
+                                    zeros_f if total_reward is None else _view(total_reward, n, np.float32), seed, step_index,
+                                    env_base=env_base)
+        _view(boards, n * 16, np.int32)[:] = res['boards'].reshape(-1)
+        _view(done_io, n, np.uint8)[:] = res['done']
+        _view(reward, n, np.float32)[:] = res['reward']
+        if step_count is not None:
+            _view(step_count, n, np.int32)[:] = res['step_count']
+        if total_reward is not None:
+            _view(total_reward, n, np.float32)[:] = res['total_reward']
+        if max_tile is not None:
+            _view(max_tile, n, np.int32)[:] = res['max_tile']
+
     def rollout(self, device, stream, n, env_base, boards, seed, step0, T, return_sum, episodes, valid_moves, flags):
         self.calls.append(('rollout', n))
         b = _view(boards, n * 16, np.uint8)

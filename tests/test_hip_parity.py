@@ -437,3 +437,32 @@ def test_trajectory_buffer_on_gpu(lib):
     np.testing.assert_array_equal(traj.legal[T].cpu().numpy(), res['legal'])
     np.testing.assert_array_equal(traj.obs[T].cpu().numpy(), res['obs'])
     np.testing.assert_array_equal(traj.reward[T - 1].cpu().numpy(), res['reward'])
+
+
+def test_step_state_i32_matches_oracle(lib):
+    """Fused reinforce/game step on int32 value boards: done-guard, bookkeeping, JAX is_done."""
+    rng = np.random.default_rng(11)
+    n = 30_001
+    exps = random_boards(rng, n)
+    values = oracle.unpack_values(exps).astype(np.int32)
+    actions = rng.integers(-3, 9, size=n).astype(np.int32)  # any int: taken mod 4 (two's complement & 3)
+    step_count = rng.integers(0, 500, size=n).astype(np.int32)
+    done = (rng.random(n) < 0.2).astype(np.uint8)
+    total = rng.integers(0, 5000, size=n).astype(np.float32)
+    seed, step, env_base = 0xABCDEF, 77, 13
+    ref = oracle.step_state_i32(values, actions, step_count, done, total, seed, step, env_base=env_base)
+    b, a = cu(values), cu(actions)
+    sc, d, tr = cu(step_count), cu(done), cu(total)
+    reward = torch.full((n,), -1.0, dtype=torch.float32, device='cuda')
+    max_tile = torch.full((n,), -1, dtype=torch.int32, device='cuda')
+    lib.step_state_i32(DEV, stream(), n, env_base, p(b), p(a), p(sc), p(d), p(tr), p(reward), p(max_tile), seed, step)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(b.cpu().numpy(), ref['boards'])
+    np.testing.assert_array_equal(sc.cpu().numpy(), ref['step_count'])
+    np.testing.assert_array_equal(d.cpu().numpy(), ref['done'])
+    np.testing.assert_array_equal(tr.cpu().numpy(), ref['total_reward'])
+    np.testing.assert_array_equal(reward.cpu().numpy(), ref['reward'])
+    np.testing.assert_array_equal(max_tile.cpu().numpy(), ref['max_tile'])
+    frozen = done.astype(bool)
+    np.testing.assert_array_equal(ref['boards'][frozen], values[frozen])  # the guard really froze them
+    assert not ref['reward'][frozen].any()
