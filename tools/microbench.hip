@@ -207,6 +207,25 @@ __global__ __launch_bounds__(256) void k_mulrate(uint32_t *out, int iters, int m
             z = (z * 0xD2511F53u) ^ w;
             w = (w * 0xCD9E8D57u) ^ x;
         }
+    } else if (mode == 3) {  // one v_mad_u64_u32 per product: hi and lo from a single instruction
+        for (int i = 0; i < iters; ++i) {
+            uint64_t p0, p1;
+            asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(p0) : "v"(x), "v"(0xD2511F53u) : "vcc");
+            asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(p1) : "v"(z), "v"(0xCD9E8D57u) : "vcc");
+            x = (uint32_t)(p1 >> 32) ^ y;
+            y = (uint32_t)p1;
+            z = (uint32_t)(p0 >> 32) ^ w;
+            w = (uint32_t)p0;
+        }
+    } else if (mode == 4) {  // the same Philox-like round with separate mul_hi / mul_lo
+        for (int i = 0; i < iters; ++i) {
+            uint32_t h0 = __umulhi(x, 0xD2511F53u), l0 = x * 0xD2511F53u;
+            uint32_t h1 = __umulhi(z, 0xCD9E8D57u), l1 = z * 0xCD9E8D57u;
+            x = h1 ^ y;
+            y = l1;
+            z = h0 ^ w;
+            w = l0;
+        }
     } else {
         for (int i = 0; i < iters; ++i) {
             x = (x + 0xD2511F53u) ^ y;
@@ -335,6 +354,17 @@ int main(int argc, char **argv)
         std::string name = std::string("EXP ") + argv[ai];
         typedef const char *(*err_fn_t)(void);
         err_fn_t err = (err_fn_t)dlsym(h, "env2048_last_error");
+        typedef int (*roll_fn_t)(int, void *, uint64_t, uint64_t, uint8_t *, uint64_t, uint64_t, uint32_t, int64_t *, uint32_t *,
+                                 uint32_t *, uint32_t);
+        roll_fn_t roll = (roll_fn_t)dlsym(h, "env2048_rollout");
+        std::string rname = std::string("EXPROLL16 ") + argv[ai];
+        run(rname.c_str(), [=](int t) {
+            int rc = roll(0, s, n, 0, (uint8_t *)boards, 0x2048, 16 * (uint64_t)t, 16, nullptr, nullptr, nullptr, 3);
+            if (rc) {
+                fprintf(stderr, "env2048_rollout failed: %d %s\n", rc, err());
+                exit(2);
+            }
+        });
         run(name.c_str(), [=](int t) {
             int rc = fn(0, s, n, 0, (uint8_t *)boards, actions + (uint64_t)(t & 7) * n, reward, done, nullptr, nullptr, 0x2048, t, 1);
             if (rc) {
@@ -444,7 +474,7 @@ int main(int argc, char **argv)
     // multiply-rate probe: 256 CUs x 8 blocks, 4096 iterations x 4 dependent chains
     uint32_t *out;
     CHECK(hipMalloc(&out, 2048 * 256 * 4));
-    for (int mode = 0; mode < 3; ++mode) {
+    for (int mode = 0; mode < 5; ++mode) {
         const int iters = 4096;
         hipLaunchKernelGGL(k_mulrate, dim3(2048), dim3(256), 0, s, out, iters, mode);
         CHECK(hipStreamSynchronize(s));
@@ -457,7 +487,7 @@ int main(int argc, char **argv)
         // wave-instructions per SIMD: 2048 blocks*4 waves / 1024 SIMDs = 8 waves/SIMD, each iters*8 instr (mul+xor)
         double instr_per_simd = 8.0 * iters * 8;
         printf("mulrate mode %d (%s): %.3f ms -> %.2f ns per wave-instr-pair-slot, ~%.2f cycles/instr at 2.4GHz\n", mode,
-               mode == 0 ? "mul_hi+xor" : mode == 1 ? "mul_lo+xor" : "add+xor", ms, ms * 1e6 / instr_per_simd,
+               mode == 0 ? "mul_hi+xor" : mode == 1 ? "mul_lo+xor" : mode == 2 ? "add+xor" : mode == 3 ? "philox round via 2x mad_u64_u32 (4 instr/iter)" : "philox round via 2x(mul_hi+mul_lo) (6 instr/iter)", ms, ms * 1e6 / instr_per_simd,
                ms * 1e6 / instr_per_simd * 2.4);
     }
     return 0;
