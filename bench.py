@@ -256,7 +256,7 @@ def main():
                 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK_GBS,
                 'traffic': load_traffic(n),
-                'kernel': 'step_kernel<false>' if not args.extras else 'step_kernel<true>',
+                'kernel': 'step_kernel<false, false>' if not args.extras else 'step_kernel<true, false>',
                 'algorithmic_bytes_per_launch': bytes_per_launch,
                 'avg_launch_us': launch_s * 1e6,
             },

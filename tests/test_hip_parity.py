@@ -466,3 +466,25 @@ def test_step_state_i32_matches_oracle(lib):
     frozen = done.astype(bool)
     np.testing.assert_array_equal(ref['boards'][frozen], values[frozen])  # the guard really froze them
     assert not ref['reward'][frozen].any()
+
+
+def test_config4_slicing_at_8x2pow20(lib):
+    """BASELINE config 4 on one GPU: 8 388 608 boards stepped as 8 contiguous slices (what 8 ranks would
+    do, each with env_base = its slice start) equal the unsliced batch -- boards, rewards and done flags."""
+    n, G, seed, T = 8 << 20, 8, 0x2048, 6
+    flags = capi.FLAG_AUTO_RESET | capi.FLAG_RANDOM_ACTIONS
+    whole = torch.empty((n, 16), dtype=torch.uint8, device='cuda')
+    lib.reset(DEV, stream(), n, 0, p(whole), None, seed, 0)
+    lib.rollout(DEV, stream(), n, 0, p(whole), seed, 0, 90, None, None, None, flags)  # mid-game
+    sliced = whole.clone()
+    rw = torch.zeros((n,), dtype=torch.int32, device='cuda')
+    dw = torch.zeros((n,), dtype=torch.uint8, device='cuda')
+    rs, ds = torch.zeros_like(rw), torch.zeros_like(dw)
+    per = n // G
+    for t in range(90, 90 + T):
+        lib.step(DEV, stream(), n, 0, p(whole), None, p(rw), p(dw), None, None, seed, t, flags)
+        for g in range(G):
+            lo = g * per
+            lib.step(DEV, stream(), per, lo, p(sliced) + 16 * lo, None, p(rs) + 4 * lo, p(ds) + lo, None, None, seed, t, flags)
+        assert torch.equal(whole, sliced) and torch.equal(rw, rs) and torch.equal(dw, ds), f'step {t}'
+    assert int(dw.sum()) > 0  # some games ended in the last step: the reset path was exercised at this size
