@@ -1,67 +1,70 @@
-"""2048 game environment class.  Mirror of ``twentyfortyeight/envs/twentyfortyeight.py``."""
+"""
+Single-board environment object with the public surface of the reference's
+``twentyfortyeight/envs/twentyfortyeight.py`` (class ``TwentyFortyEight``), backed by the HIP kernels.
+
+Surface kept (reference lines in brackets): constructor flags ``size / encoded / normalize`` [:21],
+``ACTIONS`` [:19], ``reset(seed)`` [:84-104], ``step(action)`` [:106-133], the properties
+``observation`` [:56-68], ``reward`` [:70-82], ``is_finished`` [:44-54], ``render()`` [:135-140] and the
+two attributes callers are known to poke, ``_current_state`` (int64 4x4 values) and
+``_current_reward`` (tests/test_environment.py:106-107,256,269,315,335 of the reference).
+"""
 
 from __future__ import annotations
 
-from numpy import int64, ndarray, zeros
+import numpy as np
 
-from ..core.gameboard import fill_cells, is_done, next_state
-from ..utils.binary import encode_flatten
-from ..utils.normalize import normalize_reward
+from ..core import gameboard
+from ..utils import binary, normalize
+
+_ONE_HOT_WIDTH = 31  # the reference's encodage_size for the flattened observation
 
 
 class TwentyFortyEight:
-    """
-    2048 game environment with the reference's interface [ref twentyfortyeight.py:10-140]:
-    ``reset(seed) -> observation``, ``step(action) -> (observation, reward, done)``, properties
-    ``observation`` / ``reward`` / ``is_finished``, ``ACTIONS`` and the ``_current_state`` int64
-    board that callers may read or overwrite.  Every transition runs on the GPU.
-    """
-
-    # ##: All Actions.
     ACTIONS = {'left': 0, 'up': 1, 'right': 2, 'down': 3}
 
     def __init__(self, size: int = 4, encoded: bool = False, normalize: bool = False):
         if size != 4:
             raise ValueError(f'TwentyFortyEight: the MI355X engine supports size=4 only, got size={size}')
         self.size = size
-        self._encoded = encoded
-        self._normalize = normalize
-        self._current_state: ndarray = zeros((size, size), dtype=int64)
-        self._current_reward: float = 0.0
+        self._encoded = bool(encoded)
+        self._normalize = bool(normalize)
+        self._current_state = np.zeros((4, 4), dtype=np.int64)
+        self._current_reward = 0.0
         self.reset()
 
+    # -- what the agent sees ---------------------------------------------------------------------
     @property
-    def is_finished(self) -> bool:
-        """True when no move is possible [ref :44-54]."""
-        return is_done(self._current_state)
-
-    @property
-    def observation(self) -> ndarray:
-        """Raw board, or the 16 x 31 one-hot log2 encoding when ``encoded`` [ref :56-68]."""
-        if self._encoded:
-            return encode_flatten(self._current_state, encodage_size=31)
-        return self._current_state
+    def observation(self) -> np.ndarray:
+        """The board itself, or its 16 x 31 one-hot log2 code when built with ``encoded=True``."""
+        board = self._current_state
+        return binary.encode_flatten(board, encodage_size=_ONE_HOT_WIDTH) if self._encoded else board
 
     @property
     def reward(self) -> float:
-        """Last reward, log-normalised when ``normalize`` [ref :70-82]."""
-        if self._normalize:
-            return normalize_reward(self._current_reward)
-        return self._current_reward
+        """Score of the last move; log-scaled into [0, 1] when built with ``normalize=True``."""
+        raw = self._current_reward
+        return normalize.normalize_reward(raw) if self._normalize else raw
 
-    def reset(self, seed: int | None = None) -> ndarray:
-        """Empty board plus two random tiles; returns the observation [ref :84-104]."""
-        self._current_state = zeros((self.size, self.size), dtype=int64)
-        self._current_state = fill_cells(state=self._current_state, number_tile=2, seed=seed)
+    @property
+    def is_finished(self) -> bool:
+        """No move changes the board any more (evaluated on the current ``_current_state``)."""
+        return gameboard.is_done(self._current_state)
+
+    # -- transitions ------------------------------------------------------------------------------
+    def reset(self, seed: int | None = None) -> np.ndarray:
+        """Start over: an empty board that receives two tiles. Returns the new observation."""
+        fresh = np.zeros((self.size, self.size), dtype=np.int64)
+        self._current_state = gameboard.fill_cells(state=fresh, number_tile=2, seed=seed)
         self._current_reward = 0
         return self.observation
 
-    def step(self, action: int) -> tuple[ndarray, float, bool]:
-        """Apply `action` (0 left, 1 up, 2 right, 3 down) -> (observation, reward, done) [ref :106-133]."""
-        self._current_state, self._current_reward = next_state(state=self._current_state, action=action)
+    def step(self, action: int) -> tuple[np.ndarray, float, bool]:
+        """Play ``action`` (0 left, 1 up, 2 right, 3 down): ``(observation, reward, finished)``."""
+        board, gained = gameboard.next_state(state=self._current_state, action=action)
+        self._current_state, self._current_reward = board, gained
         return self.observation, self.reward, self.is_finished
 
     def render(self) -> None:
-        """Print the board, tab separated [ref :135-140]."""
+        """Print the four rows, cells separated by ' \\t'."""
         for row in self._current_state.tolist():
-            print(' \t'.join(map(str, row)))
+            print(' \t'.join(str(cell) for cell in row))
