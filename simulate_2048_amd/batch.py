@@ -18,11 +18,16 @@ import torch
 from . import capi
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)  # int handle without building a Stream object
+
+
 def _stream_handle(device: torch.device):
     """(device ordinal, hipStream_t) of torch's CURRENT stream on `device`."""
     if device.type != 'cuda':
         return -1, None
     index = device.index if device.index is not None else torch.cuda.current_device()
+    if _raw_stream is not None:
+        return index, _raw_stream(index)
     return index, torch.cuda.current_stream(device).cuda_stream
 
 
@@ -75,6 +80,9 @@ class BatchedEnv2048:
         self.done = torch.zeros((n,), dtype=torch.uint8, device=self.device)
         self.legal = torch.zeros((n,), dtype=torch.uint8, device=self.device) if with_legal else None
         self.obs = torch.zeros((n, 16), dtype=torch.float32, device=self.device) if with_obs else None
+        # the persistent buffers never move: keep their addresses (saves ~6 data_ptr() calls per step)
+        self._ptr_boards, self._ptr_reward, self._ptr_done = _p(self.boards), _p(self.reward), _p(self.done)
+        self._ptr_legal, self._ptr_obs = _p(self.legal), _p(self.obs)
 
     # ------------------------------------------------------------------------------------------
     @property
@@ -110,12 +118,17 @@ class BatchedEnv2048:
                 actions = actions.to(device=self.boards.device, dtype=torch.uint8).contiguous()
             if actions.numel() != self.num_envs:
                 raise ValueError(f'expected {self.num_envs} actions, got {actions.numel()}')
+        dev, stream = _stream_handle(self.device)
+        if out_reward is None and out_done is None and out_legal is None and out_obs is None:  # the common, cheap path
+            self.lib.step(dev, stream, self.num_envs, self.env_base, self._ptr_boards, _p(actions), self._ptr_reward,
+                          self._ptr_done, self._ptr_legal, self._ptr_obs, self.seed, self.step_index, flags)
+            self.step_index += 1
+            return self.boards, self.reward, self.done
         reward = self.reward if out_reward is None else self._check_out(out_reward, torch.int32, (self.num_envs,))
         done = self.done if out_done is None else self._check_out(out_done, torch.uint8, (self.num_envs,))
         legal = self.legal if out_legal is None else self._check_out(out_legal, torch.uint8, (self.num_envs,))
         obs = self.obs if out_obs is None else self._check_out(out_obs, torch.float32, (self.num_envs, 16))
-        dev, stream = _stream_handle(self.device)
-        self.lib.step(dev, stream, self.num_envs, self.env_base, _p(self.boards), _p(actions), _p(reward),
+        self.lib.step(dev, stream, self.num_envs, self.env_base, self._ptr_boards, _p(actions), _p(reward),
                       _p(done), _p(legal), _p(obs), self.seed, self.step_index, flags)
         self.step_index += 1
         return self.boards, reward, done
