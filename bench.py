@@ -45,6 +45,8 @@ def parse_args():
     ap.add_argument('--boards', type=int, default=1 << 20, help='boards per GPU')
     ap.add_argument('--mode', choices=['eager', 'graph'], default='eager',
                     help='eager: one C-ABI call per step; graph: the K launches captured once in a hipGraph')
+    ap.add_argument('--chains', type=int, default=1, help='graph mode only: cut the slice into this many independent chains of '
+                    'launches on separate streams inside the graph (experiment; 1 = one launch per step)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='target duration of the CPU baseline sample')
     ap.add_argument('--extras', action='store_true', help='also emit legal mask + f32 obs (not the headline)')
@@ -177,6 +179,16 @@ def main():
         if rc != 0:
             raise capi.Env2048Error(rc, lib.last_error())
 
+    def launch_part(step_index: int, stream_handle, part: int, parts: int):
+        lo = part * (n // parts)
+        cnt = n // parts
+        off = lambda p, scale: None if p is None else ctypes.c_void_p(p.value + lo * scale)
+        rc = step_fn(device_index, stream_handle, cnt, env_base + lo, off(fixed['boards'], 16), off(action_ptrs[step_index & 7], 1),
+                     off(fixed['reward'], 4), off(fixed['done'], 1), off(fixed['legal'], 1), off(fixed['obs'], 64), SEED,
+                     step_index, capi.FLAG_AUTO_RESET)
+        if rc != 0:
+            raise capi.Env2048Error(rc, lib.last_error())
+
     def barrier():
         if dist is not None:
             dist.barrier()
@@ -191,9 +203,24 @@ def main():
                 launch(base_step + t, side.cuda_stream)
             torch.cuda.synchronize()
             with torch.cuda.graph(graph, stream=side):
-                cap = torch.cuda.current_stream(device).cuda_stream
-                for t in range(K):
-                    launch(base_step + W + t, cap)
+                cap_stream = torch.cuda.current_stream(device)
+                if args.chains <= 1:
+                    for t in range(K):
+                        launch(base_step + W + t, cap_stream.cuda_stream)
+                else:
+                    others = [torch.cuda.Stream(device) for _ in range(args.chains - 1)]
+                    fork = torch.cuda.Event()
+                    fork.record(cap_stream)
+                    for o in others:
+                        o.wait_event(fork)
+                    streams = [cap_stream] + others
+                    for t in range(K):
+                        for c, st in enumerate(streams):
+                            launch_part(base_step + W + t, st.cuda_stream, c, args.chains)
+                    for o in others:
+                        ev = torch.cuda.Event()
+                        ev.record(o)
+                        cap_stream.wait_event(ev)
         torch.cuda.synchronize()
 
     h = stream.cuda_stream
