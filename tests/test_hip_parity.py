@@ -488,3 +488,27 @@ def test_config4_slicing_at_8x2pow20(lib):
             lib.step(DEV, stream(), per, lo, p(sliced) + 16 * lo, None, p(rs) + 4 * lo, p(ds) + lo, None, None, seed, t, flags)
         assert torch.equal(whole, sliced) and torch.equal(rw, rs) and torch.equal(dw, ds), f'step {t}'
     assert int(dw.sum()) > 0  # some games ended in the last step: the reset path was exercised at this size
+
+
+def test_soak_rollout_3000_steps(lib):
+    """8192 games x 3000 steps (about 20 finished games each): the fused rollout against the oracle's
+    rollout, compared every 100 steps -- boards, return sums, episode and valid-move counts."""
+    n, seed, chunk = 8192, 424242, 100
+    flags = capi.FLAG_AUTO_RESET | capi.FLAG_RANDOM_ACTIONS
+    ref, _ = oracle.reset_batch(n, seed, 0, threads=16)
+    b = cu(ref)
+    ret = torch.zeros((n,), dtype=torch.int64, device='cuda')
+    eps = torch.zeros((n,), dtype=torch.int32, device='cuda')
+    moves = torch.zeros((n,), dtype=torch.int32, device='cuda')
+    total_eps = 0
+    for step0 in range(0, 3000, chunk):
+        lib.rollout(DEV, stream(), n, 0, p(b), seed, step0, chunk, p(ret), p(eps), p(moves), flags)
+        r = oracle.rollout_batch(ref, seed, step0, chunk, flags=flags, threads=16)
+        ref = r['boards']
+        torch.cuda.synchronize()
+        assert np.array_equal(b.cpu().numpy(), ref), f'boards differ after step {step0 + chunk}'
+        assert np.array_equal(ret.cpu().numpy(), r['return_sum'])
+        assert np.array_equal(eps.cpu().numpy().astype(np.uint32), r['episodes'])
+        assert np.array_equal(moves.cpu().numpy().astype(np.uint32), r['valid_moves'])
+        total_eps += int(r['episodes'].sum())
+    assert total_eps > 15 * n
