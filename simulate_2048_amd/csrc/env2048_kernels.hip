@@ -175,16 +175,20 @@ __device__ __forceinline__ void reset_queued(const StepArgs &a, uint64_t block0,
     }
 }
 
-// The step kernel.  Order of events in a wave (it matters: vmcnt counts loads AND stores in issue
-// order, so a wait for a load that is placed after a store also waits for that store's ack):
-//   1. issue the selector-table load (8 lanes) and the 4 board + 4 action loads of the tile
-//   2. 64 (65) Philox blocks while those are in flight; words -> wave-private LDS strip
-//   3. selector table -> LDS; LDS-only workgroup barrier
-//   4. ONE wait for all loads, then the four transitions with stores issued as results appear and
-//      no further memory waits
-//   5. queue terminal boards; the last wave of the block to finish rebuilds them
+// The step kernel.  Order of events in a wave -- it matters, because vmcnt counts loads AND stores in
+// issue order, so a wait for a load that sits behind a store also waits for that store's ack:
+//   1. issue the selector-table load (8 lanes) and the board/action loads of the FIRST half of the tile
+//   2. 64 (65) Philox blocks while those are in flight; words -> wave-private LDS strip -> registers
+//   3. issue the loads of the SECOND half (every wave has queued its first half by now, so the chip-wide
+//      load burst is served board-major); selector table -> LDS; LDS-only workgroup barrier
+//   4. wait for the first half (exact vmcnt: nothing but loads has been issued), compute it, results in
+//      registers; wait for the second half; store the first half; compute + store the second half
+//   5. queue terminal boards; the last wave of the block to finish rebuilds them (no second barrier)
 // EXTRAS: legal and/or obs requested.  FULL: every board of the block exists (no bounds checks);
-// RANDOM: actions come from the step words instead of memory.
+// RANDOM: actions come from the step words instead of memory.  Build-time knobs (defaults measured
+// best): ENV2048_BLOCK threads per block, ENV2048_BOARDS_PER_LANE; diagnostic builds
+// ENV2048_EXP_ABLATE (bit 0 no game logic, bit 1 no Philox, bit 2 no reward/done stores) and
+// ENV2048_EXP_STAMPS (s_memtime wave timeline into the obs buffer) exist for tools/microbench only.
 template <bool EXTRAS, bool FULL, bool RANDOM>
 __device__ __forceinline__ void step_block(const StepArgs &a, uint4 *dir_lds, uint32_t (*word_lds)[WORD_STRIP],
                                            uint32_t *reset_count, uint32_t *waves_finished, uint16_t *reset_slot)
