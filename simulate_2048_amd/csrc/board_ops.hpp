@@ -258,13 +258,18 @@ ENV2048_DEV uint32_t kth_empty(uint32_t m, uint32_t k)
     return m;
 }
 
-// OR (1 << shift) into the cell selected by a one-bit empty_mask (no-op for cell_bit == 0).
+// OR (1 << shift) into the cell selected by a one-bit empty_mask (no-op for cell_bit == 0); shift is 0
+// (tile 2) or 1 (tile 4).  The bit sits at 8c + 7 - r: moved down by (4 - shift) it lands on bit
+// `shift` of byte c for row 3, one/two/three places higher for rows 2/1/0, and since it is the only
+// bit set, masking with (0x01010101 << shift) after a constant shift isolates each row's share.
 ENV2048_DEV void place_tile(Board &bd, uint32_t cell_bit, uint32_t shift)
 {
-    bd.r0 |= ((cell_bit >> 7) & K01) << shift;
-    bd.r1 |= ((cell_bit >> 6) & K01) << shift;
-    bd.r2 |= ((cell_bit >> 5) & K01) << shift;
-    bd.r3 |= ((cell_bit >> 4) & K01) << shift;
+    const uint32_t lane_mask = K01 << shift;
+    const uint32_t t = cell_bit >> (4u - shift);
+    bd.r3 |= t & lane_mask;
+    bd.r2 |= (t >> 1) & lane_mask;
+    bd.r1 |= (t >> 2) & lane_mask;
+    bd.r0 |= (t >> 3) & lane_mask;
 }
 
 // Flat row-major index (4*r + c) of the cell a one-bit empty_mask selects.
