@@ -101,24 +101,33 @@ ENV2048_DEV uint32_t slide_merge_planes(uint32_t &a, uint32_t &b, uint32_t &c, u
 {
     uint32_t na = nz7(a), nb = nz7(b), nc = nz7(c), nd = nz7(d);
 
-    // 1) stable compaction toward plane a ("column[column != 0]", gameboard.py:46): a bubble
-    //    network of "pull the neighbour in if I am empty" steps; the non-zero masks ride along.
-#define ENV2048_PULL(pi, pj, ni, nj)       \
-    {                                      \
-        uint32_t moved = bsel(ni, pi, pj); \
-        pj &= ni;                          \
-        pi = moved;                        \
-        uint32_t any = ni | nj;            \
-        nj &= ni;                          \
-        ni = any;                          \
+    // 1) stable compaction toward plane a ("column[column != 0]", gameboard.py:46), in closed form:
+    //    output k is the k-th non-zero input.  Which input that is depends only on how many of the
+    //    inputs before it are non-zero, so each output is a masked OR of candidates; every mask is one
+    //    3-input boolean of the non-zero masks (v_bitop3_b32).  A zero candidate contributes nothing,
+    //    so "candidate is non-zero" never has to be tested.
+    {
+        const uint32_t both_ab = na & nb;                        // a and b occupied
+        const uint32_t one_ab = na ^ nb;                         // exactly one of a, b
+        const uint32_t one_abc = (na ^ nb ^ nc) & ~(na & nb & nc);        // exactly one of a, b, c
+        const uint32_t two_abc = (na & nb) ^ (na & nc) ^ (nb & nc) ^ (na & nb & nc);  // exactly two
+        const uint32_t all_abc = na & nb & nc;
+        const uint32_t oa = bsel(na, a, bsel(nb, b, bsel(nc, c, d)));   // first non-zero
+        const uint32_t ob = (b & both_ab) | (c & one_ab) | (d & one_abc);  // second
+        const uint32_t oc = (c & all_abc) | (d & two_abc);                  // third
+        const uint32_t od = d & all_abc;                                    // fourth
+        // occupancy of the compacted planes: at least 2 / 3 / 4 of the inputs are non-zero
+        const uint32_t n2 = both_ab | (one_ab & nc) | (one_abc & nd);
+        const uint32_t n3 = all_abc | (two_abc & nd);
+        const uint32_t n4 = all_abc & nd;
+        a = oa;
+        b = ob;
+        c = oc;
+        d = od;
+        nb = n2;
+        nc = n3;
+        nd = n4;
     }
-    ENV2048_PULL(a, b, na, nb)
-    ENV2048_PULL(b, c, nb, nc)
-    ENV2048_PULL(c, d, nc, nd)
-    ENV2048_PULL(a, b, na, nb)
-    ENV2048_PULL(b, c, nb, nc)
-    ENV2048_PULL(a, b, na, nb)
-#undef ENV2048_PULL
 
     // 2) greedy pairwise merge from the wall outward, each tile merging at most once
     //    (gameboard.py:56-67).  After compaction "b non-zero" implies "a non-zero", etc.
