@@ -9,6 +9,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "env2048.h"
 #include "board_ops.hpp"
@@ -28,9 +29,38 @@ __device__ __forceinline__ Board load_board(const uint8_t *boards, uint64_t i)
     return Board{v.x, v.y, v.z, v.w};
 }
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// Write-through (sc1) stores: the line is not left dirty in the XCD's L2, so the end-of-kernel L2
+// write-back -- which sits on the critical path of back-to-back step launches -- has nothing to do
+// (measured: -6 % per launch at 2^20 boards for the board stores alone, -12 % with reward/done).
+// Only WIDE sc1 stores are cheap: narrow ones (dword / byte per lane) are one fabric write each.
+// gfx9 hazard: a VMEM store of more than 64 bits must not be followed directly by a VALU write to its
+// data VGPRs (the data is read one cycle after issue).  hipcc inserts that wait state for stores it
+// emits itself but cannot see inside an asm statement, so it is part of the string (s_nop 1 = two
+// wait states).  Without it boards were corrupted -- only under memory back-pressure (2^20 boards).
+__device__ __forceinline__ void store_x4_through(void *ptr, u32x4 v)
+{
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store_x1_through(void *ptr, uint32_t v)
+{
+    asm volatile("global_store_dword %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory");
+}
+
 __device__ __forceinline__ void store_board(uint8_t *boards, uint64_t i, const Board &bd)
 {
     reinterpret_cast<uint4 *>(boards)[i] = make_uint4(bd.r0, bd.r1, bd.r2, bd.r3);
+}
+
+// Board store of the step kernel: write-through for launches small enough that the end-of-kernel L2
+// write-back matters, ordinary write-back stores for HBM-bound sizes (where sc1 measured 5 % slower).
+__device__ __forceinline__ void store_board(uint8_t *boards, uint64_t i, const Board &bd, bool through)
+{
+    if (through)
+        store_x4_through(reinterpret_cast<uint4 *>(boards) + i, u32x4{bd.r0, bd.r1, bd.r2, bd.r3});
+    else
+        store_board(boards, i, bd);
 }
 
 // log2(tile)/16 per cell [ref: reinforce/game/core.py:346-377 encode_observation]; exact in f32.
@@ -99,9 +129,12 @@ constexpr int WAVES_PER_BLOCK = BLOCK / 64;
 constexpr int BOARDS_PER_LANE = ENV2048_BOARDS_PER_LANE;
 constexpr int TILE_BOARDS = 64 * BOARDS_PER_LANE;                  // per wave
 constexpr int BLOCK_BOARDS = TILE_BOARDS * WAVES_PER_BLOCK;       // per block
-constexpr int WORD_STRIP = TILE_BOARDS + 4 + 4;                   // 65 Philox blocks (+ pad to 16 B)
+constexpr int WORD_STRIP = TILE_BOARDS + 4 + 4 + TILE_BOARDS / 4;  // 65 Philox blocks (+ pad to 16 B) + a byte per board
 
 __constant__ uint32_t DIR_TABLE[32] = {ENV2048_DIR_SELECTOR_VALUES};
+
+constexpr uint32_t INTERNAL_FLAG_WIDE_OUTPUTS = 0x80000000u;  // reward 16-B / done 4-B aligned: transposed wide stores
+constexpr uint32_t INTERNAL_FLAG_WRITE_THROUGH = 0x40000000u;  // sc1 stores (host decides by launch size)
 
 struct StepArgs {
     uint64_t n;
@@ -200,6 +233,9 @@ __device__ __forceinline__ void step_block(const StepArgs &a, uint4 *dir_lds, ui
     const uint64_t tile0 = block0 + (uint64_t)wave * TILE_BOARDS;
     const uint64_t env0 = a.env_base + tile0;
     const bool auto_reset = (a.flags & ENV2048_FLAG_AUTO_RESET) != 0u;
+    const bool through = (a.flags & INTERNAL_FLAG_WRITE_THROUGH) != 0u;
+    // the LDS transposition of reward/done only pays together with write-through stores (measured)
+    const bool wide_outputs = through && FULL && BOARDS_PER_LANE == 4 && (a.flags & INTERNAL_FLAG_WIDE_OUTPUTS) != 0u;
 
 #ifdef ENV2048_EXP_STAMPS  // diagnostic build: wave timeline stamps into the (otherwise unused) obs buffer
     uint64_t stamp0 = __builtin_amdgcn_s_memtime(), stamp1 = 0, stamp2 = 0;
@@ -284,16 +320,17 @@ __device__ __forceinline__ void step_block(const StepArgs &a, uint4 *dir_lds, ui
                 const uint32_t slot = atomicAdd(reset_count, 1u);
                 reset_slot[slot] = (uint16_t)(wave * TILE_BOARDS + 64u * j + lane);
             } else {
-                store_board(a.boards, i, bd[j]);
+                store_board(a.boards, i, bd[j], through);
                 if (EXTRAS && a.legal) a.legal[i] = (uint8_t)legal_mask(bd[j]);
                 if (EXTRAS && !FULL && a.obs) store_obs(a.obs, i, bd[j]);
             }
 #if defined(ENV2048_EXP_ABLATE) && (ENV2048_EXP_ABLATE & 4)  // timing-only build: no reward/done stores
             asm volatile("" ::"v"(reward[j]), "v"((uint32_t)done[j]));
 #else
-            // write-once outputs: streaming (nt) stores keep them from displacing the boards in cache
-            if (a.reward) __builtin_nontemporal_store((int32_t)reward[j], &a.reward[i]);
-            __builtin_nontemporal_store((uint8_t)(done[j] ? 1 : 0), &a.done[i]);
+            if (!wide_outputs) {  // narrow write-once outputs: streaming (nt) stores, not sc1 (see store_x4_through)
+                if (a.reward) __builtin_nontemporal_store((int32_t)reward[j], &a.reward[i]);
+                __builtin_nontemporal_store((uint8_t)(done[j] ? 1 : 0), &a.done[i]);
+            }
 #endif
         }
         if (EXTRAS && FULL && a.obs)  // (the step words were copied to registers: the strip is free)
@@ -314,6 +351,26 @@ __device__ __forceinline__ void step_block(const StepArgs &a, uint4 *dir_lds, ui
         compute(j);
         emit(j);
     }
+    // Wide write-once outputs: transpose the tile's 256 rewards / done bytes through the (now free) LDS
+    // strip so that lane l owns boards 4l..4l+3 and writes one dwordx4 (+ one dword) write-through.
+#if !(defined(ENV2048_EXP_ABLATE) && (ENV2048_EXP_ABLATE & 4))
+    if (wide_outputs) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint8_t *done_bytes = reinterpret_cast<uint8_t *>(strip + TILE_BOARDS + 8);
+#pragma unroll
+        for (int j = 0; j < BOARDS_PER_LANE; ++j) {
+            strip[64u * j + lane] = reward[j];
+            done_bytes[64u * j + lane] = done[j] ? 1 : 0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint4 r4 = reinterpret_cast<const uint4 *>(strip)[lane];
+        const uint32_t d4 = reinterpret_cast<const uint32_t *>(done_bytes)[lane];
+        if (a.reward) store_x4_through(a.reward + tile0 + 4u * lane, u32x4{r4.x, r4.y, r4.z, r4.w});
+        store_x1_through(a.done + tile0 + 4u * lane, d4);
+    }
+#endif
 #ifdef ENV2048_EXP_STAMPS
     stamp2 = __builtin_amdgcn_s_memtime();
     if (lane == 0u && a.obs) {
@@ -827,9 +884,16 @@ int env2048_step(int device, void *stream, uint64_t n, uint64_t env_base, uint8_
     if (int rc = check_count(n)) return rc;
     DeviceScope scope(device);
     if (scope.rc) return scope.rc;
+    uint32_t kernel_flags = flags;
+    if (!misaligned(reward, 16) && !misaligned(done, 4)) kernel_flags |= INTERNAL_FLAG_WIDE_OUTPUTS;
+    // Write-through stores win while boards + outputs of one launch stay within the 256 MiB Infinity Cache
+    // (measured 2^20..2^23 boards: -5..-13 %) and lose beyond it (2^24: +7 %).  ENV2048_THROUGH_LIMIT
+    // (boards per launch) overrides the crossover for tuning.
+    static const long through_limit = getenv("ENV2048_THROUGH_LIMIT") ? atol(getenv("ENV2048_THROUGH_LIMIT")) : (1L << 23);
+    if ((long)n <= through_limit) kernel_flags |= INTERNAL_FLAG_WRITE_THROUGH;
     StepArgs a{n, env_base, boards, actions, reward, done, legal, obs,
                RngKey{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)step_index, (uint32_t)(step_index >> 32)},
-               flags};
+               kernel_flags};
 #ifdef ENV2048_EXP_STAMPS
     const bool extras = false;
 #else

@@ -329,6 +329,7 @@ def test_full_size_slicing_invariance_and_rollout(lib):
     for t in range(T):
         mass_before = pow2[whole.long()].sum(dim=1)
         lib.step(DEV, stream(), FULL_N, 0, p(whole), None, p(reward), p(done), None, None, seed, t, flags)
+        assert int(whole.max()) < 32, 'corrupt board bytes'  # (before they are used as an index below)
         mass_after = pow2[whole.long()].sum(dim=1)
         grew = mass_after - mass_before
         live = done == 0
