@@ -83,7 +83,7 @@ __device__ __forceinline__ void store_obs(float *obs, uint64_t i, const Board &b
 // real row is 0xFFFFFFFF) and nothing is stored for their boards (they are rebuilt later by the
 // reset pass, possibly by another wave).  first = index of lane 0's board; boards >= n are skipped.
 __device__ __forceinline__ void store_obs_coalesced(float *obs, uint32_t *strip, uint64_t first, uint64_t n, uint32_t lane,
-                                                    const Board &bd, bool skip)
+                                                    const Board &bd, bool skip, bool through = false)
 {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // earlier reads of the strip are done
     __builtin_amdgcn_wave_barrier();
@@ -95,9 +95,15 @@ __device__ __forceinline__ void store_obs_coalesced(float *obs, uint32_t *strip,
     for (uint32_t k = 0; k < 4u; ++k) {
         const uint32_t x = strip[64u * k + lane];
         const uint64_t board = first + 16u * k + (lane >> 2);
-        if (x != ~0u && board < n)
-            out[64u * k + lane] = make_float4((float)(x & 0xFFu) * 0.0625f, (float)((x >> 8) & 0xFFu) * 0.0625f,
-                                              (float)((x >> 16) & 0xFFu) * 0.0625f, (float)(x >> 24) * 0.0625f);
+        if (x != ~0u && board < n) {
+            const float4 v = make_float4((float)(x & 0xFFu) * 0.0625f, (float)((x >> 8) & 0xFFu) * 0.0625f,
+                                         (float)((x >> 16) & 0xFFu) * 0.0625f, (float)(x >> 24) * 0.0625f);
+            if (through)
+                store_x4_through(out + 64u * k + lane, u32x4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z),
+                                                              __float_as_uint(v.w)});
+            else
+                out[64u * k + lane] = v;
+        }
     }
 }
 
@@ -334,7 +340,7 @@ __device__ __forceinline__ void step_block(const StepArgs &a, uint4 *dir_lds, ui
 #endif
         }
         if (EXTRAS && FULL && a.obs)  // (the step words were copied to registers: the strip is free)
-            store_obs_coalesced(a.obs, strip, tile0 + 64u * j, a.n, lane, bd[j], auto_reset && done[j]);
+            store_obs_coalesced(a.obs, strip, tile0 + 64u * j, a.n, lane, bd[j], auto_reset && done[j], through);
     };
 
     // first half: compute only -- its stores wait until the second half's loads are home, so that
