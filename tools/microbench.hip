@@ -90,6 +90,32 @@ __global__ __launch_bounds__(256) void k_memonly(Args a)
     a.done[i] = (uint8_t)(bd.r2 & 1);
 }
 
+// ---- memory-only floor with write-through (sc1) wide stores, 4 boards per lane like the product ------
+typedef unsigned int mb_u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(512) void k_memonly_sc1(Args a)
+{
+    const uint64_t lane_id = (uint64_t)blockIdx.x * 512 + threadIdx.x;
+    const uint64_t tile0 = (lane_id & ~63ull) * 4;
+    const uint32_t lane = threadIdx.x & 63u;
+    if (tile0 >= a.n) return;
+    uint4 v[4];
+    uint32_t act = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        v[j] = a.boards[tile0 + 64 * j + lane];
+        act ^= a.actions[tile0 + 64 * j + lane];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        mb_u32x4 w = {v[j].x ^ act, v[j].y, v[j].z, v[j].w};
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(a.boards + tile0 + 64 * j + lane), "v"(w) : "memory");
+    }
+    mb_u32x4 r = {v[0].y & 0xFF, v[1].y & 0xFF, v[2].y & 0xFF, v[3].y & 0xFF};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(a.reward + tile0 + 4 * lane), "v"(r) : "memory");
+    uint32_t d = (v[0].z & 1) | ((v[1].z & 1) << 8) | ((v[2].z & 1) << 16) | ((v[3].z & 1) << 24);
+    asm volatile("global_store_dword %0, %1, off sc1" ::"v"(a.done + tile0 + 4 * lane), "v"(d) : "memory");
+}
+
 // ---- no-Philox: cheap mixing instead of the 10-round generator (NOT the contract; cost probe) -
 __global__ __launch_bounds__(256) void k_nophilox(Args a)
 {
@@ -313,6 +339,7 @@ int main(int argc, char **argv)
     };
     const unsigned g256 = (unsigned)((n + 255) / 256);
     run("memonly", [&](int t) { hipLaunchKernelGGL(k_memonly, dim3(g256), dim3(256), 0, s, mk(t)); });
+    run("memonly_sc1_tile4", [&](int t) { hipLaunchKernelGGL(k_memonly_sc1, dim3((unsigned)((n / 4 + 511) / 512)), dim3(512), 0, s, mk(t)); });
     run("philoxonly", [&](int t) { hipLaunchKernelGGL(k_philoxonly, dim3(g256), dim3(256), 0, s, mk(t)); });
     run("nophilox", [&](int t) { hipLaunchKernelGGL(k_nophilox, dim3(g256), dim3(256), 0, s, mk(t)); });
     run("v1_b256", [&](int t) { hipLaunchKernelGGL(k_v1<256>, dim3(g256), dim3(256), 0, s, mk(t)); });
@@ -465,7 +492,7 @@ int main(int argc, char **argv)
     if (only) {
         std::vector<Variant> kept;
         for (auto &v : variants)
-            if (v.name.find(only) != std::string::npos || v.name == "memonly") kept.push_back(v);
+            if (v.name.find(only) != std::string::npos || v.name.find("memonly") == 0) kept.push_back(v);
         variants.swap(kept);
     }
     time_all(getenv("MB_ROUNDS") ? atoi(getenv("MB_ROUNDS")) : 7);
