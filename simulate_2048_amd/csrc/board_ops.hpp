@@ -21,7 +21,13 @@ static inline uint32_t emu_perm(uint32_t hi, uint32_t lo, uint32_t sel)
     uint32_t out = 0;
     for (int i = 0; i < 4; ++i) {
         const uint32_t s = (sel >> (8 * i)) & 0xFFu;
-        const uint32_t byte = s < 8 ? (uint32_t)((src >> (8 * s)) & 0xFFu) : (s == 0x0Cu ? 0u : 0xFFu);
+        uint32_t byte;
+        if (s < 8)
+            byte = (uint32_t)((src >> (8 * s)) & 0xFFu);
+        else if (s < 12)  // 8..11: the sign bit of source byte 1 / 3 / 5 / 7, replicated
+            byte = ((src >> (8 * (2 * (s - 8) + 1) + 7)) & 1u) ? 0xFFu : 0u;
+        else
+            byte = s == 12 ? 0u : 0xFFu;
         out |= byte << (8 * i);
     }
     return out;
@@ -31,6 +37,17 @@ static inline uint32_t emu_perm(uint32_t hi, uint32_t lo, uint32_t sel)
 #define ENV2048_POPC(x) ((uint32_t)__builtin_popcount(x))
 #define ENV2048_UMULHI(a, b) ((uint32_t)(((uint64_t)(a) * (uint64_t)(b)) >> 32))
 #define ENV2048_FFS(x) (__builtin_ffs((int)(x)))
+namespace env2048 {
+// v_bitop3_b32: bit t of `table` is the output for inputs (a, b, c) = (t >> 2 & 1, t >> 1 & 1, t & 1)
+static inline uint32_t emu_bitop3(uint32_t a, uint32_t b, uint32_t c, uint32_t table)
+{
+    uint32_t out = 0;
+    for (uint32_t t = 0; t < 8; ++t)
+        if ((table >> t) & 1u) out |= ((t & 4u) ? a : ~a) & ((t & 2u) ? b : ~b) & ((t & 1u) ? c : ~c);
+    return out;
+}
+}  // namespace env2048
+#define ENV2048_BITOP3(a, b, c, table) env2048::emu_bitop3(a, b, c, table)
 #else
 #include <hip/hip_runtime.h>
 #define ENV2048_DEV __device__ __forceinline__
@@ -38,13 +55,18 @@ static inline uint32_t emu_perm(uint32_t hi, uint32_t lo, uint32_t sel)
 #define ENV2048_POPC(x) ((uint32_t)__popc(x))
 #define ENV2048_UMULHI(a, b) __umulhi(a, b)
 #define ENV2048_FFS(x) (__ffs((int)(x)))
+// any 3-input boolean in one instruction; spelled out where hipcc does not find the fusion on its own
+#define ENV2048_BITOP3(a, b, c, table) __builtin_amdgcn_bitop3_b32(a, b, c, table)
 #endif
+#define ENV2048_XOR3(a, b, c) ENV2048_BITOP3(a, b, c, 0x96)
+#define ENV2048_BFI(m, a, b) ENV2048_BITOP3(a, b, m, 0xE4)  // (a & m) | (b & ~m)
 
 namespace env2048 {
 
 constexpr uint32_t K7F = 0x7F7F7F7Fu;
 constexpr uint32_t K80 = 0x80808080u;
 constexpr uint32_t K01 = 0x01010101u;
+constexpr uint32_t K1F = 0x1F1F1F1Fu;
 
 // P(tile 4) = 0.1 [ref: twentyfortyeight/core/gameboard.py:13,16-17] -> word < floor(0.1 * 2^32)
 constexpr uint32_t SPAWN4_THRESHOLD = 429496729u;
@@ -70,12 +92,46 @@ ENV2048_DEV uint32_t bsel(uint32_t m, uint32_t a, uint32_t b)
     return (a & m) | (b & ~m);
 }
 
-// 0x7F in every byte of x that is non-zero, 0x00 elsewhere.  Bytes must be <= 0x80 (exponents
-// are <= 31), so the per-byte add never carries into its neighbour.
-ENV2048_DEV uint32_t nz7(uint32_t x)
+// Bytes must be <= 0x80 (exponents are <= 31), so the per-byte add never carries into its neighbour.
+// 0xFF in every byte of x that is non-zero, 0x00 elsewhere (bytes <= 0x80 as above).  Three
+// instructions: the add puts "non-zero" into each byte's sign bit, and v_perm_b32's selectors 8..11
+// replicate the sign bits of the ODD source bytes -- the even ones come from a copy shifted by one byte.
+ENV2048_DEV uint32_t nzmask(uint32_t x)
 {
-    uint32_t f = (x + K7F) & K80;
-    return f - (f >> 7);
+    const uint32_t y = x + K7F;
+    return byte_perm(y << 8, y, 0x090B080Au);
+}
+
+// (a ^ b) + c in one v_xad_u32 (the compiler only finds it some of the time).
+ENV2048_DEV uint32_t xor_add(uint32_t a, uint32_t b, uint32_t c)
+{
+#if defined(ENV2048_HOST_EMULATION)
+    return (a ^ b) + c;
+#else
+    uint32_t r;
+    asm("v_xad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+#endif
+}
+
+// (byte J of value) << (byte J of amount): one SDWA shift, both operands byte-selected.
+template <int J>
+ENV2048_DEV uint32_t shl_byte(uint32_t value, uint32_t amount)
+{
+#if defined(ENV2048_HOST_EMULATION)
+    return ((value >> (8 * J)) & 0xFFu) << ((amount >> (8 * J)) & 31u);
+#else
+    uint32_t r;
+    if (J == 0)
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0" : "=v"(r) : "v"(amount), "v"(value));
+    else if (J == 1)
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_1" : "=v"(r) : "v"(amount), "v"(value));
+    else if (J == 2)
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:BYTE_2" : "=v"(r) : "v"(amount), "v"(value));
+    else
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_3" : "=v"(r) : "v"(amount), "v"(value));
+    return r;
+#endif
 }
 
 // 4x4 byte transpose: rows <-> columns.
@@ -97,9 +153,11 @@ ENV2048_DEV void transpose4x4(uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3
 // tile VALUES over the four lines).
 // [ref: twentyfortyeight/core/gameboard.py:23-69 merge_column, :72-102 slide_and_merge;
 //       reinforce/game/core.py:32-101 _compact_row/merge_row]
-ENV2048_DEV uint32_t slide_merge_planes(uint32_t &a, uint32_t &b, uint32_t &c, uint32_t &d)
+ENV2048_DEV uint32_t slide_merge_planes(uint32_t &a, uint32_t &b, uint32_t &c, uint32_t &d, uint32_t &changed_bits)
 {
-    uint32_t na = nz7(a), nb = nz7(b), nc = nz7(c), nd = nz7(d);
+    uint32_t na = nzmask(a), nb = nzmask(b), nc = nzmask(c), nd = nzmask(d);
+    // a tile moves iff some cell nearer the wall is empty: "empty before occupied" somewhere in the line
+    const uint32_t moved = (~na & (nb | nc | nd)) | (~nb & (nc | nd)) | (~nc & nd);
 
     // 1) stable compaction toward plane a ("column[column != 0]", gameboard.py:46), in closed form:
     //    output k is the k-th non-zero input.  Which input that is depends only on how many of the
@@ -131,9 +189,9 @@ ENV2048_DEV uint32_t slide_merge_planes(uint32_t &a, uint32_t &b, uint32_t &c, u
 
     // 2) greedy pairwise merge from the wall outward, each tile merging at most once
     //    (gameboard.py:56-67).  After compaction "b non-zero" implies "a non-zero", etc.
-    uint32_t m_ab = (nz7(a ^ b) ^ K7F) & nb;
-    uint32_t m_bc = (nz7(b ^ c) ^ K7F) & nc & ~m_ab;
-    uint32_t m_cd = (nz7(c ^ d) ^ K7F) & nd & ~m_bc;
+    uint32_t m_ab = ~nzmask(a ^ b) & nb;
+    uint32_t m_bc = ~nzmask(b ^ c) & nc & ~m_ab;
+    uint32_t m_cd = ~nzmask(c ^ d) & nd & ~m_bc;
     uint32_t x_ab = m_ab & K01, x_bc = m_bc & K01, x_cd = m_cd & K01;
     uint32_t a1 = a + x_ab;  // merged tile: value * 2 == exponent + 1
     uint32_t b1 = b + x_bc;
@@ -148,20 +206,14 @@ ENV2048_DEV uint32_t slide_merge_planes(uint32_t &a, uint32_t &b, uint32_t &c, u
     b = bsel(m_ab, c1, b1);
     c = bsel(s2, d1, c1);
     d = d1 & ~s2;
+    changed_bits = moved | s2 | m_cd;
 
     // score = sum over merged cells of 2^exponent: shift the 0/1 merge flag of each byte lane by
     // that lane's merged exponent (one SDWA v_lshlrev per byte: both operands byte-selected), so
     // lanes without a merge contribute 0.
     const uint32_t f1 = x_ab | x_bc, f2 = x_cd;
-    uint32_t s = (f1 & 0xFFu) << (v1 & 0xFFu);
-    s += ((f1 >> 8) & 0xFFu) << ((v1 >> 8) & 0xFFu);
-    s += ((f1 >> 16) & 0xFFu) << ((v1 >> 16) & 0xFFu);
-    s += (f1 >> 24) << (v1 >> 24);
-    s += (f2 & 0xFFu) << (v2 & 0xFFu);
-    s += ((f2 >> 8) & 0xFFu) << ((v2 >> 8) & 0xFFu);
-    s += ((f2 >> 16) & 0xFFu) << ((v2 >> 16) & 0xFFu);
-    s += (f2 >> 24) << (v2 >> 24);
-    return s;
+    return (shl_byte<0>(f1, v1) + shl_byte<1>(f1, v1) + shl_byte<2>(f1, v1)) +
+           (shl_byte<3>(f1, v1) + shl_byte<0>(f2, v2) + shl_byte<1>(f2, v2)) + (shl_byte<2>(f2, v2) + shl_byte<3>(f2, v2));
 }
 
 // Afterstate of one move, no spawn [ref: gameboard.py:105-129 latent_state; directions pinned by
@@ -183,9 +235,9 @@ ENV2048_DEV void afterstate(Board &bd, uint32_t action, uint32_t &score, bool &c
     uint32_t p1 = reversed ? x2 : x1;
     uint32_t p2 = reversed ? x1 : x2;
     uint32_t p3 = reversed ? x0 : x3;
-    uint32_t q0 = p0, q1 = p1, q2 = p2, q3 = p3;
-    score = slide_merge_planes(q0, q1, q2, q3);
-    changed = (((q0 ^ p0) | (q1 ^ p1)) | ((q2 ^ p2) | (q3 ^ p3))) != 0u;
+    uint32_t q0 = p0, q1 = p1, q2 = p2, q3 = p3, changed_bits;
+    score = slide_merge_planes(q0, q1, q2, q3, changed_bits);
+    changed = changed_bits != 0u;
     uint32_t y0 = reversed ? q3 : q0;
     uint32_t y1 = reversed ? q2 : q1;
     uint32_t y2 = reversed ? q1 : q2;
@@ -224,9 +276,9 @@ ENV2048_DEV void afterstate_sel(Board &bd, const DirSelectors &s, uint32_t &scor
     uint32_t t1 = byte_perm(bd.r1, bd.r0, s.fB), t3 = byte_perm(bd.r3, bd.r2, s.fB);
     const uint32_t p0 = byte_perm(t2, t0, s.fC), p2 = byte_perm(t2, t0, s.fD);
     const uint32_t p1 = byte_perm(t3, t1, s.fC), p3 = byte_perm(t3, t1, s.fD);
-    uint32_t q0 = p0, q1 = p1, q2 = p2, q3 = p3;
-    score = slide_merge_planes(q0, q1, q2, q3);
-    changed = (((q0 ^ p0) | (q1 ^ p1)) | ((q2 ^ p2) | (q3 ^ p3))) != 0u;
+    uint32_t q0 = p0, q1 = p1, q2 = p2, q3 = p3, changed_bits;
+    score = slide_merge_planes(q0, q1, q2, q3, changed_bits);
+    changed = changed_bits != 0u;
     t0 = byte_perm(q1, q0, s.iA);
     t2 = byte_perm(q3, q2, s.iA);
     t1 = byte_perm(q1, q0, s.iB);
@@ -237,55 +289,81 @@ ENV2048_DEV void afterstate_sel(Board &bd, const DirSelectors &s, uint32_t &scor
     bd.r3 = byte_perm(t3, t1, s.iD);
 }
 
-// Bit (8*c + 7 - r) set <=> cell (r, c) is EMPTY.
-ENV2048_DEV uint32_t empty_mask(const Board &bd)
+// Cell masks: one bit per cell, cell (r, c) at bit 8*c + CELL_ROW_BIT[r] with CELL_ROW_BIT = {5, 6, 7, 4}
+// (the layout the cheapest construction below produces).  Bytes of the board must be <= 31.
+constexpr uint32_t CELL_BITS = 0xF0F0F0F0u;
+constexpr uint32_t CELL_ROWS_01 = 0x60606060u;  // rows 0 and 1
+constexpr uint32_t CELL_ROWS_02 = 0xA0A0A0A0u;  // rows 0 and 2
+constexpr uint32_t CELL_COLS_01 = 0x0000F0F0u;  // columns 0 and 1
+constexpr uint32_t CELL_COLS_02 = 0x00F000F0u;  // columns 0 and 2
+
+// Occupancy in the cell-mask layout, with JUNK in the low nibble of every byte: value + 0x1F sets bit 5
+// of a byte iff the value is non-zero and never reaches bit 6, so shifted copies (v_add_lshl_u32) drop
+// each row's flag onto its own bit and three v_bfi_b32 collect them.
+ENV2048_DEV uint32_t occupied_cells_dirty(const Board &bd)
 {
-    uint32_t y0 = bd.r0 + K7F, y1 = bd.r1 + K7F, y2 = bd.r2 + K7F, y3 = bd.r3 + K7F;
-    uint32_t occ = (y0 & 0x80808080u) | ((y1 >> 1) & 0x40404040u) | ((y2 >> 2) & 0x20202020u) |
-                   ((y3 >> 3) & 0x10101010u);
-    return occ ^ 0xF0F0F0F0u;
+    const uint32_t f0 = bd.r0 + K1F;          // flag at bit 5
+    const uint32_t f1 = (bd.r1 + K1F) << 1;   // bit 6
+    const uint32_t f2 = (bd.r2 + K1F) << 2;   // bit 7
+    const uint32_t f3 = (bd.r3 + K1F) >> 1;   // bit 4 (bit 7 receives junk from the next byte: never selected)
+    return ENV2048_BFI(0x20202020u, f0, ENV2048_BFI(0x40404040u, f1, ENV2048_BFI(0x80808080u, f2, f3)));
 }
 
-// Keep only the k-th set bit of an empty_mask, counting cells in row-major order -- the order of
+// Cell mask of the EMPTY cells.
+ENV2048_DEV uint32_t empty_mask(const Board &bd) { return ~occupied_cells_dirty(bd) & CELL_BITS; }
+
+// Keep only the k-th set bit of a cell mask, counting cells in row-major order -- the order of
 // argwhere(state == 0) [ref: gameboard.py:275,287; reinforce/game/core.py:206-213].  Four rounds
 // of "is it in the first half of what is left?" (rows 0-1 | row 0/2 | columns 0-1 | column 0/2).
+// The rank is carried as j = ~k: popc(first half) + j = cnt - k - 1 comes out of v_bcnt_u32_b32 itself, is
+// negative iff the cell lies beyond the first half, and is then already the new ~k (k - cnt); as
+// unsigned numbers the right one of {j, cnt - k - 1} is always the larger.  5 instructions per round.
 ENV2048_DEV uint32_t kth_empty(uint32_t m, uint32_t k)
 {
-#define ENV2048_HALVE(FIRST)                \
-    {                                       \
-        uint32_t lo = m & (FIRST);          \
-        uint32_t cnt = ENV2048_POPC(lo);          \
-        bool beyond = k >= cnt;             \
-        m = beyond ? (m ^ lo) : lo;         \
-        k = beyond ? k - cnt : k;           \
+    uint32_t j = ~k;
+#define ENV2048_HALVE(FIRST, LAST)                                                               \
+    {                                                                                            \
+        const uint32_t t = ENV2048_POPC(m & (FIRST)) + j;                                        \
+        const uint32_t beyond = (uint32_t)((int32_t)t >> 31);                                    \
+        m = ENV2048_BITOP3(m, (FIRST), beyond, 0x60); /* m & (FIRST ^ beyond) */                 \
+        if (!(LAST)) j = t > j ? t : j;                                                          \
     }
-    ENV2048_HALVE(0xC0C0C0C0u)
-    ENV2048_HALVE(0xA0A0A0A0u)
-    ENV2048_HALVE(0x0000FFFFu)
-    ENV2048_HALVE(0x00FF00FFu)
+    ENV2048_HALVE(CELL_ROWS_01, false)
+    ENV2048_HALVE(CELL_ROWS_02, false)
+    ENV2048_HALVE(CELL_COLS_01, false)
+    ENV2048_HALVE(CELL_COLS_02, true)
 #undef ENV2048_HALVE
     return m;
 }
 
-// OR (1 << shift) into the cell selected by a one-bit empty_mask (no-op for cell_bit == 0); shift is 0
-// (tile 2) or 1 (tile 4).  The bit sits at 8c + 7 - r: moved down by (4 - shift) it lands on bit
-// `shift` of byte c for row 3, one/two/three places higher for rows 2/1/0, and since it is the only
-// bit set, masking with (0x01010101 << shift) after a constant shift isolates each row's share.
-ENV2048_DEV void place_tile(Board &bd, uint32_t cell_bit, uint32_t shift)
+// Spread a one-bit cell mask into per-row planes: bit 0 of byte c of p_r set iff the cell is (r, c).
+ENV2048_DEV void cell_planes(uint32_t cell_bit, uint32_t &p0, uint32_t &p1, uint32_t &p2, uint32_t &p3)
 {
-    const uint32_t lane_mask = K01 << shift;
-    const uint32_t t = cell_bit >> (4u - shift);
-    bd.r3 |= t & lane_mask;
-    bd.r2 |= (t >> 1) & lane_mask;
-    bd.r1 |= (t >> 2) & lane_mask;
-    bd.r0 |= (t >> 3) & lane_mask;
+    p0 = (cell_bit >> 5) & K01;
+    p1 = (cell_bit >> 6) & K01;
+    p2 = (cell_bit >> 7) & K01;
+    p3 = (cell_bit >> 4) & K01;
 }
 
-// Flat row-major index (4*r + c) of the cell a one-bit empty_mask selects.
+// OR a new tile into the cell selected by a one-bit cell mask (no-op for cell_bit == 0): tile 4
+// (exponent 2) if `four`, else tile 2 (exponent 1).  Moved down by 4 (tile 2) or 3 (tile 4) places, the
+// bit lands on bit 0 / bit 1 of its byte for row 3 and one/two/three places higher for rows 0/1/2;
+// being the only bit set, a constant shift and the byte-lane mask isolate each row's share.
+ENV2048_DEV void place_tile(Board &bd, uint32_t cell_bit, bool four)
+{
+    const uint32_t lane_mask = four ? 0x02020202u : K01;
+    const uint32_t t = cell_bit >> (four ? 3u : 4u);
+    bd.r3 |= t & lane_mask;
+    bd.r0 |= (t >> 1) & lane_mask;
+    bd.r1 |= (t >> 2) & lane_mask;
+    bd.r2 |= (t >> 3) & lane_mask;
+}
+
+// Flat row-major index (4*r + c) of the cell a one-bit cell mask selects.
 ENV2048_DEV uint32_t cell_index(uint32_t cell_bit)
 {
-    uint32_t pos = (uint32_t)ENV2048_FFS(cell_bit) - 1u;  // 8*c + 7 - r
-    return 4u * (7u - (pos & 7u)) + (pos >> 3);
+    const uint32_t pos = (uint32_t)ENV2048_FFS(cell_bit) - 1u;  // 8*c + {5, 6, 7, 4}[r]
+    return 4u * ((pos - 5u) & 3u) + (pos >> 3);
 }
 
 ENV2048_DEV uint32_t mulhi32(uint32_t a, uint32_t b) { return ENV2048_UMULHI(a, b); }
@@ -300,7 +378,7 @@ ENV2048_DEV uint32_t spawn_tile(Board &bd, uint32_t w_cell, uint32_t w_val, bool
     uint32_t k = mulhi32(w_cell, n_empty);
     uint32_t bit = kth_empty(empt, k);
     bit = enable ? bit : 0u;
-    place_tile(bd, bit, (w_val < SPAWN4_THRESHOLD) ? 1u : 0u);
+    place_tile(bd, bit, w_val < SPAWN4_THRESHOLD);
     return n_empty - (enable ? 1u : 0u);  // empties left on the board
 }
 
@@ -315,7 +393,7 @@ ENV2048_DEV uint32_t spawn_tile_word(Board &bd, uint32_t w, bool enable)
     const uint64_t prod = (uint64_t)(w & ~3u) * (uint64_t)n_empty;
     uint32_t bit = kth_empty(empt, (uint32_t)(prod >> 32));
     bit = enable ? bit : 0u;
-    place_tile(bd, bit, ((uint32_t)prod < SPAWN4_THRESHOLD) ? 1u : 0u);
+    place_tile(bd, bit, (uint32_t)prod < SPAWN4_THRESHOLD);
     return n_empty - (enable ? 1u : 0u);  // empties left on the board
 }
 
@@ -341,10 +419,12 @@ ENV2048_DEV Board fresh_board(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3
 // terminal test together with "board is full" [ref: gameboard.py:346-348 is_done].
 ENV2048_DEV bool no_equal_neighbours(const Board &bd)
 {
-    // bit 7 of a byte of (x + K7F) is set iff that byte of x is non-zero, i.e. the pair differs
-    uint32_t h = ((bd.r0 ^ (bd.r0 >> 8)) + K7F) & ((bd.r1 ^ (bd.r1 >> 8)) + K7F) &
-                 ((bd.r2 ^ (bd.r2 >> 8)) + K7F) & ((bd.r3 ^ (bd.r3 >> 8)) + K7F);
-    uint32_t v = ((bd.r0 ^ bd.r1) + K7F) & ((bd.r1 ^ bd.r2) + K7F) & ((bd.r2 ^ bd.r3) + K7F);
+    // bit 7 of a byte of ((x ^ y) + K7F) is set iff that byte of x and y differs
+    const uint32_t h0 = xor_add(bd.r0, bd.r0 >> 8, K7F), h1 = xor_add(bd.r1, bd.r1 >> 8, K7F);
+    const uint32_t h2 = xor_add(bd.r2, bd.r2 >> 8, K7F), h3 = xor_add(bd.r3, bd.r3 >> 8, K7F);
+    const uint32_t v0 = xor_add(bd.r0, bd.r1, K7F), v1 = xor_add(bd.r1, bd.r2, K7F), v2 = xor_add(bd.r2, bd.r3, K7F);
+    const uint32_t h = (h0 & h1 & h2) & h3;
+    const uint32_t v = v0 & v1 & v2;
     // byte 3 of h compares column 3 with nothing: ignore it
     return (((h | 0x80000000u) & v) & K80) == K80;
 }
@@ -401,9 +481,9 @@ ENV2048_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c
         uint32_t hi0, lo0, hi1, lo1;
         mul_wide(PHILOX_M0, c0, hi0, lo0);
         mul_wide(PHILOX_M1, c2, hi1, lo1);
-        c0 = hi1 ^ c1 ^ k0;
+        c0 = ENV2048_XOR3(hi1, c1, k0);
         c1 = lo1;
-        c2 = hi0 ^ c3 ^ k1;
+        c2 = ENV2048_XOR3(hi0, c3, k1);
         c3 = lo0;
         k0 += PHILOX_W0;
         k1 += PHILOX_W1;

@@ -244,7 +244,7 @@ __device__ __forceinline__ void step_block(const StepArgs &a, uint4 *dir_lds, ui
     const bool wide_outputs = through && FULL && BOARDS_PER_LANE == 4 && (a.flags & INTERNAL_FLAG_WIDE_OUTPUTS) != 0u;
 
 #ifdef ENV2048_EXP_STAMPS  // diagnostic build: wave timeline stamps into the (otherwise unused) obs buffer
-    uint64_t stamp0 = __builtin_amdgcn_s_memtime(), stamp1 = 0, stamp2 = 0;
+    uint64_t stamp0 = __builtin_amdgcn_s_memrealtime(), stamp1 = 0, stamp2 = 0, stamp3 = 0, stamp4 = 0;
 #endif
     // 1. loads of the FIRST half of the tile (boards 0,1) -- and the selector table
     uint4 table_row = make_uint4(0u, 0u, 0u, 0u);
@@ -298,7 +298,7 @@ __device__ __forceinline__ void step_block(const StepArgs &a, uint4 *dir_lds, ui
     else
         ENV2048_WAIT_ALL_VMEM();
 #ifdef ENV2048_EXP_STAMPS
-    stamp1 = __builtin_amdgcn_s_memtime();
+    stamp1 = __builtin_amdgcn_s_memrealtime();
 #endif
     // fetch the selector records of all boards now: one LDS round trip instead of one per board
     DirSelectors sel[BOARDS_PER_LANE];
@@ -347,7 +347,14 @@ __device__ __forceinline__ void step_block(const StepArgs &a, uint4 *dir_lds, ui
     // no vmcnt wait ever has a store (whose ack takes a memory round trip) in front of it
 #pragma unroll
     for (int j = 0; j < HALF; ++j) compute(j);
+#ifdef ENV2048_EXP_STAMPS
+    asm volatile("" ::"v"(bd[0].r0), "v"(bd[HALF - 1].r3), "v"(reward[0]), "v"(reward[HALF - 1]));
+    stamp3 = __builtin_amdgcn_s_memrealtime();
+#endif
     ENV2048_WAIT_ALL_VMEM();
+#ifdef ENV2048_EXP_STAMPS
+    stamp4 = __builtin_amdgcn_s_memrealtime();
+#endif
 #pragma unroll
     for (int j = HALF; j < BOARDS_PER_LANE; ++j) sel[j] = load_selectors(dir_lds, (RANDOM ? word[j] : act[j]) & 3u);
 #pragma unroll
@@ -378,13 +385,19 @@ __device__ __forceinline__ void step_block(const StepArgs &a, uint4 *dir_lds, ui
     }
 #endif
 #ifdef ENV2048_EXP_STAMPS
-    stamp2 = __builtin_amdgcn_s_memtime();
+    stamp2 = __builtin_amdgcn_s_memrealtime();
     if (lane == 0u && a.obs) {
-        uint64_t *out = reinterpret_cast<uint64_t *>(a.obs) + 4 * ((uint64_t)blockIdx.x * WAVES_PER_BLOCK + wave);
+        uint64_t *out = reinterpret_cast<uint64_t *>(a.obs) + 8 * ((uint64_t)blockIdx.x * WAVES_PER_BLOCK + wave);
         out[0] = stamp0;
         out[1] = stamp1;
-        out[2] = stamp2;
-        out[3] = __builtin_amdgcn_s_memrealtime();
+        out[2] = stamp3;
+        out[3] = stamp4;
+        out[4] = stamp2;
+        uint32_t hw_id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+        uint32_t xcc_id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+        out[5] = ((uint64_t)xcc_id << 32) | hw_id;
     }
 #endif
 
@@ -609,10 +622,12 @@ __global__ __launch_bounds__(BLOCK) void spawn_kernel(uint64_t n, uint8_t *board
     const uint32_t bit = ok ? kth_empty(empt, k) : 0u;
     const uint32_t e = spawn_e[i];
     // general exponent (not only 1/2): OR the byte value into the selected (empty) cell
-    bd.r0 |= ((bit >> 7) & K01) * e;
-    bd.r1 |= ((bit >> 6) & K01) * e;
-    bd.r2 |= ((bit >> 5) & K01) * e;
-    bd.r3 |= ((bit >> 4) & K01) * e;
+    uint32_t p0, p1, p2, p3;
+    cell_planes(bit, p0, p1, p2, p3);
+    bd.r0 |= p0 * e;
+    bd.r1 |= p1 * e;
+    bd.r2 |= p2 * e;
+    bd.r3 |= p3 * e;
     store_board(boards, i, bd);
     if (placed) placed[i] = ok ? (uint8_t)cell_index(bit) : (uint8_t)0xFF;
 }
@@ -657,7 +672,7 @@ __global__ __launch_bounds__(BLOCK) void chance_outcomes_kernel(uint64_t n, cons
         prob = slot == 0u ? 1.0f : 0.0f;  // [ref gameboard.py:156-157] full board: itself, probability 1
         if (slot != 0u) bd = Board{0u, 0u, 0u, 0u};
     } else if (k < n_empty) {
-        place_tile(bd, kth_empty(empt, k), slot & 1u);
+        place_tile(bd, kth_empty(empt, k), (slot & 1u) != 0u);
         prob = ((slot & 1u) ? 0.1f : 0.9f) / (float)n_empty;
     } else {
         bd = Board{0u, 0u, 0u, 0u};

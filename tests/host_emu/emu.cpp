@@ -110,10 +110,12 @@ void emu_spawn(uint64_t n, uint8_t *boards, const uint8_t *k, const uint8_t *e, 
         const uint32_t empt = empty_mask(b);
         const bool ok = k[i] < ENV2048_POPC(empt);
         const uint32_t bit = ok ? kth_empty(empt, k[i]) : 0u;
-        b.r0 |= ((bit >> 7) & K01) * e[i];
-        b.r1 |= ((bit >> 6) & K01) * e[i];
-        b.r2 |= ((bit >> 5) & K01) * e[i];
-        b.r3 |= ((bit >> 4) & K01) * e[i];
+        uint32_t p0, p1, p2, p3;
+        cell_planes(bit, p0, p1, p2, p3);
+        b.r0 |= p0 * e[i];
+        b.r1 |= p1 * e[i];
+        b.r2 |= p2 * e[i];
+        b.r3 |= p3 * e[i];
         store(boards + 16 * i, b);
         placed[i] = ok ? (uint8_t)cell_index(bit) : (uint8_t)0xFF;
     }

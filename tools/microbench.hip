@@ -436,28 +436,48 @@ int main(int argc, char **argv)
         step_fn_t fn = (step_fn_t)dlsym(h, "env2048_step");
         const uint64_t n_waves = n / 256;
         uint64_t *stamps;
-        CHECK(hipMalloc(&stamps, n_waves * 32));
-        for (int t = 0; t < 200; ++t)
+        CHECK(hipMalloc(&stamps, n_waves * 64));
+        hipEvent_t e0, e1;
+        CHECK(hipEventCreate(&e0));
+        CHECK(hipEventCreate(&e1));
+        for (int t = 0; t < 200; ++t) {
+            if (t == 199) CHECK(hipEventRecord(e0, s));
             fn(0, s, n, 0, (uint8_t *)boards, actions + (uint64_t)(t & 7) * n, reward, done, nullptr, (float *)stamps, 0x2048, t, 1);
-        CHECK(hipStreamSynchronize(s));
-        std::vector<uint64_t> hst(n_waves * 4);
-        CHECK(hipMemcpy(hst.data(), stamps, n_waves * 32, hipMemcpyDeviceToHost));
-        uint64_t t0 = ~0ull, r0 = ~0ull, r1 = 0;
-        for (uint64_t w = 0; w < n_waves; ++w) { t0 = std::min(t0, hst[4 * w]); r0 = std::min(r0, hst[4 * w + 3]); r1 = std::max(r1, hst[4 * w + 3]); }
-        std::vector<double> start, loaded, end, wait, comp;
-        for (uint64_t w = 0; w < n_waves; ++w) {
-            start.push_back((double)(hst[4 * w] - t0));
-            loaded.push_back((double)(hst[4 * w + 1] - t0));
-            end.push_back((double)(hst[4 * w + 2] - t0));
-            wait.push_back((double)(hst[4 * w + 1] - hst[4 * w]));
-            comp.push_back((double)(hst[4 * w + 2] - hst[4 * w + 1]));
         }
+        CHECK(hipEventRecord(e1, s));
+        CHECK(hipStreamSynchronize(s));
+        float last_ms = 0;
+        CHECK(hipEventElapsedTime(&last_ms, e0, e1));
+        std::vector<uint64_t> hst(n_waves * 8);
+        CHECK(hipMemcpy(hst.data(), stamps, n_waves * 64, hipMemcpyDeviceToHost));
+        // all stamps are s_memrealtime ticks (100 MHz, chip-global): 0.01 us each
+        uint64_t t0 = ~0ull;
+        for (uint64_t w = 0; w < n_waves; ++w) t0 = std::min(t0, hst[8 * w]);
+        const char *names[5] = {"wave start", "half-1 home", "half-1 done", "half-2 home", "wave end"};
         auto pct = [](std::vector<double> v, double p) { std::sort(v.begin(), v.end()); return v[(size_t)(p * (v.size() - 1))]; };
-        printf("stamps in shader cycles (s_memtime); realtime span of end stamps: %.2f us (100 MHz ticks)\n", (r1 - r0) / 100.0);
-        for (auto pr : {std::make_pair("wave start", &start), std::make_pair("loads home", &loaded), std::make_pair("wave end", &end),
-                        std::make_pair("start->loads", &wait), std::make_pair("loads->end", &comp)})
-            printf("  %-14s p0 %8.0f  p10 %8.0f  p50 %8.0f  p90 %8.0f  p100 %8.0f\n", pr.first, pct(*pr.second, 0), pct(*pr.second, .1),
-                   pct(*pr.second, .5), pct(*pr.second, .9), pct(*pr.second, 1));
+        printf("last launch by events: %.2f us; stamps in us since the first wave start\n", last_ms * 1e3);
+        for (int k = 0; k < 5; ++k) {
+            std::vector<double> v;
+            for (uint64_t w = 0; w < n_waves; ++w) v.push_back((double)(hst[8 * w + k] - t0) / 100.0);
+            printf("  %-12s p0 %6.2f  p10 %6.2f  p25 %6.2f  p50 %6.2f  p75 %6.2f  p90 %6.2f  p100 %6.2f\n", names[k], pct(v, 0), pct(v, .1),
+                   pct(v, .25), pct(v, .5), pct(v, .75), pct(v, .9), pct(v, 1));
+        }
+        const char *dnames[4] = {"start->h1home", "h1 compute", "wait h2", "h2+stores"};
+        for (int k = 0; k < 4; ++k) {
+            std::vector<double> v;
+            for (uint64_t w = 0; w < n_waves; ++w) v.push_back((double)(hst[8 * w + k + 1] - hst[8 * w + k]) / 100.0);
+            printf("  %-12s p0 %6.2f  p10 %6.2f  p25 %6.2f  p50 %6.2f  p75 %6.2f  p90 %6.2f  p100 %6.2f\n", dnames[k], pct(v, 0), pct(v, .1),
+                   pct(v, .25), pct(v, .5), pct(v, .75), pct(v, .9), pct(v, 1));
+        }
+        if (getenv("MB_STAMPS_DUMP")) {  // one SIMD's waves: hw_id fields
+            FILE *f = fopen(getenv("MB_STAMPS_DUMP"), "w");
+            for (uint64_t w = 0; w < n_waves; ++w)
+                fprintf(f, "%llu %llu %llu %llu %llu %llu 0x%llx\n", (unsigned long long)w, (unsigned long long)(hst[8 * w] - t0),
+                        (unsigned long long)(hst[8 * w + 1] - t0), (unsigned long long)(hst[8 * w + 2] - t0),
+                        (unsigned long long)(hst[8 * w + 3] - t0), (unsigned long long)(hst[8 * w + 4] - t0),
+                        (unsigned long long)hst[8 * w + 5]);
+            fclose(f);
+        }
         return 0;
     }
 

@@ -17,9 +17,9 @@ __device__ __forceinline__ void afterstate_sel4(Board &bd, const uint4 &f, const
     uint32_t t1 = byte_perm(bd.r1, bd.r0, f.y), t3 = byte_perm(bd.r3, bd.r2, f.y);
     uint32_t p0 = byte_perm(t2, t0, f.z), p2 = byte_perm(t2, t0, f.w);
     uint32_t p1 = byte_perm(t3, t1, f.z), p3 = byte_perm(t3, t1, f.w);
-    uint32_t q0 = p0, q1 = p1, q2 = p2, q3 = p3;
-    score = slide_merge_planes(q0, q1, q2, q3);
-    changed = (((q0 ^ p0) | (q1 ^ p1)) | ((q2 ^ p2) | (q3 ^ p3))) != 0u;
+    uint32_t q0 = p0, q1 = p1, q2 = p2, q3 = p3, changed_bits;
+    score = slide_merge_planes(q0, q1, q2, q3, changed_bits);
+    changed = changed_bits != 0u;
     t0 = byte_perm(q1, q0, inv.x); t2 = byte_perm(q3, q2, inv.x);
     t1 = byte_perm(q1, q0, inv.y); t3 = byte_perm(q3, q2, inv.y);
     bd.r0 = byte_perm(t2, t0, inv.z); bd.r2 = byte_perm(t2, t0, inv.w);
@@ -34,7 +34,7 @@ __device__ __forceinline__ uint32_t spawn_tile1(Board &bd, uint32_t w, bool enab
     uint64_t prod = (uint64_t)(w & ~3u) * n_empty;
     uint32_t bit = kth_empty(empt, (uint32_t)(prod >> 32));
     bit = enable ? bit : 0u;
-    place_tile(bd, bit, ((uint32_t)prod < SPAWN4_THRESHOLD) ? 1u : 0u);
+    place_tile(bd, bit, (uint32_t)prod < SPAWN4_THRESHOLD);
     return n_empty - (enable ? 1u : 0u);
 }
 
