@@ -114,6 +114,23 @@ ENV2048_DEV uint32_t xor_add(uint32_t a, uint32_t b, uint32_t c)
 #endif
 }
 
+// (x + c) << SH in one v_add_lshl_u32 with the constant in an SGPR (left alone, hipcc folds the shift into the
+// constant and re-materialises that in a VGPR for every board).
+template <int SH>
+ENV2048_DEV uint32_t add_shl(uint32_t x, uint32_t c)
+{
+#if defined(ENV2048_HOST_EMULATION)
+    return (x + c) << SH;
+#else
+    uint32_t r;
+    asm("v_add_lshl_u32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(c), "n"(SH));
+    return r;
+#endif
+}
+
+// (a & b) | c -- v_and_or_b32 semantics, spelled as a bitop3 so that it is always ONE instruction.
+#define ENV2048_AND_OR(a, b, c) ENV2048_BITOP3(a, b, c, 0xEA)
+
 // (byte J of value) << (byte J of amount): one SDWA shift, both operands byte-selected.
 template <int J>
 ENV2048_DEV uint32_t shl_byte(uint32_t value, uint32_t amount)
@@ -156,8 +173,8 @@ ENV2048_DEV void transpose4x4(uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3
 ENV2048_DEV uint32_t slide_merge_planes(uint32_t &a, uint32_t &b, uint32_t &c, uint32_t &d, uint32_t &changed_bits)
 {
     uint32_t na = nzmask(a), nb = nzmask(b), nc = nzmask(c), nd = nzmask(d);
-    // a tile moves iff some cell nearer the wall is empty: "empty before occupied" somewhere in the line
-    const uint32_t moved = (~na & (nb | nc | nd)) | (~nb & (nc | nd)) | (~nc & nd);
+    // a tile moves iff an empty cell sits directly before an occupied one somewhere in the line
+    const uint32_t moved = ENV2048_BITOP3(ENV2048_BITOP3(na, nb, nc, 0x2E), nd, nc, 0xF4);
 
     // 1) stable compaction toward plane a ("column[column != 0]", gameboard.py:46), in closed form:
     //    output k is the k-th non-zero input.  Which input that is depends only on how many of the
@@ -302,9 +319,9 @@ constexpr uint32_t CELL_COLS_02 = 0x00F000F0u;  // columns 0 and 2
 // each row's flag onto its own bit and three v_bfi_b32 collect them.
 ENV2048_DEV uint32_t occupied_cells_dirty(const Board &bd)
 {
-    const uint32_t f0 = bd.r0 + K1F;          // flag at bit 5
-    const uint32_t f1 = (bd.r1 + K1F) << 1;   // bit 6
-    const uint32_t f2 = (bd.r2 + K1F) << 2;   // bit 7
+    const uint32_t f0 = bd.r0 + K1F;             // flag at bit 5
+    const uint32_t f1 = add_shl<1>(bd.r1, K1F);  // bit 6
+    const uint32_t f2 = add_shl<2>(bd.r2, K1F);  // bit 7
     const uint32_t f3 = (bd.r3 + K1F) >> 1;   // bit 4 (bit 7 receives junk from the next byte: never selected)
     return ENV2048_BFI(0x20202020u, f0, ENV2048_BFI(0x40404040u, f1, ENV2048_BFI(0x80808080u, f2, f3)));
 }
@@ -351,12 +368,13 @@ ENV2048_DEV void cell_planes(uint32_t cell_bit, uint32_t &p0, uint32_t &p1, uint
 // being the only bit set, a constant shift and the byte-lane mask isolate each row's share.
 ENV2048_DEV void place_tile(Board &bd, uint32_t cell_bit, bool four)
 {
-    const uint32_t lane_mask = four ? 0x02020202u : K01;
-    const uint32_t t = cell_bit >> (four ? 3u : 4u);
-    bd.r3 |= t & lane_mask;
-    bd.r0 |= (t >> 1) & lane_mask;
-    bd.r1 |= (t >> 2) & lane_mask;
-    bd.r2 |= (t >> 3) & lane_mask;
+    const uint32_t exponent_bit = four ? 1u : 0u;
+    const uint32_t lane_mask = K01 << exponent_bit;
+    const uint32_t t = (cell_bit >> 4) << exponent_bit;
+    bd.r3 = ENV2048_AND_OR(t, lane_mask, bd.r3);
+    bd.r0 = ENV2048_AND_OR(t >> 1, lane_mask, bd.r0);
+    bd.r1 = ENV2048_AND_OR(t >> 2, lane_mask, bd.r1);
+    bd.r2 = ENV2048_AND_OR(t >> 3, lane_mask, bd.r2);
 }
 
 // Flat row-major index (4*r + c) of the cell a one-bit cell mask selects.
