@@ -178,57 +178,57 @@ ENV2048_DEV uint32_t slide_merge_planes(uint32_t &a, uint32_t &b, uint32_t &c, u
 
     // 1) stable compaction toward plane a ("column[column != 0]", gameboard.py:46), in closed form:
     //    output k is the k-th non-zero input.  Which input that is depends only on how many of the
-    //    inputs before it are non-zero, so each output is a masked OR of candidates; every mask is one
-    //    3-input boolean of the non-zero masks (v_bitop3_b32).  A zero candidate contributes nothing,
-    //    so "candidate is non-zero" never has to be tested.
+    //    inputs before it are non-zero, so each output is a masked OR of candidates and every mask is a
+    //    boolean of the non-zero masks -- written out as v_bitop3_b32 truth tables (argument order =
+    //    table order), which is 4 instructions fewer than what hipcc derives from the plain expressions.
+    //    A zero candidate contributes nothing, so "candidate is non-zero" never has to be tested.
     {
-        const uint32_t both_ab = na & nb;                        // a and b occupied
-        const uint32_t one_ab = na ^ nb;                         // exactly one of a, b
-        const uint32_t one_abc = (na ^ nb ^ nc) & ~(na & nb & nc);        // exactly one of a, b, c
-        const uint32_t two_abc = (na & nb) ^ (na & nc) ^ (nb & nc) ^ (na & nb & nc);  // exactly two
-        const uint32_t all_abc = na & nb & nc;
-        const uint32_t oa = bsel(na, a, bsel(nb, b, bsel(nc, c, d)));   // first non-zero
-        const uint32_t ob = (b & both_ab) | (c & one_ab) | (d & one_abc);  // second
-        const uint32_t oc = (c & all_abc) | (d & two_abc);                  // third
-        const uint32_t od = d & all_abc;                                    // fourth
+        const uint32_t one_abc = ENV2048_BITOP3(na, nb, nc, 0x16);  // exactly one of a, b, c occupied
+        const uint32_t two_abc = ENV2048_BITOP3(na, nb, nc, 0x68);  // exactly two
+        const uint32_t all_abc = ENV2048_BITOP3(na, nb, nc, 0x80);
+        const uint32_t maj_abc = ENV2048_BITOP3(na, nb, nc, 0xE8);  // at least two
+        const uint32_t oa = ENV2048_BFI(na, a, ENV2048_BFI(nb, b, ENV2048_BFI(nc, c, d)));   // first non-zero
+        const uint32_t ob_b = ENV2048_BITOP3(b, na, nb, 0x80);                                // b, if a and b occupied
+        const uint32_t ob_c = ENV2048_BITOP3(c, na, nb, 0x60);                                // c, if exactly one of a, b
+        const uint32_t ob = ENV2048_AND_OR(d, one_abc, ob_b) | ob_c;                          // second non-zero
+        const uint32_t oc = ENV2048_AND_OR(c, all_abc, d & two_abc);                          // third
+        const uint32_t od = d & all_abc;                                                      // fourth
         // occupancy of the compacted planes: at least 2 / 3 / 4 of the inputs are non-zero
-        const uint32_t n2 = both_ab | (one_ab & nc) | (one_abc & nd);
-        const uint32_t n3 = all_abc | (two_abc & nd);
-        const uint32_t n4 = all_abc & nd;
+        nb = ENV2048_AND_OR(one_abc, nd, maj_abc);
+        nc = ENV2048_AND_OR(two_abc, nd, all_abc);
+        nd = all_abc & nd;
         a = oa;
         b = ob;
         c = oc;
         d = od;
-        nb = n2;
-        nc = n3;
-        nd = n4;
     }
 
     // 2) greedy pairwise merge from the wall outward, each tile merging at most once
     //    (gameboard.py:56-67).  After compaction "b non-zero" implies "a non-zero", etc.
-    uint32_t m_ab = ~nzmask(a ^ b) & nb;
-    uint32_t m_bc = ~nzmask(b ^ c) & nc & ~m_ab;
-    uint32_t m_cd = ~nzmask(c ^ d) & nd & ~m_bc;
-    uint32_t x_ab = m_ab & K01, x_bc = m_bc & K01, x_cd = m_cd & K01;
-    uint32_t a1 = a + x_ab;  // merged tile: value * 2 == exponent + 1
-    uint32_t b1 = b + x_bc;
-    uint32_t c1 = c + x_cd;
-    uint32_t d1 = d & ~m_cd;
-    uint32_t s2 = m_ab | m_bc;
+    const uint32_t d_ab = nzmask(a ^ b), d_bc = nzmask(b ^ c), d_cd = nzmask(c ^ d);  // planes differ
+    const uint32_t m_ab = ENV2048_BITOP3(d_ab, nb, nb, 0x0C);    // ~d_ab & nb
+    const uint32_t m_bc = ENV2048_BITOP3(d_bc, nc, m_ab, 0x04);  // ~d_bc & nc & ~m_ab
+    const uint32_t m_cd = ENV2048_BITOP3(d_cd, nd, m_bc, 0x04);  // ~d_cd & nd & ~m_bc
+    const uint32_t s2 = m_ab | m_bc;
+    const uint32_t x_cd = m_cd & K01;
+    const uint32_t a1 = a + (m_ab & K01);  // merged tile: value * 2 == exponent + 1
+    const uint32_t b1 = b + (m_bc & K01);
+    const uint32_t c1 = c + x_cd;
+    const uint32_t d1 = ENV2048_BITOP3(d, m_cd, m_cd, 0x30);  // d & ~m_cd
     // merged exponents, for the score: at most two merges per line (ab+cd) or one (bc)
-    uint32_t v1 = (a1 & m_ab) | (b1 & m_bc);
-    uint32_t v2 = c1 & m_cd;
+    const uint32_t v1 = ENV2048_AND_OR(b1, m_bc, a1 & m_ab);
+    const uint32_t v2 = c1 & m_cd;
     // 3) close the hole a merge leaves behind
     a = a1;
-    b = bsel(m_ab, c1, b1);
-    c = bsel(s2, d1, c1);
-    d = d1 & ~s2;
+    b = ENV2048_BFI(m_ab, c1, b1);
+    c = ENV2048_BFI(s2, d1, c1);
+    d = ENV2048_BITOP3(d1, s2, s2, 0x30);  // d1 & ~s2
     changed_bits = moved | s2 | m_cd;
 
     // score = sum over merged cells of 2^exponent: shift the 0/1 merge flag of each byte lane by
     // that lane's merged exponent (one SDWA v_lshlrev per byte: both operands byte-selected), so
     // lanes without a merge contribute 0.
-    const uint32_t f1 = x_ab | x_bc, f2 = x_cd;
+    const uint32_t f1 = s2 & K01, f2 = x_cd;
     return (shl_byte<0>(f1, v1) + shl_byte<1>(f1, v1) + shl_byte<2>(f1, v1)) +
            (shl_byte<3>(f1, v1) + shl_byte<0>(f2, v2) + shl_byte<1>(f2, v2)) + (shl_byte<2>(f2, v2) + shl_byte<3>(f2, v2));
 }
