@@ -447,29 +447,54 @@ ENV2048_DEV bool no_equal_neighbours(const Board &bd)
     return (((h | 0x80000000u) & v) & K80) == K80;
 }
 
-// Legal-action bitmask (bit a <=> action a changes the board) and the two "mergeable pair"
-// facts, from adjacency alone [ref: twentyfortyeight/core/gamemove.py:45-83 legal_actions_mask].
+// legal = 2 * legal + (x != 0): one v_cmp + one v_addc_co_u32 (the carry-in is the compare result).
+ENV2048_DEV uint32_t shift_in_nonzero(uint32_t legal, uint32_t x)
+{
+#if defined(ENV2048_HOST_EMULATION)
+    return 2u * legal + (x != 0u ? 1u : 0u);
+#else
+    uint32_t r;
+    asm("v_cmp_ne_u32_e32 vcc, 0, %1\n\tv_addc_co_u32_e32 %0, vcc, %2, %2, vcc" : "=v"(r) : "v"(x), "v"(legal) : "vcc");
+    return r;
+#endif
+}
+
+// Legal-action bitmask (bit a <=> action a changes the board), from adjacency alone
+// [ref: twentyfortyeight/core/gamemove.py:45-83 legal_actions_mask]: a move is legal iff, along its
+// axis, an empty cell sits directly before an occupied one (in the direction of the move) or two
+// equal tiles are adjacent.  Only bit 7 of every byte is meaningful in the intermediate words; the
+// xor_add terms are the ones no_equal_neighbours() computes, so next to it they cost nothing.
 ENV2048_DEV uint32_t legal_mask(const Board &bd)
 {
-    uint32_t f0 = (bd.r0 + K7F) & K80, f1 = (bd.r1 + K7F) & K80;  // non-zero flags
-    uint32_t f2 = (bd.r2 + K7F) & K80, f3 = (bd.r3 + K7F) & K80;
-    // horizontal pairs (c, c+1): byte c of (x >> 8) is cell c+1; byte 3 pairs with "nothing"
-    uint32_t g0 = f0 >> 8, g1 = f1 >> 8, g2 = f2 >> 8, g3 = f3 >> 8;
-    uint32_t slide_left = (~f0 & g0) | (~f1 & g1) | (~f2 & g2) | (~f3 & g3);              // left empty, right tile
-    uint32_t slide_right = ((f0 & ~g0) | (f1 & ~g1) | (f2 & ~g2) | (f3 & ~g3)) & 0x00808080u;  // left tile, right empty
-    uint32_t h_merge = (f0 & ~((bd.r0 ^ (bd.r0 >> 8)) + K7F)) | (f1 & ~((bd.r1 ^ (bd.r1 >> 8)) + K7F)) |
-                       (f2 & ~((bd.r2 ^ (bd.r2 >> 8)) + K7F)) | (f3 & ~((bd.r3 ^ (bd.r3 >> 8)) + K7F));
-    uint32_t slide_up = (~f0 & f1) | (~f1 & f2) | (~f2 & f3);    // top empty, bottom tile
-    uint32_t slide_down = (f0 & ~f1) | (f1 & ~f2) | (f2 & ~f3);  // top tile, bottom empty
-    uint32_t v_merge = (f0 & ~((bd.r0 ^ bd.r1) + K7F)) | (f1 & ~((bd.r1 ^ bd.r2) + K7F)) |
-                       (f2 & ~((bd.r2 ^ bd.r3) + K7F));
-    h_merge &= K80;
-    v_merge &= K80;
-    uint32_t legal = 0;
-    legal |= ((slide_left | h_merge) != 0u) ? 1u : 0u;
-    legal |= ((slide_up | v_merge) != 0u) ? 2u : 0u;
-    legal |= ((slide_right | h_merge) != 0u) ? 4u : 0u;
-    legal |= ((slide_down | v_merge) != 0u) ? 8u : 0u;
+    const uint32_t y0 = bd.r0 + K7F, y1 = bd.r1 + K7F, y2 = bd.r2 + K7F, y3 = bd.r3 + K7F;  // bit 7: occupied
+    // horizontal pairs (c, c+1): byte c of (y >> 8) is cell c+1; byte 3 pairs with "nothing"
+    const uint32_t g0 = y0 >> 8, g1 = y1 >> 8, g2 = y2 >> 8, g3 = y3 >> 8;
+    const uint32_t h0 = xor_add(bd.r0, bd.r0 >> 8, K7F), h1 = xor_add(bd.r1, bd.r1 >> 8, K7F);  // bit 7: pair differs
+    const uint32_t h2 = xor_add(bd.r2, bd.r2 >> 8, K7F), h3 = xor_add(bd.r3, bd.r3 >> 8, K7F);
+    const uint32_t v0 = xor_add(bd.r0, bd.r1, K7F), v1 = xor_add(bd.r1, bd.r2, K7F), v2 = xor_add(bd.r2, bd.r3, K7F);
+    // (~a & b) | c = 0xAE, (a & ~b) | c = 0xBA
+    uint32_t slide_left = ENV2048_BITOP3(y0, g0, g0, 0x0C);  // left cell empty, right cell occupied
+    slide_left = ENV2048_BITOP3(y1, g1, slide_left, 0xAE);
+    slide_left = ENV2048_BITOP3(y2, g2, slide_left, 0xAE);
+    slide_left = ENV2048_BITOP3(y3, g3, slide_left, 0xAE);
+    uint32_t slide_right = ENV2048_BITOP3(y0, g0, g0, 0x30);  // left occupied, right empty (byte 3: masked below)
+    slide_right = ENV2048_BITOP3(y1, g1, slide_right, 0xBA);
+    slide_right = ENV2048_BITOP3(y2, g2, slide_right, 0xBA);
+    slide_right = ENV2048_BITOP3(y3, g3, slide_right, 0xBA) & 0x00808080u;
+    uint32_t h_merge = ENV2048_BITOP3(h0, y0, y0, 0x0C);  // pair equal and occupied (byte 3 can never fire)
+    h_merge = ENV2048_BITOP3(h1, y1, h_merge, 0xAE);
+    h_merge = ENV2048_BITOP3(h2, y2, h_merge, 0xAE);
+    h_merge = ENV2048_BITOP3(h3, y3, h_merge, 0xAE);
+    const uint32_t slide_up = ENV2048_BITOP3(ENV2048_BITOP3(y0, y1, y2, 0x2E), y3, y2, 0xF4);    // upper empty, lower occupied
+    const uint32_t slide_down = ENV2048_BITOP3(ENV2048_BITOP3(y0, y1, y2, 0x74), y2, y3, 0xF4);  // upper occupied, lower empty
+    uint32_t v_merge = ENV2048_BITOP3(v0, y0, y0, 0x0C);
+    v_merge = ENV2048_BITOP3(v1, y1, v_merge, 0xAE);
+    v_merge = ENV2048_BITOP3(v2, y2, v_merge, 0xAE);
+    // (a | b) & c = 0xA8, a | (b & c) = 0xF8
+    uint32_t legal = shift_in_nonzero(0u, ENV2048_BITOP3(slide_down, v_merge, K80, 0xA8));   // bit 3: down
+    legal = shift_in_nonzero(legal, ENV2048_BITOP3(slide_right, h_merge, K80, 0xF8));        // bit 2: right
+    legal = shift_in_nonzero(legal, ENV2048_BITOP3(slide_up, v_merge, K80, 0xA8));           // bit 1: up
+    legal = shift_in_nonzero(legal, ENV2048_BITOP3(slide_left, h_merge, K80, 0xA8));         // bit 0: left
     return legal;
 }
 

@@ -199,14 +199,14 @@ __device__ __forceinline__ void lds_barrier()
 // Rebuild the queued (terminal) boards of this block; executed by `nthreads` threads with ids `t`.
 template <bool EXTRAS>
 __device__ __forceinline__ void reset_queued(const StepArgs &a, uint64_t block0, const uint16_t *reset_slot,
-                                             uint32_t n_reset, uint32_t t, uint32_t nthreads)
+                                             uint32_t n_reset, uint32_t t, uint32_t nthreads, bool through)
 {
     for (uint32_t q = t; q < n_reset; q += nthreads) {
         const uint64_t i = block0 + reset_slot[q];
         uint32_t w0, w1, w2, w3;
         env_block(a.key, a.env_base + i, STREAM_RESET, w0, w1, w2, w3);
         const Board fresh = fresh_board(w0, w1, w2, w3);
-        store_board(a.boards, i, fresh);
+        store_board(a.boards, i, fresh, through);  // same policy as the step's own stores: no dirty L2 lines left
         if (EXTRAS) {
             if (a.legal) a.legal[i] = (uint8_t)legal_mask(fresh);
             if (a.obs) store_obs(a.obs, i, fresh);
@@ -230,7 +230,7 @@ __device__ __forceinline__ void reset_queued(const StepArgs &a, uint64_t block0,
 // ENV2048_EXP_STAMPS (s_memtime wave timeline into the obs buffer) exist for tools/microbench only.
 template <bool EXTRAS, bool FULL, bool RANDOM>
 __device__ __forceinline__ void step_block(const StepArgs &a, uint4 *dir_lds, uint32_t (*word_lds)[WORD_STRIP],
-                                           uint32_t *reset_count, uint32_t *waves_finished, uint16_t *reset_slot)
+                                           uint32_t *queue_state, uint16_t *reset_slot)
 {
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -286,8 +286,7 @@ __device__ __forceinline__ void step_block(const StepArgs &a, uint4 *dir_lds, ui
     // 3. selector table (its load was issued first, so it has long arrived) + bookkeeping words
     if (tid < 8u) dir_lds[tid] = table_row;
     if (tid == 0u) {
-        *reset_count = 0u;
-        *waves_finished = 0u;
+        *queue_state = 0u;  // bits 0-15: queued terminal boards, bits 16+: waves of the block that have finished
     }
     lds_barrier();
 
@@ -323,7 +322,7 @@ __device__ __forceinline__ void step_block(const StepArgs &a, uint4 *dir_lds, ui
         if (FULL || i < a.n) {
             const bool pending_reset = auto_reset && done[j];
             if (pending_reset) {
-                const uint32_t slot = atomicAdd(reset_count, 1u);
+                const uint32_t slot = atomicAdd(queue_state, 1u) & 0xFFFFu;
                 reset_slot[slot] = (uint16_t)(wave * TILE_BOARDS + 64u * j + lane);
             } else {
                 store_board(a.boards, i, bd[j], through);
@@ -364,6 +363,16 @@ __device__ __forceinline__ void step_block(const StepArgs &a, uint4 *dir_lds, ui
         compute(j);
         emit(j);
     }
+    // 5a. No second barrier: waves retire as they finish.  Each announces itself with ONE LDS atomic on the
+    // word that also counts the queue entries (its own entries were queued before, and a wave's LDS
+    // operations execute in order), so the LAST wave of the block learns from the returned value both that
+    // it is last and how many boards are queued.  Issued before the output transposition below, whose
+    // LDS round trips hide its latency.
+    uint32_t state_at_arrival = 0u;
+    if (auto_reset) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        if (lane == 0u) state_at_arrival = atomicAdd(queue_state, 0x10000u);
+    }
     // Wide write-once outputs: transpose the tile's 256 rewards / done bytes through the (now free) LDS
     // strip so that lane l owns boards 4l..4l+3 and writes one dwordx4 (+ one dword) write-through.
 #if !(defined(ENV2048_EXP_ABLATE) && (ENV2048_EXP_ABLATE & 4))
@@ -401,18 +410,17 @@ __device__ __forceinline__ void step_block(const StepArgs &a, uint4 *dir_lds, ui
     }
 #endif
 
-    // 5. No second barrier: waves retire as they finish; the LAST wave of the block to get here sees
-    // every queue entry (LDS is coherent within the CU; each wave's queue writes are complete before
-    // its arrival count) and rebuilds the terminal boards.
+    // 5b. the last wave of the block rebuilds the queued terminal boards
     if (!auto_reset) return;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    uint32_t arrived = 0u;
-    if (lane == 0u) arrived = atomicAdd(waves_finished, 1u);
-    arrived = __builtin_amdgcn_readfirstlane(arrived);
-    if (arrived != WAVES_PER_BLOCK - 1u) return;
+    state_at_arrival = __builtin_amdgcn_readfirstlane(state_at_arrival);
+    if ((state_at_arrival >> 16) != WAVES_PER_BLOCK - 1u) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-    const uint32_t n_reset = atomicAdd(reset_count, 0u);  // LDS read-through (a volatile load would go flat + vmcnt(0))
-    reset_queued<EXTRAS>(a, block0, reset_slot, n_reset, lane, 64u);
+    const uint32_t n_reset = state_at_arrival & 0xFFFFu;
+#if defined(ENV2048_EXP_ABLATE) && (ENV2048_EXP_ABLATE & 8)  // timing-only build: terminal boards are not rebuilt
+    (void)n_reset;
+#else
+    reset_queued<EXTRAS>(a, block0, reset_slot, n_reset, lane, 64u, through);
+#endif
 }
 
 template <bool EXTRAS, bool RANDOM>
@@ -420,14 +428,13 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(StepArgs a)
 {
     __shared__ uint4 dir_lds[8];
     __shared__ __attribute__((aligned(16))) uint32_t word_lds[WAVES_PER_BLOCK][WORD_STRIP];
-    __shared__ uint32_t reset_count;
-    __shared__ uint32_t waves_finished;
+    __shared__ uint32_t queue_state;
     __shared__ uint16_t reset_slot[BLOCK_BOARDS];
     const uint64_t block0 = (uint64_t)blockIdx.x * BLOCK_BOARDS;
     if (block0 + BLOCK_BOARDS <= a.n)  // block-uniform: every block but the last takes the unchecked path
-        step_block<EXTRAS, true, RANDOM>(a, dir_lds, word_lds, &reset_count, &waves_finished, reset_slot);
+        step_block<EXTRAS, true, RANDOM>(a, dir_lds, word_lds, &queue_state, reset_slot);
     else
-        step_block<EXTRAS, false, RANDOM>(a, dir_lds, word_lds, &reset_count, &waves_finished, reset_slot);
+        step_block<EXTRAS, false, RANDOM>(a, dir_lds, word_lds, &queue_state, reset_slot);
 }
 
 struct ResetArgs {
