@@ -380,6 +380,28 @@ def test_full_size_checksum_vs_oracle(lib):
 
 
 # ---------------------------------------------------------------------------- entry points added for the API mirrors
+def test_spawn_and_status_every_occupancy(lib):
+    """Every occupancy pattern of a board: k-th empty cell for every rank (tiles 2 and 4, neighbours up to
+    exponent 31) and done / legal / counts, HIP vs oracle."""
+    rng = np.random.default_rng(21)
+    occ = (np.arange(1 << 16, dtype=np.uint32)[:, None] >> np.arange(16, dtype=np.uint32)) & 1
+    base = (occ * rng.integers(1, 32, size=occ.shape)).astype(np.uint8)
+    boards = np.tile(base, (17, 1))
+    k = np.repeat(np.arange(17, dtype=np.uint8), base.shape[0])
+    e = rng.integers(1, 3, size=boards.shape[0]).astype(np.uint8)
+    ref = oracle.spawn_batch(boards, k, e)
+    got = hip_spawn(lib, boards, k, e)
+    np.testing.assert_array_equal(got['boards'], ref['boards'])
+    np.testing.assert_array_equal(got['placed'], ref['placed'])
+    for lo, hi in ((1, 2), (30, 31), (1, 31)):
+        b = (occ * rng.integers(lo, hi + 1, size=occ.shape)).astype(np.uint8)
+        ref = oracle.status_batch(b)
+        got = hip_status(lib, b)
+        for key in ('done', 'legal', 'n_empty', 'max_exp'):
+            np.testing.assert_array_equal(got[key], ref[key], err_msg=f'{key} [{lo},{hi}]')
+        np.testing.assert_array_equal(got['obs'], ref['obs'])
+
+
 def test_chance_outcomes_match_oracle(lib, golden):
     boards = golden['afterstates']['boards']
     n = boards.shape[0]

@@ -110,6 +110,43 @@ def test_status_and_spawn(emu, golden):
     np.testing.assert_array_equal(placed, ref['placed'])
 
 
+def occupancy_boards(rng, lo=1, hi=31):
+    """All 65 536 occupancy patterns of a board; occupied cells hold random exponents in [lo, hi]."""
+    occ = (np.arange(1 << 16, dtype=np.uint32)[:, None] >> np.arange(16, dtype=np.uint32)) & 1
+    return (occ * rng.integers(lo, hi + 1, size=occ.shape)).astype(np.uint8)
+
+
+def test_spawn_every_occupancy_every_rank(emu):
+    """k-th empty cell, every occupancy pattern x every rank 0..16 (16 = always out of range), tiles 2 and 4,
+    neighbours up to exponent 31 (the occupancy flags rely on value + 0x1F staying below bit 6)."""
+    rng = np.random.default_rng(11)
+    base = occupancy_boards(rng)
+    for k in range(17):
+        kk = np.full(base.shape[0], k, dtype=np.uint8)
+        e = rng.integers(1, 3, size=base.shape[0]).astype(np.uint8)
+        ref = oracle.spawn_batch(base, kk, e)
+        b = base.copy()
+        placed = np.zeros(base.shape[0], dtype=np.uint8)
+        emu.emu_spawn(ctypes.c_uint64(b.shape[0]), u8(b), u8(kk), u8(e), u8(placed))
+        np.testing.assert_array_equal(b, ref['boards'], err_msg=f'k={k}')
+        np.testing.assert_array_equal(placed, ref['placed'], err_msg=f'k={k}')
+
+
+def test_status_every_occupancy(emu):
+    """done / legal / empty count on every occupancy pattern, with two tile values (so that equal and
+    different neighbours both occur) and with all-different large exponents."""
+    rng = np.random.default_rng(12)
+    for lo, hi in ((1, 2), (30, 31), (1, 31)):
+        boards = occupancy_boards(rng, lo, hi)
+        n = boards.shape[0]
+        ref = oracle.status_batch(boards)
+        done, legal, n_empty = (np.zeros(n, dtype=np.uint8) for _ in range(3))
+        emu.emu_status(ctypes.c_uint64(n), u8(boards), u8(done), u8(legal), u8(n_empty))
+        np.testing.assert_array_equal(done, ref['done'])
+        np.testing.assert_array_equal(legal, ref['legal'])
+        np.testing.assert_array_equal(n_empty, ref['n_empty'])
+
+
 def test_step_words_match_oracle(emu):
     seed, step = 0x1122334455667788, (1 << 33) + 5
     for env_base in (0, 1001, (1 << 34) + 3):
