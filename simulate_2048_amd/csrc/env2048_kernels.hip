@@ -289,6 +289,10 @@ __device__ __forceinline__ void step_block(const StepArgs &a, uint4 *dir_lds, ui
         *queue_state = 0u;  // bits 0-15: queued terminal boards, bits 16+: waves of the block that have finished
     }
     lds_barrier();
+    // Nothing that touches a loaded value may be scheduled above the barrier: hipcc otherwise hoists the
+    // selector address of board 0 (action << 5) there, the vmcnt wait goes with it, and every wave of the
+    // block then waits at the barrier for the slowest wave's boards.
+    __builtin_amdgcn_sched_barrier(0);
 
     // 4. first half home (exact count: vmcnt counts in issue order and no store has been issued
     //    yet; in the bounds-checked path loads may be skipped, so wait for everything there)
