@@ -427,9 +427,17 @@ __device__ __forceinline__ void step_block(const StepArgs &a, uint4 *dir_lds, ui
 #endif
 }
 
+// Scalar kernel arguments in the order the kernel needs them: the first 13 dwords (everything up to the
+// Philox key) are preloaded into SGPRs by the command processor (built with
+// -mllvm -amdgpu-kernarg-preload-count=16; gfx950 has 14 free user SGPRs), so a wave issues its board
+// loads without first waiting for an s_load of the argument block; the output pointers arrive while the
+// Philox blocks are computed.
 template <bool EXTRAS, bool RANDOM>
-__global__ __launch_bounds__(BLOCK) void step_kernel(StepArgs a)
+__global__ __launch_bounds__(BLOCK) void step_kernel(uint8_t *boards, const uint8_t *actions, uint64_t n, uint64_t env_base,
+                                                     uint32_t flags, uint32_t seed_lo, uint32_t seed_hi, uint32_t step_lo,
+                                                     uint32_t step_hi, int32_t *reward, uint8_t *done, uint8_t *legal, float *obs)
 {
+    const StepArgs a{n, env_base, boards, actions, reward, done, legal, obs, RngKey{seed_lo, seed_hi, step_lo, step_hi}, flags};
     __shared__ uint4 dir_lds[8];
     __shared__ __attribute__((aligned(16))) uint32_t word_lds[WAVES_PER_BLOCK][WORD_STRIP];
     __shared__ uint32_t queue_state;
@@ -934,13 +942,13 @@ int env2048_step(int device, void *stream, uint64_t n, uint64_t env_base, uint8_
     const bool random_actions = (flags & ENV2048_FLAG_RANDOM_ACTIONS) != 0u;
     const dim3 grid = tile_grid_for(n), block(BLOCK);
     if (extras && random_actions)
-        hipLaunchKernelGGL((step_kernel<true, true>), grid, block, 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((step_kernel<true, true>), grid, block, 0, (hipStream_t)stream, a.boards, a.actions, a.n, a.env_base, a.flags, a.key.seed_lo, a.key.seed_hi, a.key.step_lo, a.key.step_hi, a.reward, a.done, a.legal, a.obs);
     else if (extras)
-        hipLaunchKernelGGL((step_kernel<true, false>), grid, block, 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((step_kernel<true, false>), grid, block, 0, (hipStream_t)stream, a.boards, a.actions, a.n, a.env_base, a.flags, a.key.seed_lo, a.key.seed_hi, a.key.step_lo, a.key.step_hi, a.reward, a.done, a.legal, a.obs);
     else if (random_actions)
-        hipLaunchKernelGGL((step_kernel<false, true>), grid, block, 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((step_kernel<false, true>), grid, block, 0, (hipStream_t)stream, a.boards, a.actions, a.n, a.env_base, a.flags, a.key.seed_lo, a.key.seed_hi, a.key.step_lo, a.key.step_hi, a.reward, a.done, a.legal, a.obs);
     else
-        hipLaunchKernelGGL((step_kernel<false, false>), grid, block, 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((step_kernel<false, false>), grid, block, 0, (hipStream_t)stream, a.boards, a.actions, a.n, a.env_base, a.flags, a.key.seed_lo, a.key.seed_hi, a.key.step_lo, a.key.step_hi, a.reward, a.done, a.legal, a.obs);
     return launched("env2048_step launch");
 }
 
