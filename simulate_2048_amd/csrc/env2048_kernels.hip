@@ -226,8 +226,9 @@ __device__ __forceinline__ void reset_queued(const StepArgs &a, uint64_t block0,
 // EXTRAS: legal and/or obs requested.  FULL: every board of the block exists (no bounds checks);
 // RANDOM: actions come from the step words instead of memory.  Build-time knobs (defaults measured
 // best): ENV2048_BLOCK threads per block, ENV2048_BOARDS_PER_LANE; diagnostic builds
-// ENV2048_EXP_ABLATE (bit 0 no game logic, bit 1 no Philox, bit 2 no reward/done stores) and
-// ENV2048_EXP_STAMPS (s_memtime wave timeline into the obs buffer) exist for tools/microbench only.
+// ENV2048_EXP_ABLATE (bit 0 no game logic, bit 1 no Philox, bit 2 no reward/done stores, bit 3 terminal
+// boards queued but not rebuilt) and ENV2048_EXP_STAMPS (five s_memrealtime stamps + HW_ID per wave into
+// the obs buffer) exist for tools/microbench only.
 template <bool EXTRAS, bool FULL, bool RANDOM>
 __device__ __forceinline__ void step_block(const StepArgs &a, uint4 *dir_lds, uint32_t (*word_lds)[WORD_STRIP],
                                            uint32_t *queue_state, uint16_t *reset_slot)
