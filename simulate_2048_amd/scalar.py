@@ -1,0 +1,120 @@
+"""
+Single-board calls of the API mirrors (``twentyfortyeight.core.gameboard`` / ``gamemove`` / the
+``TwentyFortyEight`` env): one kernel launch and one stream synchronisation per call.
+
+The kernels behind the C-ABI take *device-accessible* pointers.  Pinned host memory is
+device-accessible on HIP (unified addressing), so for a batch of one the operands live in a small set
+of pinned host buffers that the kernel reads and writes across the bus directly: no staging copies,
+no device allocations and no torch operators on the call path -- the Python side fills NumPy views of
+those buffers, launches, waits for the stream and reads the views.  Tile values <-> log2 exponents are
+converted on the host (16 integers).
+
+Not thread-safe (one scratch set per runtime), like the module-level generator of the reference.
+With an injected host library (tests) the buffers are ordinary host memory and the same code runs.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import capi, runtime
+
+
+class ScalarOps:
+    """Scratch buffers + the single-board operations, bound to one ``runtime.Runtime``."""
+
+    def __init__(self, rt: runtime.Runtime):
+        self.rt = rt
+        pin = rt.device.type == 'cuda'
+
+        def buf(shape, dtype):
+            t = torch.zeros(shape, dtype=dtype, pin_memory=pin)
+            return t, t.numpy(), t.data_ptr()
+
+        self._board_t, self.board, self._board = buf((16,), torch.uint8)
+        self._out_t, self.out, self._out = buf((16,), torch.uint8)
+        self._outcomes_t, self.outcomes, self._outcomes = buf((32, 16), torch.uint8)
+        self._prob_t, self.prob, self._prob = buf((32,), torch.float32)
+        self._action_t, self.action, self._action = buf((1,), torch.uint8)
+        self._reward_t, self.reward, self._reward = buf((1,), torch.int32)
+        self._flags_t, self.flags, self._flags_ptr = buf((4,), torch.uint8)  # done, legal, changed, count
+        self._ptr_done = self._flags_ptr
+        self._ptr_legal = self._flags_ptr + 1
+        self._ptr_changed = self._flags_ptr + 2
+        self._ptr_count = self._flags_ptr + 3
+
+    # -- host-side value <-> exponent conversion (same mapping as env2048_pack_i64 / unpack_i64) -----
+    def load(self, values) -> None:
+        """(4,4) tile values -> the packed input buffer: e = floor(log2(v)) for v > 0, else 0."""
+        flat = np.asarray(values).reshape(16)
+        board = self.board
+        for i, v in enumerate(flat.tolist()):
+            board[i] = (int(v).bit_length() - 1) & 0xFF if v > 0 else 0
+
+    @staticmethod
+    def values(packed: np.ndarray, dtype) -> np.ndarray:
+        """packed exponents (..., 16) -> tile values (..., 4, 4) of `dtype`."""
+        e = packed.astype(np.int64)
+        return np.where(e > 0, np.left_shift(np.int64(1), e), 0).astype(dtype, copy=False).reshape(packed.shape[:-1] + (4, 4))
+
+    def _sync(self) -> None:
+        if self.rt.device.type == 'cuda':
+            torch.cuda.current_stream(self.rt.device).synchronize()
+
+    # -- operations ----------------------------------------------------------------------------------
+    def afterstate(self, values, action: int, dtype):
+        """-> (afterstate values, reward int, changed bool); no tile is spawned."""
+        self.load(values)
+        self.action[0] = action & 3
+        dev, stream = self.rt.handles()
+        self.rt.lib.afterstate(dev, stream, 1, self._board, self._action, self._out, self._reward, self._ptr_changed)
+        self._sync()
+        return self.values(self.out, dtype), int(self.reward[0]), bool(self.flags[2])
+
+    def step(self, values, action: int, seed: int, step_index: int, dtype):
+        """Full transition -> (new values, reward int, done bool). The input array is not touched."""
+        self.load(values)
+        self.action[0] = action & 3
+        dev, stream = self.rt.handles()
+        self.rt.lib.step(dev, stream, 1, 0, self._board, self._action, self._reward, self._ptr_done, None, None, seed,
+                         step_index, 0)
+        self._sync()
+        return self.values(self.board, dtype), int(self.reward[0]), bool(self.flags[0])
+
+    def status(self, values):
+        """-> (done bool, legal bitmask int)."""
+        self.load(values)
+        dev, stream = self.rt.handles()
+        self.rt.lib.status(dev, stream, 1, self._board, self._ptr_done, self._ptr_legal, None, None, None)
+        self._sync()
+        return bool(self.flags[0]), int(self.flags[1])
+
+    def spawn_random(self, values, seed: int, step_index: int, count: int, dtype) -> np.ndarray:
+        self.load(values)
+        dev, stream = self.rt.handles()
+        self.rt.lib.spawn_random(dev, stream, 1, 0, self._board, seed, step_index, count)
+        self._sync()
+        return self.values(self.board, dtype)
+
+    def chance_outcomes(self, values, dtype):
+        """-> (outcome values (count,4,4), count) in the reference's enumeration order."""
+        self.load(values)
+        dev, stream = self.rt.handles()
+        self.rt.lib.chance_outcomes(dev, stream, 1, self._board, self._outcomes, self._prob, self._ptr_count)
+        self._sync()
+        count = int(self.flags[3])
+        return self.values(self.outcomes[:count], dtype), count
+
+
+def current() -> ScalarOps:
+    """The ScalarOps of the current runtime (created on first use, dropped when the runtime changes)."""
+    rt = runtime.current()
+    ops = getattr(rt, '_scalar_ops', None)
+    if ops is None:
+        ops = ScalarOps(rt)
+        rt._scalar_ops = ops
+    return ops
+
+
+__all__ = ['ScalarOps', 'current', 'capi']

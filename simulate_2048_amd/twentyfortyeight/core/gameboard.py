@@ -12,8 +12,8 @@ from __future__ import annotations
 import numpy as np
 from numpy import argwhere, ndarray
 
-from ... import ops
-from ._device import host, rng_for, to_device, to_numpy
+from ... import scalar
+from ._device import require_4x4, rng_for
 
 # ##>: Tile spawn probabilities (90% for 2, 10% for 4) [ref gameboard.py:13].
 TILE_SPAWN_PROBS: dict[int, float] = {2: 0.9, 4: 0.1}
@@ -29,23 +29,25 @@ def merge_column(column: ndarray) -> tuple[int, ndarray]:
         raise ValueError(f'merge_column: the MI355X engine handles columns of length 4, got shape {column.shape}')
     board = np.zeros((4, 4), dtype=np.int64)
     board[0] = column
-    after, reward, _ = ops.afterstate(to_device(board), [0])
-    row = to_numpy(after, column.dtype)[0]
-    return int(host(reward)[0]), row[row != 0]
+    after, reward, _ = scalar.current().afterstate(board, 0, column.dtype)
+    row = after[0]
+    return reward, row[row != 0]
 
 
 def slide_and_merge(board: ndarray) -> tuple[float, ndarray]:
     """[ref gameboard.py:72-102] slide every row left and merge; score is a float like the reference."""
     board = np.asarray(board)
-    after, reward, _ = ops.afterstate(to_device(board), [0])
-    return 0.0 + float(host(reward)[0]), to_numpy(after, board.dtype)
+    require_4x4(board, 'board')
+    after, reward, _ = scalar.current().afterstate(board, 0, board.dtype)
+    return 0.0 + float(reward), after
 
 
 def latent_state(state: ndarray, action: int) -> tuple[ndarray, float]:
     """[ref gameboard.py:105-129] afterstate of `action` (0 left, 1 up, 2 right, 3 down), no new tile."""
     state = np.asarray(state)
-    after, reward, _ = ops.afterstate(to_device(state), [int(action) & 3])
-    return to_numpy(after, state.dtype), 0.0 + float(host(reward)[0])
+    require_4x4(state, 'board')
+    after, reward, _ = scalar.current().afterstate(state, int(action), state.dtype)
+    return after, 0.0 + float(reward)
 
 
 def after_state(state: ndarray) -> list[tuple[ndarray, float]]:
@@ -55,9 +57,8 @@ def after_state(state: ndarray) -> list[tuple[ndarray, float]]:
     num_empty_cells = int((state == 0).sum())
     if num_empty_cells == 0:
         return [(state, 1.0)]
-    boards, _, count = ops.chance_outcomes(to_device(state))
-    count = int(host(count)[0])
-    values = host(ops.unpack(boards.reshape(32, 16)[:count])).reshape(-1, 4, 4).astype(state.dtype, copy=False)
+    require_4x4(state, 'board')
+    values, count = scalar.current().chance_outcomes(state, state.dtype)
     # ##>: probabilities in float64 exactly as the reference computes them (TILE_SPAWN_PROBS[v] / n)
     return [(values[i], TILE_SPAWN_PROBS[2 if i % 2 == 0 else 4] / num_empty_cells) for i in range(count)]
 
@@ -84,10 +85,9 @@ def fill_cells(state: ndarray, number_tile: int, seed: int | None = None) -> nda
     if num_available == 0:
         return state
     number_tile = min(int(number_tile), num_available)
-    boards = to_device(state)
+    require_4x4(np.asarray(state), 'board')
     stream_seed, step = rng_for(seed)
-    ops.spawn_random(boards, stream_seed, step, number_tile)
-    state[...] = to_numpy(boards, state.dtype)
+    state[...] = scalar.current().spawn_random(state, stream_seed, step, number_tile, state.dtype)
     return state
 
 
@@ -96,15 +96,22 @@ def next_state(state: ndarray, action: int, seed: int | None = None) -> tuple[nd
 
     An invalid move returns the SAME `state` object and the int 0, like the reference (:325).
     """
-    boards = to_device(state)
-    stream_seed, step = rng_for(seed)
-    out = ops.step(boards, [int(action) & 3], stream_seed, step)
-    after = to_numpy(boards, np.asarray(state).dtype)
+    after, reward, _ = _transition(state, action, seed)
     if np.array_equal(after, state):
         return state, 0
-    return after, 0.0 + float(host(out['reward'])[0])
+    return after, 0.0 + float(reward)
+
+
+def _transition(state: ndarray, action: int, seed: int | None):
+    """One launch of the step kernel on one board: (new values, reward int, done bool)."""
+    arr = np.asarray(state)
+    require_4x4(arr, 'board')
+    stream_seed, step = rng_for(seed)
+    return scalar.current().step(arr, int(action), stream_seed, step, arr.dtype)
 
 
 def is_done(state: ndarray) -> bool:
     """[ref gameboard.py:328-348] no empty cell and no equal horizontal / vertical neighbours."""
-    return bool(host(ops.status(to_device(state), done=True, legal=False)['done'])[0])
+    state = np.asarray(state)
+    require_4x4(state, 'board')
+    return scalar.current().status(state)[0]

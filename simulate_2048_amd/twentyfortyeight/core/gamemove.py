@@ -5,14 +5,16 @@ Game move utilities: legal / illegal moves.  Mirror of ``twentyfortyeight/core/g
 
 from __future__ import annotations
 
-from numpy import ndarray, rot90
+from numpy import asarray, ndarray, rot90
 
-from ... import ops
-from ._device import host, to_device
+from ... import scalar
+from ._device import require_4x4
 
 
 def _legal_bits(state: ndarray) -> int:
-    return int(host(ops.status(to_device(state), done=False, legal=True)['legal'])[0])
+    state = asarray(state)
+    require_4x4(state, 'board')
+    return scalar.current().status(state)[1]
 
 
 def _can_move_direction(board: ndarray, direction: int) -> bool:

@@ -60,9 +60,15 @@ class TwentyFortyEight:
 
     def step(self, action: int) -> tuple[np.ndarray, float, bool]:
         """Play ``action`` (0 left, 1 up, 2 right, 3 down): ``(observation, reward, finished)``."""
-        board, gained = gameboard.next_state(state=self._current_state, action=action)
+        # next_state + is_done of the reference in ONE launch: the step kernel reports the terminal test
+        # of the board it wrote.  An invalid move keeps the same state object and earns the int 0.
+        board, gained, finished = gameboard._transition(self._current_state, action, None)
+        if np.array_equal(board, self._current_state):
+            board, gained = self._current_state, 0
+        else:
+            gained = 0.0 + float(gained)
         self._current_state, self._current_reward = board, gained
-        return self.observation, self.reward, self.is_finished
+        return self.observation, self.reward, finished
 
     def render(self) -> None:
         """Print the four rows, cells separated by ' \\t'."""
