@@ -72,11 +72,15 @@ def api_loop():
 
 
 dt_api = timed(api_loop)
+env_c = BatchedEnv2048(n, SEED, device='cuda:0', auto_reset=True)
+env_c.reset()
+dt_api_pure = timed(lambda: [env_c.step(None) for _ in range(512)])
 res = {}
 dt_roll = timed(lambda: res.update(env_b.rollout(512)))
 same = bool(torch.equal(env_a.boards, env_b.boards)) and int(res['return_sum'].sum()) == int(total) and int(res['episodes'].sum()) == int(episodes)
 out['config4_rollout_512'] = {
-    'api_512_launches_s': dt_api, 'api_board_steps_per_s': n * 512 / dt_api,
+    'api_512_launches_s': dt_api_pure, 'api_board_steps_per_s': n * 512 / dt_api_pure,
+    'api_512_launches_with_torch_reductions_s': dt_api,  # the cross-check loop: + r.sum() and d.sum() per step
     'fused_rollout_s': dt_roll, 'fused_board_steps_per_s': n * 512 / dt_roll,
     'identical_boards_return_episodes': same,
     'episodes': int(episodes), 'mean_episode_length': n * 512 / max(1, int(episodes)),
