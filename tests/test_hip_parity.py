@@ -239,6 +239,24 @@ def test_step_matches_oracle_random_boards(lib, flags):
         np.testing.assert_array_equal(lean[k], ref[k], err_msg='lean ' + k)
 
 
+@pytest.mark.parametrize('n', [1, 3, 63, 64, 65, 255, 256, 257, 2047, 2048, 2049, 4096, 6145])
+def test_step_tile_and_block_edges(lib, n):
+    """Batch sizes around the wave tile (256 boards) and block (2048) boundaries, every alignment of the
+    first environment within its Philox group (env_base & 3), near-terminal boards so that the reset
+    queue is exercised, all four kernel variants."""
+    rng = np.random.default_rng(1000 + n)
+    boards = np.where(rng.random((n, 16)) < 0.06, 0, rng.integers(1, 4, size=(n, 16))).astype(np.uint8)
+    actions = rng.integers(0, 4, size=n).astype(np.uint8)
+    for env_base in (0, 1, 2, 3, (1 << 32) - 2):
+        for flags in (capi.FLAG_AUTO_RESET, capi.FLAG_AUTO_RESET | capi.FLAG_RANDOM_ACTIONS, 0):
+            acts = None if flags & capi.FLAG_RANDOM_ACTIONS else actions
+            ref = oracle.step_batch(boards, acts, 77, 5, env_base=env_base, flags=flags, want_legal=True, want_obs=True)
+            for extras in (False, True):
+                got = hip_step(lib, boards, acts, 77, 5, env_base=env_base, flags=flags, extras=extras)
+                for k in ('boards', 'reward', 'done') + (('legal', 'obs') if extras else ()):
+                    np.testing.assert_array_equal(got[k], ref[k], err_msg=f'{k} n={n} env_base={env_base} flags={flags}')
+
+
 def test_long_random_play_matches_oracle(lib):
     """4096 games x 300 steps with auto-reset: every branch of real play, compared every step."""
     n, T, seed = 4096, 300, 20480
