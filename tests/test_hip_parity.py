@@ -459,6 +459,24 @@ def test_spawn_random_and_onehot_match_oracle(lib, golden):
     np.testing.assert_array_equal(out.cpu().numpy(), g['onehot31'])  # the reference's encode_flatten(..., 31)
 
 
+@pytest.mark.parametrize('width', [1, 2, 3, 15, 16, 17, 31, 32, 33, 255])
+def test_onehot_every_width_class(lib, width):
+    """One-hot encoder for widths below / at / above the 16-byte store granule, ragged board count, with a
+    16-byte aligned output (wide-store kernel) and a 4-byte aligned one (dword kernel)."""
+    rng = np.random.default_rng(width)
+    n = 64 * 3 + 7
+    boards = rng.integers(0, min(width, 32), size=(n, 16)).astype(np.uint8)
+    want = oracle.encode_onehot(boards, width)
+    b = cu(boards)
+    for shift in (0, 4):  # byte offset of the output inside a 16-byte aligned allocation
+        raw = torch.full((n * 16 * width + 16,), 7, dtype=torch.uint8, device='cuda')
+        out = raw[shift:shift + n * 16 * width]
+        lib.encode_onehot(DEV, stream(), n, p(b), width, out.data_ptr())
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(out.cpu().numpy().reshape(n, 16 * width), want, err_msg=f'shift={shift}')
+        assert int(raw[shift + n * 16 * width:].min()) == 7  # nothing written past the end
+
+
 def test_trajectory_buffer_on_gpu(lib):
     from simulate_2048_amd import BatchedEnv2048
     from simulate_2048_amd.trajectory import TrajectoryBuffer
