@@ -124,6 +124,20 @@ ENV2048_EXPORT int env2048_step_state_i32(int device, void *stream, uint64_t n, 
                                           float *reward, int32_t *max_tile, uint64_t seed, uint64_t step_index);
 
 /*
+ * The same transition written to NEW arrays -- the functional form the reference API has (batched_step
+ * returns a new GameState and leaves its argument alone, reinforce/game/env.py:193-211): every `*_in` array
+ * is only read, every `*_out` array is written for all n environments (a finished game is copied through).
+ * Passing the same pointer for an in/out pair gives the in-place call above.  step_count and total_reward
+ * need both of their arrays or neither.
+ * [replaces: reinforce/game/env.py:79-133 step, :193-211 batched_step]
+ */
+ENV2048_EXPORT int env2048_step_state_i32_to(int device, void *stream, uint64_t n, uint64_t env_base, const int32_t *boards_in,
+                                             int32_t *boards_out, const int32_t *actions, const int32_t *step_count_in,
+                                             int32_t *step_count_out, const uint8_t *done_in, uint8_t *done_out,
+                                             const float *total_reward_in, float *total_reward_out, float *reward,
+                                             int32_t *max_tile, uint64_t seed, uint64_t step_index);
+
+/*
  * T consecutive transitions per board, boards held in registers, actions drawn on device
  * (low two bits of each step word): identical to T calls of env2048_step(..., step0 + t,
  * flags | RANDOM_ACTIONS).  Per-environment outputs (each may be NULL):

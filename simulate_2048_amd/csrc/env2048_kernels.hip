@@ -570,35 +570,54 @@ __device__ __forceinline__ int4 unpack4(uint32_t r)
     return make_int4(v(r & 0xFFu), v((r >> 8) & 0xFFu), v((r >> 16) & 0xFFu), v(r >> 24));
 }
 
-__global__ __launch_bounds__(BLOCK) void step_state_i32_kernel(uint64_t n, uint64_t env_base, int32_t *boards,
-                                                               const int32_t *actions, int32_t *step_count, uint8_t *done_io,
-                                                               float *total_reward, float *reward_out, int32_t *max_tile,
-                                                               RngKey key)
+// `*_in` -> `*_out` (the same pointers for the in-place entry point): a finished game copies through.
+__global__ __launch_bounds__(BLOCK) void step_state_i32_kernel(uint64_t n, uint64_t env_base, const int32_t *boards_in,
+                                                               int32_t *boards_out, const int32_t *actions,
+                                                               const int32_t *step_count_in, int32_t *step_count_out,
+                                                               const uint8_t *done_in, uint8_t *done_out,
+                                                               const float *total_in, float *total_out, float *reward_out,
+                                                               int32_t *max_tile, RngKey key)
 {
     const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
-    int4 *rows = reinterpret_cast<int4 *>(boards) + 4 * i;
-    Board bd{pack4(rows[0]), pack4(rows[1]), pack4(rows[2]), pack4(rows[3])};
-    const bool was_done = done_io[i] != 0;
+    const int4 *rows_in = reinterpret_cast<const int4 *>(boards_in) + 4 * i;
+    int4 *rows_out = reinterpret_cast<int4 *>(boards_out) + 4 * i;
+    const int4 v0 = rows_in[0], v1 = rows_in[1], v2 = rows_in[2], v3 = rows_in[3];
+    Board bd{pack4(v0), pack4(v1), pack4(v2), pack4(v3)};
+    const bool was_done = done_in[i] != 0;
+    const bool in_place = boards_in == boards_out && done_in == done_out && step_count_in == step_count_out && total_in == total_out;
     const uint64_t env = env_base + i;
     uint32_t w[4];
     env_block(key, env >> 2, STREAM_STEP, w[0], w[1], w[2], w[3]);
     const uint32_t sel = (uint32_t)env & 3u;
     const uint32_t word = sel == 0u ? w[0] : sel == 1u ? w[1] : sel == 2u ? w[2] : w[3];
     float reward = 0.0f;
+    int32_t steps = step_count_in ? step_count_in[i] : 0;
+    float total = total_in ? total_in[i] : 0.0f;
+    uint8_t done = 1;
     if (!was_done) {
         uint32_t score;
         bool changed;
         afterstate(bd, (uint32_t)actions[i] & 3u, score, changed);
         spawn_tile_word(bd, word, changed);
         reward = (float)score;  // exact: a step's score is < 2^24
-        rows[0] = unpack4(bd.r0);
-        rows[1] = unpack4(bd.r1);
-        rows[2] = unpack4(bd.r2);
-        rows[3] = unpack4(bd.r3);
-        done_io[i] = legal_mask(bd) == 0u ? 1 : 0;
-        if (step_count) step_count[i] += 1;
-        if (total_reward) total_reward[i] += reward;
+        rows_out[0] = unpack4(bd.r0);
+        rows_out[1] = unpack4(bd.r1);
+        rows_out[2] = unpack4(bd.r2);
+        rows_out[3] = unpack4(bd.r3);
+        done = legal_mask(bd) == 0u ? 1 : 0;
+        steps += 1;
+        total += reward;
+    } else if (!in_place) {  // the values as they came in (not re-derived from the packed form)
+        rows_out[0] = v0;
+        rows_out[1] = v1;
+        rows_out[2] = v2;
+        rows_out[3] = v3;
+    }
+    if (!was_done || !in_place) {
+        done_out[i] = done;
+        if (step_count_out) step_count_out[i] = steps;
+        if (total_out) total_out[i] = total;
     }
     reward_out[i] = reward;
     if (max_tile) {
@@ -987,25 +1006,38 @@ int env2048_step(int device, void *stream, uint64_t n, uint64_t env_base, uint8_
     return launched("env2048_step launch");
 }
 
-int env2048_step_state_i32(int device, void *stream, uint64_t n, uint64_t env_base, int32_t *boards, const int32_t *actions,
-                           int32_t *step_count, uint8_t *done_io, float *total_reward, float *reward, int32_t *max_tile,
-                           uint64_t seed, uint64_t step_index)
+int env2048_step_state_i32_to(int device, void *stream, uint64_t n, uint64_t env_base, const int32_t *boards_in,
+                              int32_t *boards_out, const int32_t *actions, const int32_t *step_count_in, int32_t *step_count_out,
+                              const uint8_t *done_in, uint8_t *done_out, const float *total_reward_in, float *total_reward_out,
+                              float *reward, int32_t *max_tile, uint64_t seed, uint64_t step_index)
 {
     if (n == 0) return ENV2048_OK;
-    if (!boards || !actions || !done_io || !reward)
-        return fail(ENV2048_ERR_INVALID_ARG, "env2048_step_state_i32: boards, actions, done_io and reward are required");
-    if (misaligned(boards, 16)) return fail(ENV2048_ERR_ALIGNMENT, "env2048_step_state_i32: boards must be 16-byte aligned");
-    if (misaligned(actions, 4) || misaligned(step_count, 4) || misaligned(total_reward, 4) || misaligned(reward, 4) ||
-        misaligned(max_tile, 4))
+    if (!boards_in || !boards_out || !actions || !done_in || !done_out || !reward)
+        return fail(ENV2048_ERR_INVALID_ARG, "env2048_step_state_i32: boards, actions, done and reward are required");
+    if ((step_count_in == nullptr) != (step_count_out == nullptr) || (total_reward_in == nullptr) != (total_reward_out == nullptr))
+        return fail(ENV2048_ERR_INVALID_ARG, "env2048_step_state_i32: step_count / total_reward need both their in and out array");
+    if (misaligned(boards_in, 16) || misaligned(boards_out, 16))
+        return fail(ENV2048_ERR_ALIGNMENT, "env2048_step_state_i32: boards must be 16-byte aligned");
+    if (misaligned(actions, 4) || misaligned(step_count_in, 4) || misaligned(step_count_out, 4) || misaligned(total_reward_in, 4) ||
+        misaligned(total_reward_out, 4) || misaligned(reward, 4) || misaligned(max_tile, 4))
         return fail(ENV2048_ERR_ALIGNMENT, "env2048_step_state_i32: misaligned 4-byte array");
     if (int rc = check_range(n, env_base)) return rc;
     if (int rc = check_count(n)) return rc;
     DeviceScope scope(device);
     if (scope.rc) return scope.rc;
     const RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)step_index, (uint32_t)(step_index >> 32)};
-    hipLaunchKernelGGL(step_state_i32_kernel, grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, n, env_base, boards, actions,
-                       step_count, done_io, total_reward, reward, max_tile, key);
+    hipLaunchKernelGGL(step_state_i32_kernel, grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, n, env_base, boards_in, boards_out,
+                       actions, step_count_in, step_count_out, done_in, done_out, total_reward_in, total_reward_out, reward,
+                       max_tile, key);
     return launched("env2048_step_state_i32 launch");
+}
+
+int env2048_step_state_i32(int device, void *stream, uint64_t n, uint64_t env_base, int32_t *boards, const int32_t *actions,
+                           int32_t *step_count, uint8_t *done_io, float *total_reward, float *reward, int32_t *max_tile,
+                           uint64_t seed, uint64_t step_index)
+{
+    return env2048_step_state_i32_to(device, stream, n, env_base, boards, boards, actions, step_count, step_count, done_io, done_io,
+                                     total_reward, total_reward, reward, max_tile, seed, step_index);
 }
 
 int env2048_rollout(int device, void *stream, uint64_t n, uint64_t env_base, uint8_t *boards, uint64_t seed,

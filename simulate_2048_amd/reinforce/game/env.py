@@ -51,26 +51,43 @@ def batched_reset(keys) -> GameState:
     )
 
 
+def _dev(x, dtype, n, rt) -> torch.Tensor:
+    """`x` as a contiguous (n,) device tensor of `dtype`; no copy when it already is one."""
+    t = x if isinstance(x, torch.Tensor) else torch.as_tensor(x)
+    if t.dtype != dtype or t.device != rt.device:
+        t = t.to(device=rt.device, dtype=dtype)
+    return t.reshape(n).contiguous()
+
+
 def batched_step(states: GameState, actions, keys):
     """[ref env.py:193-211] one move per environment -> (GameState, reward (N,) f32, done (N,) bool, info).
 
-    One fused kernel (env2048_step_state_i32).  Finished games are frozen exactly like the
-    reference's done-guard (env.py:103-104): state unchanged, reward 0.0, done True, step_count not
-    advanced.  The input state is not modified (functional API): its fields are copied first.
+    One fused, out-of-place kernel (env2048_step_state_i32_to): the input state is only read (functional
+    API) and the new state is written to fresh tensors -- no copies on either side.  Finished games are
+    frozen exactly like the reference's done-guard (env.py:103-104): state unchanged, reward 0.0, done True,
+    step_count not advanced.
     """
     rt = runtime.current()
-    board = _board_tensor(states.board).reshape(-1, 4, 4).clone()
-    n = board.shape[0]
-    step_count = torch.as_tensor(states.step_count).to(device=rt.device, dtype=torch.int32).reshape(n).clone()
-    done_u8 = torch.as_tensor(states.done).to(device=rt.device).reshape(n).to(torch.uint8).contiguous()
-    total = torch.as_tensor(states.total_reward).to(device=rt.device, dtype=torch.float32).reshape(n).clone()
-    acts = torch.as_tensor(actions).reshape(n).to(device=rt.device, dtype=torch.int32).contiguous()
-    reward = torch.empty((n,), dtype=torch.float32, device=rt.device)
-    max_tile = torch.empty((n,), dtype=torch.int32, device=rt.device)
+    board_in = _board_tensor(states.board).reshape(-1, 4, 4)
+    n = board_in.shape[0]
+    steps_in = _dev(states.step_count, torch.int32, n, rt)
+    total_in = _dev(states.total_reward, torch.float32, n, rt)
+    acts = _dev(actions, torch.int32, n, rt)
+    d = states.done if isinstance(states.done, torch.Tensor) else torch.as_tensor(states.done)
+    if d.dtype == torch.bool and d.device == rt.device:
+        done_in = d.reshape(n).contiguous().view(torch.uint8)  # same bytes, no copy
+    else:
+        done_in = _dev(d.to(torch.uint8), torch.uint8, n, rt)
+    board = torch.empty_like(board_in)
+    i32 = torch.empty((2, n), dtype=torch.int32, device=rt.device)   # step_count, max_tile
+    f32 = torch.empty((2, n), dtype=torch.float32, device=rt.device)  # total_reward, reward
+    done_u8 = torch.empty((n,), dtype=torch.uint8, device=rt.device)
+    step_count, max_tile, total, reward = i32[0], i32[1], f32[0], f32[1]
     dev, stream = rt.handles()
-    rt.lib.step_state_i32(dev, stream, n, 0, board.data_ptr(), acts.data_ptr(), step_count.data_ptr(), done_u8.data_ptr(),
-                          total.data_ptr(), reward.data_ptr(), max_tile.data_ptr(), _keys_to_seed(keys), 0)
-    done = done_u8.to(torch.bool)
+    rt.lib.step_state_i32_to(dev, stream, n, 0, board_in.data_ptr(), board.data_ptr(), acts.data_ptr(), steps_in.data_ptr(),
+                             step_count.data_ptr(), done_in.data_ptr(), done_u8.data_ptr(), total_in.data_ptr(), total.data_ptr(),
+                             reward.data_ptr(), max_tile.data_ptr(), _keys_to_seed(keys), 0)
+    done = done_u8.view(torch.bool)
     new_state = GameState(board=board, step_count=step_count, done=done, total_reward=total)
     info = {'max_tile': max_tile, 'step_count': step_count, 'total_reward': total}
     return new_state, reward, done, info

@@ -80,6 +80,20 @@ class OracleLibrary:
         if max_tile is not None:
             _view(max_tile, n, np.int32)[:] = res['max_tile']
 
+    def step_state_i32_to(self, device, stream, n, env_base, boards_in, boards_out, actions, step_count_in, step_count_out,
+                          done_in, done_out, total_in, total_out, reward, max_tile, seed, step_index):
+        # copy in -> out, then the in-place form on the outputs (the inputs are never written)
+        if boards_out != boards_in:
+            _view(boards_out, n * 16, np.int32)[:] = _view(boards_in, n * 16, np.int32)
+        if done_out != done_in:
+            _view(done_out, n, np.uint8)[:] = _view(done_in, n, np.uint8)
+        if step_count_out is not None and step_count_out != step_count_in:
+            _view(step_count_out, n, np.int32)[:] = _view(step_count_in, n, np.int32)
+        if total_out is not None and total_out != total_in:
+            _view(total_out, n, np.float32)[:] = _view(total_in, n, np.float32)
+        self.step_state_i32(device, stream, n, env_base, boards_out, actions, step_count_out, done_out, total_out, reward,
+                            max_tile, seed, step_index)
+
     def rollout(self, device, stream, n, env_base, boards, seed, step0, T, return_sum, episodes, valid_moves, flags):
         self.calls.append(('rollout', n))
         b = _view(boards, n * 16, np.uint8)

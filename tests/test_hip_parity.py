@@ -525,6 +525,30 @@ def test_step_state_i32_matches_oracle(lib):
     frozen = done.astype(bool)
     np.testing.assert_array_equal(ref['boards'][frozen], values[frozen])  # the guard really froze them
     assert not ref['reward'][frozen].any()
+    # the functional form: inputs only read, every output written (poisoned first), same results
+    b_in, sc_in, d_in, tr_in = cu(values), cu(step_count), cu(done), cu(total)
+    b_out = torch.full((n, 16), -5, dtype=torch.int32, device='cuda')
+    sc_out = torch.full((n,), -5, dtype=torch.int32, device='cuda')
+    d_out = torch.full((n,), 9, dtype=torch.uint8, device='cuda')
+    tr_out = torch.full((n,), -5.0, dtype=torch.float32, device='cuda')
+    reward.fill_(-1.0)
+    max_tile.fill_(-1)
+    lib.step_state_i32_to(DEV, stream(), n, env_base, p(b_in), p(b_out), p(a), p(sc_in), p(sc_out), p(d_in), p(d_out), p(tr_in),
+                          p(tr_out), p(reward), p(max_tile), seed, step)
+    torch.cuda.synchronize()
+    for got, key in ((b_out, 'boards'), (sc_out, 'step_count'), (d_out, 'done'), (tr_out, 'total_reward'), (reward, 'reward'),
+                     (max_tile, 'max_tile')):
+        np.testing.assert_array_equal(got.cpu().numpy(), ref[key], err_msg='functional ' + key)
+    for got, want in ((b_in, values), (sc_in, step_count), (d_in, done), (tr_in, total)):
+        np.testing.assert_array_equal(got.cpu().numpy().reshape(want.shape), want)  # inputs untouched
+    # optional arrays left out: both of a pair or neither
+    lib.step_state_i32_to(DEV, stream(), n, env_base, p(b_in), p(b_out), p(a), None, None, p(d_in), p(d_out), None, None,
+                          p(reward), None, seed, step)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(b_out.cpu().numpy(), ref['boards'])
+    with pytest.raises(capi.Env2048Error):
+        lib.step_state_i32_to(DEV, stream(), n, env_base, p(b_in), p(b_out), p(a), p(sc_in), None, p(d_in), p(d_out), None, None,
+                              p(reward), None, seed, step)
 
 
 def test_config4_slicing_at_8x2pow20(lib):
