@@ -138,6 +138,17 @@ ENV2048_EXPORT int env2048_step_state_i32_to(int device, void *stream, uint64_t 
                                              int32_t *max_tile, uint64_t seed, uint64_t step_index);
 
 /*
+ * Per-move queries of the reinforce/game callers on int32 tile VALUE boards (n x 16), one launch, each
+ * output optional:
+ *     obs[16*i..]    float32 log2(tile)/16, 0 for empty      (encode_observation, core.py:346-377)
+ *     legal4[4*i+a]  1 iff action a changes board i, else 0  (legal_actions_mask, core.py:275-302)
+ *     done[i]        1 iff no action changes the board       (the JAX is_done, core.py:305-321)
+ * [replaces: reinforce/game/env.py:214-245 batched_get_observation / batched_get_legal_actions]
+ */
+ENV2048_EXPORT int env2048_status_i32(int device, void *stream, uint64_t n, const int32_t *boards, float *obs, uint8_t *legal4,
+                                      uint8_t *done);
+
+/*
  * T consecutive transitions per board, boards held in registers, actions drawn on device
  * (low two bits of each step word): identical to T calls of env2048_step(..., step0 + t,
  * flags | RANDOM_ACTIONS).  Per-environment outputs (each may be NULL):

@@ -41,6 +41,7 @@ PROTOTYPES = {
     'env2048_step_state_i32': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _u64, _u64]),
     'env2048_step_state_i32_to': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _u64,
                                             _u64]),
+    'env2048_status_i32': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr]),
     'env2048_rollout': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _u64, _u64, _u32, _ptr, _ptr, _ptr, _u32]),
     'env2048_afterstate': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr, _ptr]),
     'env2048_spawn': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr]),
@@ -119,6 +120,9 @@ class Library:
         self._check(self._dll.env2048_step_state_i32_to(device, stream, n, env_base, boards_in, boards_out, actions, step_count_in,
                                                         step_count_out, done_in, done_out, total_in, total_out, reward, max_tile,
                                                         seed, step_index))
+
+    def status_i32(self, device, stream, n, boards, obs, legal4, done) -> None:
+        self._check(self._dll.env2048_status_i32(device, stream, n, boards, obs, legal4, done))
 
     def rollout(self, device, stream, n, env_base, boards, seed, step0, T, return_sum, episodes, valid_moves,
                 flags) -> None:

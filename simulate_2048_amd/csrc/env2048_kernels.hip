@@ -634,6 +634,24 @@ __global__ __launch_bounds__(BLOCK) void step_state_i32_kernel(uint64_t n, uint6
     }
 }
 
+// What the reinforce/game callers ask about a batch of int32 value boards, in one launch: the f32
+// observation, the legal-action mask as four 0/1 BYTES per board (a torch/NumPy bool array) and the
+// JAX-flavoured done flag ("no action changes the board").
+__global__ __launch_bounds__(BLOCK) void status_i32_kernel(uint64_t n, const int32_t *boards, float *obs, uint32_t *legal4,
+                                                           uint8_t *done)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int4 *rows = reinterpret_cast<const int4 *>(boards) + 4 * i;
+    const Board bd{pack4(rows[0]), pack4(rows[1]), pack4(rows[2]), pack4(rows[3])};
+    if (obs) store_obs(obs, i, bd);
+    if (legal4 || done) {
+        const uint32_t bits = legal_mask(bd);
+        if (legal4) legal4[i] = (bits & 1u) | ((bits & 2u) << 7) | ((bits & 4u) << 14) | ((bits & 8u) << 21);
+        if (done) done[i] = bits == 0u ? 1 : 0;
+    }
+}
+
 __global__ __launch_bounds__(BLOCK) void afterstate_kernel(uint64_t n, const uint8_t *boards_in,
                                                            const uint8_t *actions, uint8_t *boards_out,
                                                            int32_t *reward, uint8_t *changed_out)
@@ -1038,6 +1056,20 @@ int env2048_step_state_i32(int device, void *stream, uint64_t n, uint64_t env_ba
 {
     return env2048_step_state_i32_to(device, stream, n, env_base, boards, boards, actions, step_count, step_count, done_io, done_io,
                                      total_reward, total_reward, reward, max_tile, seed, step_index);
+}
+
+int env2048_status_i32(int device, void *stream, uint64_t n, const int32_t *boards, float *obs, uint8_t *legal4, uint8_t *done)
+{
+    if (n == 0) return ENV2048_OK;
+    if (!boards) return fail(ENV2048_ERR_INVALID_ARG, "env2048_status_i32: boards is NULL");
+    if (misaligned(boards, 16) || misaligned(obs, 16) || misaligned(legal4, 4))
+        return fail(ENV2048_ERR_ALIGNMENT, "env2048_status_i32: boards/obs must be 16-byte, legal4 4-byte aligned");
+    if (int rc = check_count(n)) return rc;
+    DeviceScope scope(device);
+    if (scope.rc) return scope.rc;
+    hipLaunchKernelGGL(status_i32_kernel, grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, n, boards, obs,
+                       reinterpret_cast<uint32_t *>(legal4), done);
+    return launched("env2048_status_i32 launch");
 }
 
 int env2048_rollout(int device, void *stream, uint64_t n, uint64_t env_base, uint8_t *boards, uint64_t seed,

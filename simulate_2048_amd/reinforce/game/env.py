@@ -94,16 +94,25 @@ def batched_step(states: GameState, actions, keys):
 
 
 def batched_get_observation(states: GameState) -> torch.Tensor:
-    """[ref env.py:214-228] (N, 16) float32 log2/16 observations."""
+    """[ref env.py:214-228] (N, 16) float32 log2/16 observations -- one kernel on the int32 boards."""
+    rt = runtime.current()
     boards = _board_tensor(states.board).reshape(-1, 16)
-    return ops.status(ops.pack(boards), done=False, legal=False, obs=True)['obs']
+    n = boards.shape[0]
+    obs = torch.empty((n, 16), dtype=torch.float32, device=rt.device)
+    dev, stream = rt.handles()
+    rt.lib.status_i32(dev, stream, n, boards.data_ptr(), obs.data_ptr(), None, None)
+    return obs
 
 
 def batched_get_legal_actions(states: GameState) -> torch.Tensor:
-    """[ref env.py:231-245] (N, 4) bool legal-action masks."""
+    """[ref env.py:231-245] (N, 4) bool legal-action masks -- one kernel, written as bool bytes."""
+    rt = runtime.current()
     boards = _board_tensor(states.board).reshape(-1, 16)
-    bits = ops.status(ops.pack(boards), done=False, legal=True)['legal'].to(torch.int32)
-    return ((bits.unsqueeze(1) >> torch.arange(4, device=bits.device, dtype=torch.int32)) & 1).to(torch.bool)
+    n = boards.shape[0]
+    legal = torch.empty((n, 4), dtype=torch.uint8, device=rt.device)
+    dev, stream = rt.handles()
+    rt.lib.status_i32(dev, stream, n, boards.data_ptr(), None, legal.data_ptr(), None)
+    return legal.view(torch.bool)
 
 
 def _squeeze(state: GameState) -> GameState:

@@ -136,6 +136,16 @@ class OracleLibrary:
             if ptr is not None:
                 _view(ptr, n * width, dtype)[:] = res[key].reshape(-1)
 
+    def status_i32(self, device, stream, n, boards, obs, legal4, done):
+        self.calls.append(('status_i32', n))
+        res = oracle.status_batch(oracle.pack_values(_view(boards, n * 16, np.int32)).reshape(n, 16))
+        if obs is not None:
+            _view(obs, n * 16, np.float32)[:] = res['obs'].reshape(-1)
+        if legal4 is not None:
+            _view(legal4, n * 4, np.uint8)[:] = ((res['legal'][:, None] >> np.arange(4)) & 1).astype(np.uint8).reshape(-1)
+        if done is not None:
+            _view(done, n, np.uint8)[:] = (res['legal'] == 0).astype(np.uint8)  # JAX is_done: no legal action
+
     def chance_outcomes(self, device, stream, n, boards, out_boards, out_prob, out_count):
         self.calls.append(('chance_outcomes', n))
         res = oracle.chance_outcomes(_view(boards, n * 16, np.uint8).reshape(n, 16).copy())

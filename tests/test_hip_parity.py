@@ -551,6 +551,30 @@ def test_step_state_i32_matches_oracle(lib):
                               p(reward), None, seed, step)
 
 
+def test_status_i32_matches_oracle(lib):
+    """obs / (n,4) legal bytes / JAX done on int32 value boards, every output optional."""
+    rng = np.random.default_rng(12)
+    n = 20_011
+    exps = random_boards(rng, n)
+    values = oracle.unpack_values(exps).astype(np.int32)
+    ref = oracle.status_batch(exps)
+    want_legal = ((ref['legal'][:, None] >> np.arange(4)) & 1).astype(np.uint8)
+    b = cu(values)
+    obs = torch.full((n, 16), -1.0, dtype=torch.float32, device='cuda')
+    legal = torch.full((n, 4), 9, dtype=torch.uint8, device='cuda')
+    done = torch.full((n,), 9, dtype=torch.uint8, device='cuda')
+    lib.status_i32(DEV, stream(), n, p(b), p(obs), p(legal), p(done))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(obs.cpu().numpy(), ref['obs'])
+    np.testing.assert_array_equal(legal.cpu().numpy(), want_legal)
+    np.testing.assert_array_equal(done.cpu().numpy(), (ref['legal'] == 0).astype(np.uint8))
+    assert bool(legal.view(torch.bool).cpu().numpy()[5].tolist() == want_legal[5].astype(bool).tolist())
+    legal.fill_(9)
+    lib.status_i32(DEV, stream(), n, p(b), None, p(legal), None)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(legal.cpu().numpy(), want_legal)
+
+
 def test_config4_slicing_at_8x2pow20(lib):
     """BASELINE config 4 on one GPU: 8 388 608 boards stepped as 8 contiguous slices (what 8 ranks would
     do, each with env_base = its slice start) equal the unsliced batch -- boards, rewards and done flags."""

@@ -46,6 +46,10 @@ for nn in (8, 1 << 20):
     acts = torch.randint(0, 4, (nn,), dtype=torch.int32).cuda()
     dt = per_call(lambda: genv.batched_step(st, acts, keys), 200)
     out[f'N2_batched_step_n{nn}'] = {'us_per_call': dt * 1e6, 'board_steps_per_s': nn / dt}
+    dt = per_call(lambda: genv.batched_get_observation(st), 200)
+    out[f'N2_batched_get_observation_n{nn}'] = {'us_per_call': dt * 1e6}
+    dt = per_call(lambda: genv.batched_get_legal_actions(st), 200)
+    out[f'N2_batched_get_legal_actions_n{nn}'] = {'us_per_call': dt * 1e6}
 
 # N3: all chance outcomes of 2^18 afterstates (512 B out per board)
 e = BatchedEnv2048(1 << 18, 2, device='cuda:0', auto_reset=True)
