@@ -80,12 +80,21 @@ def cpu_baseline(boards_np, seconds: float):
         elapsed = time.perf_counter() - t0
         if elapsed >= seconds or steps >= 100_000:
             break
+    # the same loop on ONE thread for ~2 s, quoted in the sample text (per-core figure next to the reference's)
+    single_steps, t1 = 0, time.perf_counter()
+    while threads > 1:
+        oracle.step_batch_inplace(boards, actions, reward, done, SEED, 500_000 + single_steps, flags=1, threads=1)
+        single_steps += 1
+        single_elapsed = time.perf_counter() - t1
+        if single_elapsed >= 2.0:
+            break
+    single = f'; 1 thread: {n * single_steps / single_elapsed:.2e} steps/s' if single_steps else ''
     return {
         'value': n * steps / elapsed,
         'unit': 'board-steps/s',
         'cores': threads,
         'kind': 'port',
-        'sample': f'{steps} steps x {n} boards (same mid-game boards, auto-reset, host uint8 actions) in {elapsed:.1f} s; '
+        'sample': f'{steps} steps x {n} boards (same mid-game boards, auto-reset, host uint8 actions) in {elapsed:.1f} s{single}; '
                   f'oracle/env2048_oracle.c, gcc -O2 -fopenmp; reference NumPy engine itself: ~1.0e4 steps/s/core (BASELINE.md)',
     }
 
