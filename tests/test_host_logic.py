@@ -32,6 +32,32 @@ def test_library_exports_every_declared_symbol():
     assert f'#define ENV2048_ABI_VERSION {capi.ABI_VERSION}' in header
 
 
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """The boundary is a C-ABI: include/env2048.h compiles as strict C99 and as C++, and a C program linked
+    against libenv2048.so reaches the non-compute entry points (argument validation needs no GPU)."""
+    src = tmp_path / 'abi.c'
+    src.write_text(
+        '#include <stdio.h>\n#include <string.h>\n#include "env2048.h"\n'
+        'int main(void) {\n'
+        '  if (env2048_abi_version() != ENV2048_ABI_VERSION) return 1;\n'
+        '  /* a NULL board pointer is refused before any device is touched */\n'
+        '  int rc = env2048_step(0, NULL, 4, 0, NULL, NULL, NULL, NULL, NULL, NULL, 1, 0, ENV2048_FLAG_AUTO_RESET);\n'
+        '  if (rc != ENV2048_ERR_INVALID_ARG) return 2;\n'
+        '  if (strlen(env2048_last_error()) == 0) return 3;\n'
+        '  if (env2048_step(0, NULL, 0, 0, NULL, NULL, NULL, NULL, NULL, NULL, 1, 0, 0) != ENV2048_OK) return 4; /* n = 0: no-op */\n'
+        '  puts("ok");\n  return 0;\n}\n')
+    inc = str(REPO / 'include')
+    subprocess.run(['gcc', '-std=c99', '-Wall', '-Wextra', '-pedantic', '-Werror', f'-I{inc}', '-fsyntax-only', str(src)], check=True)
+    subprocess.run(['g++', '-std=c++11', '-Wall', '-Wextra', '-pedantic', '-Werror', f'-I{inc}', '-x', 'c++', '-fsyntax-only', str(src)],
+                   check=True)
+    exe = tmp_path / 'abi'
+    lib_dir = str(capi.LIB_PATH.parent)
+    subprocess.run(['gcc', '-std=c99', f'-I{inc}', str(src), f'-L{lib_dir}', '-lenv2048', f'-Wl,-rpath,{lib_dir}', '-o', str(exe)],
+                   check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip() == 'ok', (out.returncode, out.stdout, out.stderr)
+
+
 @pytest.mark.skipif(torch.cuda.is_available(), reason='checks the behaviour on a machine WITHOUT a GPU')
 def test_product_fails_loudly_without_gpu():
     lib = capi.Library()
