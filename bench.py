@@ -49,7 +49,8 @@ def parse_args():
                     'launches on separate streams inside the graph (experiment; 1 = one launch per step)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='target duration of the CPU baseline sample')
-    ap.add_argument('--extras', action='store_true', help='also emit legal mask + f32 obs (not the headline)')
+    ap.add_argument('--extras', action='store_true', help='also emit legal mask + obs (not the headline)')
+    ap.add_argument('--obs-dtype', choices=['f32', 'f16', 'bf16'], default='f32', help='with --extras: element type of obs')
     ap.add_argument('--dist-backend', default='nccl', help="'nccl' (= RCCL, one GPU per rank); 'gloo' only to rehearse the "
                     'multi-rank logic on a single-GPU box (all ranks then share device 0)')
     return ap.parse_args()
@@ -158,8 +159,10 @@ def main():
 
     n = args.boards
     K, W = args.steps, args.warmup
+    obs_bytes = 4 if args.obs_dtype == 'f32' else 2
+    obs_dtype = {'f32': torch.float32, 'f16': torch.float16, 'bf16': torch.bfloat16}[args.obs_dtype]
     env = BatchedEnv2048(n, SEED, device=device, env_base=rank * n, auto_reset=True, with_legal=args.extras,
-                         with_obs=args.extras)
+                         with_obs=args.extras, obs_dtype=obs_dtype)
     env.reset()
     for _ in range(64):  # bring the boards to mid-game
         env.step(None)
@@ -184,7 +187,7 @@ def main():
 
     def launch(step_index: int, stream_handle):
         rc = step_fn(device_index, stream_handle, n, env_base, fixed['boards'], action_ptrs[step_index & 7], fixed['reward'],
-                     fixed['done'], fixed['legal'], fixed['obs'], SEED, step_index, capi.FLAG_AUTO_RESET)
+                     fixed['done'], fixed['legal'], fixed['obs'], SEED, step_index, env.flags)
         if rc != 0:
             raise capi.Env2048Error(rc, lib.last_error())
 
@@ -193,8 +196,8 @@ def main():
         cnt = n // parts
         off = lambda p, scale: None if p is None else ctypes.c_void_p(p.value + lo * scale)
         rc = step_fn(device_index, stream_handle, cnt, env_base + lo, off(fixed['boards'], 16), off(action_ptrs[step_index & 7], 1),
-                     off(fixed['reward'], 4), off(fixed['done'], 1), off(fixed['legal'], 1), off(fixed['obs'], 64), SEED,
-                     step_index, capi.FLAG_AUTO_RESET)
+                     off(fixed['reward'], 4), off(fixed['done'], 1), off(fixed['legal'], 1), off(fixed['obs'], 16 * obs_bytes), SEED,
+                     step_index, env.flags)
         if rc != 0:
             raise capi.Env2048Error(rc, lib.last_error())
 
@@ -261,7 +264,7 @@ def main():
         total_steps = float(n) * K * world
         value = total_steps / wall
         launch_s = event_ms * 1e-3 / K
-        bytes_per_launch = ALGO_BYTES_PER_STEP * n + (n * (1 + 64) if args.extras else 0)
+        bytes_per_launch = ALGO_BYTES_PER_STEP * n + (n * (1 + 16 * obs_bytes) if args.extras else 0)
         achieved = bytes_per_launch / launch_s / 1e9
         out = {
             'metric': 'env_board_steps_per_sec',
@@ -283,7 +286,7 @@ def main():
                 'global_boards': n * world,
                 'launch_mode': args.mode,
                 'sharding': 'contiguous env-index slices, one process per GPU, no collective on the hot path',
-                'outputs': 'board,reward,done' + (',legal,obs' if args.extras else ''),
+                'outputs': 'board,reward,done' + (f',legal,obs({args.obs_dtype})' if args.extras else ''),
             },
             'roofline': {
                 'bound': 'hbm',

@@ -68,6 +68,8 @@ extern "C" {
 /* step / rollout flags */
 #define ENV2048_FLAG_AUTO_RESET 1u     /* a board that became terminal is replaced by a fresh one */
 #define ENV2048_FLAG_RANDOM_ACTIONS 2u /* ignore `actions`; use the low two bits of the step word */
+#define ENV2048_FLAG_OBS_F16 4u        /* env2048_step only: `obs` is n x 16 IEEE binary16 instead of float32 */
+#define ENV2048_FLAG_OBS_BF16 8u       /* env2048_step only: `obs` is n x 16 bfloat16 (excludes OBS_F16)      */
 
 ENV2048_EXPORT int env2048_abi_version(void);
 ENV2048_EXPORT const char *env2048_last_error(void);
@@ -97,14 +99,16 @@ ENV2048_EXPORT int env2048_reset(int device, void *stream, uint64_t n, uint64_t 
  * Outputs (each may be NULL except boards/done; `actions` may be NULL only with RANDOM_ACTIONS):
  *     reward[i]  int32 score delta            legal[i]  bit a set <=> action a legal on the
  *     done[i]    0/1                                     board written back
- *     obs[16*i..] float32 log2(tile)/16 of the board written back (0 for empty)
+ *     obs[16*i..] log2(tile)/16 of the board written back (0 for empty): float32, or with
+ *                 ENV2048_FLAG_OBS_F16 / _BF16 the same values as 16-bit floats (e/16, e <= 31, is exact in
+ *                 all three formats) -- half the bytes of the output that bounds the trainer-facing path
  * [replaces: twentyfortyeight/core/gameboard.py:291-325 next_state, :328-348 is_done;
  *            twentyfortyeight/envs/twentyfortyeight.py:106-133 step;
  *            reinforce/game/core.py:234-272 next_state, :275-321 legal_actions_mask/is_done,
  *            :346-377 encode_observation; reinforce/game/env.py:79-133 step, :193-245 batched_*]
  */
 ENV2048_EXPORT int env2048_step(int device, void *stream, uint64_t n, uint64_t env_base, uint8_t *boards,
-                 const uint8_t *actions, int32_t *reward, uint8_t *done, uint8_t *legal, float *obs,
+                 const uint8_t *actions, int32_t *reward, uint8_t *done, uint8_t *legal, void *obs,
                  uint64_t seed, uint64_t step_index, uint32_t flags);
 
 /*

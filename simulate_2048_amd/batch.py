@@ -53,12 +53,18 @@ class BatchedEnv2048:
         Replace a board by a fresh one in the same step in which it became terminal
         (new capability; the reference freezes finished games, reinforce/game/env.py:103-104).
     with_legal, with_obs : bool
-        Also emit the legal-action bitmask / the f32 observation from the step kernel
+        Also emit the legal-action bitmask / the observation from the step kernel
         (what reinforce/training/self_play.py:316-317 asks the env for every move).
+    obs_dtype : torch.float32 | torch.float16 | torch.bfloat16
+        Element type of ``obs``.  The values (log2(tile)/16) are exact in all three; the 16-bit forms halve
+        the output that bounds the step-with-observations path and are what a bf16/fp16 network consumes.
     """
 
+    _OBS_FLAGS = {torch.float32: 0, torch.float16: capi.FLAG_OBS_F16, torch.bfloat16: capi.FLAG_OBS_BF16}
+
+
     def __init__(self, num_envs: int, seed: int = 0, *, device='cuda', env_base: int = 0, auto_reset: bool = False,
-                 with_legal: bool = False, with_obs: bool = False, lib=None):
+                 with_legal: bool = False, with_obs: bool = False, obs_dtype=torch.float32, lib=None):
         self.device = torch.device(device)
         if lib is None:
             if self.device.type != 'cuda':
@@ -79,7 +85,10 @@ class BatchedEnv2048:
         self.reward = torch.zeros((n,), dtype=torch.int32, device=self.device)
         self.done = torch.zeros((n,), dtype=torch.uint8, device=self.device)
         self.legal = torch.zeros((n,), dtype=torch.uint8, device=self.device) if with_legal else None
-        self.obs = torch.zeros((n, 16), dtype=torch.float32, device=self.device) if with_obs else None
+        if obs_dtype not in self._OBS_FLAGS:
+            raise ValueError(f'obs_dtype must be float32, float16 or bfloat16, got {obs_dtype}')
+        self.obs_dtype = obs_dtype
+        self.obs = torch.zeros((n, 16), dtype=obs_dtype, device=self.device) if with_obs else None
         # the persistent buffers never move: keep their addresses (saves ~6 data_ptr() calls per step)
         self._ptr_boards, self._ptr_reward, self._ptr_done = _p(self.boards), _p(self.reward), _p(self.done)
         self._ptr_legal, self._ptr_obs = _p(self.legal), _p(self.obs)
@@ -87,7 +96,7 @@ class BatchedEnv2048:
     # ------------------------------------------------------------------------------------------
     @property
     def flags(self) -> int:
-        return capi.FLAG_AUTO_RESET if self.auto_reset else 0
+        return (capi.FLAG_AUTO_RESET if self.auto_reset else 0) | self._OBS_FLAGS[self.obs_dtype]
 
     def reset(self, step_index: int | None = None) -> torch.Tensor:
         """Fresh boards for the whole batch (two spawned tiles each). Returns ``boards``."""
@@ -98,8 +107,19 @@ class BatchedEnv2048:
                        self.step_index)
         self.reward.zero_()
         if self.legal is not None or self.obs is not None:
-            self.lib.status(dev, stream, self.num_envs, _p(self.boards), None, _p(self.legal), _p(self.obs), None, None)
+            self.describe(self.legal, self.obs)
         return self.boards
+
+    def describe(self, legal: torch.Tensor | None, obs: torch.Tensor | None) -> None:
+        """Legal mask / observation of the CURRENT boards into the given tensors (obs of this env's obs_dtype;
+        the status kernel writes f32, a 16-bit obs is converted from it -- exact)."""
+        dev, stream = _stream_handle(self.device)
+        if obs is None or obs.dtype == torch.float32:
+            self.lib.status(dev, stream, self.num_envs, _p(self.boards), None, _p(legal), _p(obs), None, None)
+            return
+        tmp = torch.empty((self.num_envs, 16), dtype=torch.float32, device=self.device)
+        self.lib.status(dev, stream, self.num_envs, _p(self.boards), None, _p(legal), _p(tmp), None, None)
+        obs.copy_(tmp)
 
     def step(self, actions: torch.Tensor | None = None, *, out_reward=None, out_done=None, out_legal=None, out_obs=None):
         """One transition per board, in place; asynchronous on torch's current stream.
@@ -127,7 +147,7 @@ class BatchedEnv2048:
         reward = self.reward if out_reward is None else self._check_out(out_reward, torch.int32, (self.num_envs,))
         done = self.done if out_done is None else self._check_out(out_done, torch.uint8, (self.num_envs,))
         legal = self.legal if out_legal is None else self._check_out(out_legal, torch.uint8, (self.num_envs,))
-        obs = self.obs if out_obs is None else self._check_out(out_obs, torch.float32, (self.num_envs, 16))
+        obs = self.obs if out_obs is None else self._check_out(out_obs, self.obs_dtype, (self.num_envs, 16))
         self.lib.step(dev, stream, self.num_envs, self.env_base, self._ptr_boards, _p(actions), _p(reward),
                       _p(done), _p(legal), _p(obs), self.seed, self.step_index, flags)
         self.step_index += 1
@@ -148,7 +168,7 @@ class BatchedEnv2048:
         moves = torch.zeros((n,), dtype=torch.int32, device=self.device)
         dev, stream = _stream_handle(self.device)
         self.lib.rollout(dev, stream, n, self.env_base, _p(self.boards), self.seed, self.step_index, int(num_steps),
-                         _p(ret), _p(eps), _p(moves), self.flags | capi.FLAG_RANDOM_ACTIONS)
+                         _p(ret), _p(eps), _p(moves), (capi.FLAG_AUTO_RESET if self.auto_reset else 0) | capi.FLAG_RANDOM_ACTIONS)
         self.step_index += int(num_steps)
         return {'return_sum': ret, 'episodes': eps, 'valid_moves': moves}
 

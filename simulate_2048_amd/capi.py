@@ -23,6 +23,8 @@ ERR_HIP_BASE = -1000
 
 FLAG_AUTO_RESET = 1
 FLAG_RANDOM_ACTIONS = 2
+FLAG_OBS_F16 = 4
+FLAG_OBS_BF16 = 8
 
 LIB_PATH = Path(__file__).resolve().parent / 'lib' / 'libenv2048.so'
 

@@ -107,6 +107,72 @@ __device__ __forceinline__ void store_obs_coalesced(float *obs, uint32_t *strip,
     }
 }
 
+// 16-bit observations (ENV2048_FLAG_OBS_F16 / _BF16): the same values -- e/16 with e <= 31 has five
+// significant bits, exact in both formats -- at half the bytes, which is what bounds the trainer-facing path.
+constexpr uint32_t OBS_F32 = 0u, OBS_BF16 = 2u;  // flags bits 2..3 (1 = f16)
+__device__ __forceinline__ uint32_t obs_format(uint32_t flags) { return (flags >> 2) & 3u; }
+
+__device__ __forceinline__ uint32_t obs_pair16(uint32_t e_lo, uint32_t e_hi, bool bf16)
+{
+    const float a = (float)e_lo * 0.0625f, b = (float)e_hi * 0.0625f;
+    if (bf16) return (__float_as_uint(a) >> 16) | (__float_as_uint(b) & 0xFFFF0000u);  // exact: low 16 bits are zero
+    return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a, b));             // exact: no rounding happens
+}
+__device__ __forceinline__ uint2 obs_row16(uint32_t x, bool bf16)
+{
+    return make_uint2(obs_pair16(x & 0xFFu, (x >> 8) & 0xFFu, bf16), obs_pair16((x >> 16) & 0xFFu, x >> 24, bf16));
+}
+
+__device__ __forceinline__ void store_obs16(void *obs, uint64_t i, const Board &bd, bool bf16)
+{
+    uint4 *o = reinterpret_cast<uint4 *>(obs) + 2 * i;
+    const uint2 r0 = obs_row16(bd.r0, bf16), r1 = obs_row16(bd.r1, bf16), r2 = obs_row16(bd.r2, bf16), r3 = obs_row16(bd.r3, bf16);
+    o[0] = make_uint4(r0.x, r0.y, r1.x, r1.y);
+    o[1] = make_uint4(r2.x, r2.y, r3.x, r3.y);
+}
+
+// The coalesced form for 16-bit observations: a board is 32 B, so a lane reads back TWO row dwords of the
+// strip (rows 2l, 2l+1 of each half) and each of the two store instructions writes 1 KiB contiguous.
+__device__ __forceinline__ void store_obs16_coalesced(void *obs, uint32_t *strip, uint64_t first, uint64_t n, uint32_t lane,
+                                                      const Board &bd, bool skip, bool through, bool bf16)
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    reinterpret_cast<uint4 *>(strip)[lane] = skip ? make_uint4(~0u, ~0u, ~0u, ~0u) : make_uint4(bd.r0, bd.r1, bd.r2, bd.r3);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint4 *out = reinterpret_cast<uint4 *>(obs) + 2 * first;
+#pragma unroll
+    for (uint32_t k = 0; k < 2u; ++k) {
+        const uint2 x = reinterpret_cast<const uint2 *>(strip)[64u * k + lane];
+        const uint64_t board = first + 32u * k + (lane >> 1);
+        if (x.x != ~0u && board < n) {
+            const uint2 lo = obs_row16(x.x, bf16), hi = obs_row16(x.y, bf16);
+            if (through)
+                store_x4_through(out + 64u * k + lane, u32x4{lo.x, lo.y, hi.x, hi.y});
+            else
+                out[64u * k + lane] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+    }
+}
+
+// Observation of one board / of a wave's 64 boards in the format the flags ask for.
+__device__ __forceinline__ void store_obs_any(void *obs, uint64_t i, const Board &bd, uint32_t fmt)
+{
+    if (fmt == OBS_F32)
+        store_obs(reinterpret_cast<float *>(obs), i, bd);
+    else
+        store_obs16(obs, i, bd, fmt == OBS_BF16);
+}
+__device__ __forceinline__ void store_obs_any_coalesced(void *obs, uint32_t *strip, uint64_t first, uint64_t n, uint32_t lane,
+                                                        const Board &bd, bool skip, bool through, uint32_t fmt)
+{
+    if (fmt == OBS_F32)
+        store_obs_coalesced(reinterpret_cast<float *>(obs), strip, first, n, lane, bd, skip, through);
+    else
+        store_obs16_coalesced(obs, strip, first, n, lane, bd, skip, through, fmt == OBS_BF16);
+}
+
 // ------------------------------------------------------------------------------------------
 // Hot kernels: step and rollout.
 //
@@ -150,7 +216,7 @@ struct StepArgs {
     int32_t *reward;
     uint8_t *done;
     uint8_t *legal;
-    float *obs;
+    void *obs;  // f32, or f16 / bf16 with ENV2048_FLAG_OBS_F16 / _BF16
     RngKey key;
     uint32_t flags;
 };
@@ -209,7 +275,7 @@ __device__ __forceinline__ void reset_queued(const StepArgs &a, uint64_t block0,
         store_board(a.boards, i, fresh, through);  // same policy as the step's own stores: no dirty L2 lines left
         if (EXTRAS) {
             if (a.legal) a.legal[i] = (uint8_t)legal_mask(fresh);
-            if (a.obs) store_obs(a.obs, i, fresh);
+            if (a.obs) store_obs_any(a.obs, i, fresh, obs_format(a.flags));
         }
     }
 }
@@ -332,7 +398,7 @@ __device__ __forceinline__ void step_block(const StepArgs &a, uint4 *dir_lds, ui
             } else {
                 store_board(a.boards, i, bd[j], through);
                 if (EXTRAS && a.legal) a.legal[i] = (uint8_t)legal_mask(bd[j]);
-                if (EXTRAS && !FULL && a.obs) store_obs(a.obs, i, bd[j]);
+                if (EXTRAS && !FULL && a.obs) store_obs_any(a.obs, i, bd[j], obs_format(a.flags));
             }
 #if defined(ENV2048_EXP_ABLATE) && (ENV2048_EXP_ABLATE & 4)  // timing-only build: no reward/done stores
             asm volatile("" ::"v"(reward[j]), "v"((uint32_t)done[j]));
@@ -344,7 +410,8 @@ __device__ __forceinline__ void step_block(const StepArgs &a, uint4 *dir_lds, ui
 #endif
         }
         if (EXTRAS && FULL && a.obs)  // (the step words were copied to registers: the strip is free)
-            store_obs_coalesced(a.obs, strip, tile0 + 64u * j, a.n, lane, bd[j], auto_reset && done[j], through);
+            store_obs_any_coalesced(a.obs, strip, tile0 + 64u * j, a.n, lane, bd[j], auto_reset && done[j], through,
+                                    obs_format(a.flags));
     };
 
     // first half: compute only -- its stores wait until the second half's loads are home, so that
@@ -436,7 +503,7 @@ __device__ __forceinline__ void step_block(const StepArgs &a, uint4 *dir_lds, ui
 template <bool EXTRAS, bool RANDOM>
 __global__ __launch_bounds__(BLOCK) void step_kernel(uint8_t *boards, const uint8_t *actions, uint64_t n, uint64_t env_base,
                                                      uint32_t flags, uint32_t seed_lo, uint32_t seed_hi, uint32_t step_lo,
-                                                     uint32_t step_hi, int32_t *reward, uint8_t *done, uint8_t *legal, float *obs)
+                                                     uint32_t step_hi, int32_t *reward, uint8_t *done, uint8_t *legal, void *obs)
 {
     const StepArgs a{n, env_base, boards, actions, reward, done, legal, obs, RngKey{seed_lo, seed_hi, step_lo, step_hi}, flags};
     __shared__ uint4 dir_lds[8];
@@ -980,12 +1047,14 @@ int env2048_reset(int device, void *stream, uint64_t n, uint64_t env_base, uint8
 }
 
 int env2048_step(int device, void *stream, uint64_t n, uint64_t env_base, uint8_t *boards,
-                 const uint8_t *actions, int32_t *reward, uint8_t *done, uint8_t *legal, float *obs,
+                 const uint8_t *actions, int32_t *reward, uint8_t *done, uint8_t *legal, void *obs,
                  uint64_t seed, uint64_t step_index, uint32_t flags)
 {
     if (n == 0) return ENV2048_OK;
-    if (flags & ~(ENV2048_FLAG_AUTO_RESET | ENV2048_FLAG_RANDOM_ACTIONS))
+    if (flags & ~(ENV2048_FLAG_AUTO_RESET | ENV2048_FLAG_RANDOM_ACTIONS | ENV2048_FLAG_OBS_F16 | ENV2048_FLAG_OBS_BF16))
         return fail(ENV2048_ERR_INVALID_ARG, "env2048_step: unknown flag bits 0x%x", flags);
+    if ((flags & ENV2048_FLAG_OBS_F16) && (flags & ENV2048_FLAG_OBS_BF16))
+        return fail(ENV2048_ERR_INVALID_ARG, "env2048_step: OBS_F16 and OBS_BF16 exclude each other");
     if (!boards || !done) return fail(ENV2048_ERR_INVALID_ARG, "env2048_step: boards and done are required");
     if (!actions && !(flags & ENV2048_FLAG_RANDOM_ACTIONS))
         return fail(ENV2048_ERR_INVALID_ARG, "env2048_step: actions is NULL without ENV2048_FLAG_RANDOM_ACTIONS");

@@ -10,7 +10,7 @@ from __future__ import annotations
 
 import torch
 
-from .batch import BatchedEnv2048, _p, _stream_handle
+from .batch import BatchedEnv2048
 
 
 class TrajectoryBuffer:
@@ -18,7 +18,7 @@ class TrajectoryBuffer:
 
     Layout (T = horizon, N = env.num_envs):
         actions (T, N) u8, reward (T, N) i32, done (T, N) u8,
-        legal (T+1, N) u8 and obs (T+1, N, 16) f32  -- row t describes the board the action of step t
+        legal (T+1, N) u8 and obs (T+1, N, 16) of the env's obs_dtype  -- row t describes the board the action of step t
         was chosen on; row T the final boards,
         boards (T+1, N, 16) u8 only with ``record_boards=True`` (one 16 B/board device copy per step).
     """
@@ -32,7 +32,7 @@ class TrajectoryBuffer:
         self.reward = torch.zeros((T, n), dtype=torch.int32, device=dev)
         self.done = torch.zeros((T, n), dtype=torch.uint8, device=dev)
         self.legal = torch.zeros((T + 1, n), dtype=torch.uint8, device=dev) if record_legal else None
-        self.obs = torch.zeros((T + 1, n, 16), dtype=torch.float32, device=dev) if record_obs else None
+        self.obs = torch.zeros((T + 1, n, 16), dtype=env.obs_dtype, device=dev) if record_obs else None
         self.boards = torch.zeros((T + 1, n, 16), dtype=torch.uint8, device=dev) if record_boards else None
         self.t = 0
 
@@ -40,10 +40,7 @@ class TrajectoryBuffer:
         """Describe the CURRENT boards in row 0 (call after env.reset() or whenever a new recording starts)."""
         self.t = 0
         if self.legal is not None or self.obs is not None:
-            dev, stream = _stream_handle(self.env.device)
-            self.env.lib.status(dev, stream, self.env.num_envs, _p(self.env.boards), None,
-                                _p(self.legal[0]) if self.legal is not None else None,
-                                _p(self.obs[0]) if self.obs is not None else None, None, None)
+            self.env.describe(self.legal[0] if self.legal is not None else None, self.obs[0] if self.obs is not None else None)
         if self.boards is not None:
             self.boards[0].copy_(self.env.boards)
 

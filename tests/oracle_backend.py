@@ -50,7 +50,7 @@ class OracleLibrary:
         self.calls.append(('step', n))
         b = _view(boards, n * 16, np.uint8)
         a = None if actions is None else _view(actions, n, np.uint8).copy()
-        res = oracle.step_batch(b.reshape(n, 16), a, seed, step_index, env_base=env_base, flags=flags,
+        res = oracle.step_batch(b.reshape(n, 16), a, seed, step_index, env_base=env_base, flags=flags & 3,
                                 want_legal=legal is not None, want_obs=obs is not None)
         b[:] = res['boards'].reshape(-1)
         if reward is not None:
@@ -59,7 +59,12 @@ class OracleLibrary:
         if legal is not None:
             _view(legal, n, np.uint8)[:] = res['legal']
         if obs is not None:
-            _view(obs, n * 16, np.float32)[:] = res['obs'].reshape(-1)
+            if flags & 4:  # OBS_F16
+                _view(obs, n * 16, np.float16)[:] = res['obs'].reshape(-1).astype(np.float16)
+            elif flags & 8:  # OBS_BF16: the upper half of the (exact) float32
+                _view(obs, n * 16, np.uint16)[:] = (res['obs'].reshape(-1).view(np.uint32) >> 16).astype(np.uint16)
+            else:
+                _view(obs, n * 16, np.float32)[:] = res['obs'].reshape(-1)
 
     def step_state_i32(self, device, stream, n, env_base, boards, actions, step_count, done_io, total_reward, reward, max_tile,
                        seed, step_index):

@@ -257,6 +257,31 @@ def test_step_tile_and_block_edges(lib, n):
                     np.testing.assert_array_equal(got[k], ref[k], err_msg=f'{k} n={n} env_base={env_base} flags={flags}')
 
 
+@pytest.mark.parametrize('obs_flag,torch_dtype', [(capi.FLAG_OBS_F16, torch.float16), (capi.FLAG_OBS_BF16, torch.bfloat16)])
+def test_sixteen_bit_observations(lib, obs_flag, torch_dtype):
+    """ENV2048_FLAG_OBS_F16 / _BF16: bit-identical values to the f32 observation (e/16 is exact in all three),
+    full blocks (LDS-transposed stores), ragged tail (per-lane stores) and rebuilt boards (reset pass)."""
+    rng = np.random.default_rng(31)
+    for n in (2048 * 3, 4999):
+        boards = np.where(rng.random((n, 16)) < 0.06, 0, rng.integers(1, 4, size=(n, 16))).astype(np.uint8)  # many terminal
+        boards[: n // 3] = random_boards(rng, n // 3)  # exponents up to 17
+        actions = rng.integers(0, 4, size=n).astype(np.uint8)
+        for flags in (capi.FLAG_AUTO_RESET, 0):
+            ref = oracle.step_batch(boards, actions, 5, 9, env_base=7, flags=flags, want_legal=True, want_obs=True)
+            b, a = cu(boards), cu(actions)
+            reward = torch.zeros((n,), dtype=torch.int32, device='cuda')
+            done = torch.zeros((n,), dtype=torch.uint8, device='cuda')
+            legal = torch.zeros((n,), dtype=torch.uint8, device='cuda')
+            obs = torch.full((n, 16), -1.0, dtype=torch_dtype, device='cuda')
+            lib.step(DEV, stream(), n, 7, p(b), p(a), p(reward), p(done), p(legal), p(obs), 5, 9, flags | obs_flag)
+            torch.cuda.synchronize()
+            np.testing.assert_array_equal(b.cpu().numpy(), ref['boards'])
+            np.testing.assert_array_equal(legal.cpu().numpy(), ref['legal'])
+            np.testing.assert_array_equal(obs.to(torch.float32).cpu().numpy(), ref['obs'], err_msg=f'n={n} flags={flags}')
+    with pytest.raises(capi.Env2048Error):
+        lib.step(DEV, stream(), n, 7, p(b), p(a), p(reward), p(done), None, p(obs), 5, 9, capi.FLAG_OBS_F16 | capi.FLAG_OBS_BF16)
+
+
 def test_long_random_play_matches_oracle(lib):
     """4096 games x 300 steps with auto-reset: every branch of real play, compared every step."""
     n, T, seed = 4096, 300, 20480

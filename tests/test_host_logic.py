@@ -133,6 +133,26 @@ def test_batched_env_bookkeeping():
     assert [c[0] for c in lib.calls[:3]] == ['reset', 'status', 'step']
 
 
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+def test_batched_env_sixteen_bit_observations(dtype):
+    """obs_dtype: same values (exact), initial observation after reset included, rollout unaffected."""
+    lib = OracleLibrary()
+    env = BatchedEnv2048(130, seed=3, device='cpu', auto_reset=True, with_legal=True, with_obs=True, obs_dtype=dtype, lib=lib)
+    ref = env.reset().numpy().copy()
+    assert env.obs.dtype == dtype
+    np.testing.assert_array_equal(env.obs.to(torch.float32).numpy(), oracle.status_batch(ref)['obs'])
+    for t in range(20):
+        env.step(None)
+        res = oracle.step_batch(ref, None, 3, t, flags=3, want_obs=True)
+        ref = res['boards']
+        np.testing.assert_array_equal(env.obs.to(torch.float32).numpy(), res['obs'])
+    env.rollout(5)
+    with pytest.raises(ValueError):
+        BatchedEnv2048(4, device='cpu', with_obs=True, obs_dtype=torch.float64, lib=lib)
+    with pytest.raises(ValueError):
+        env.step(None, out_obs=torch.zeros((130, 16), dtype=torch.float32))  # wrong dtype for this env
+
+
 def test_shard_range_covers_everything_once():
     for total in (0, 1, 5, 1024, (1 << 20) + 3, 8 << 20):
         for world in (1, 2, 3, 4, 8):

@@ -39,6 +39,16 @@ for name, kw in (('plain', {}), ('legal', {'with_legal': True}), ('legal_obs', {
     nbytes = 38 + (1 if 'legal' in name else 0) + (64 if 'obs' in name else 0)
     out[f'N1_step_{name}'] = {'us_per_step': dt * 1e6, 'GB_per_s': nbytes * n / dt / 1e9, 'bytes_per_board': nbytes}
 
+# N1 with 16-bit observations (f16 / bf16): the same kernel, half the observation bytes
+for name, dt_ in (('f16', torch.float16), ('bf16', torch.bfloat16)):
+    e16 = BatchedEnv2048(n, 7, device='cuda:0', auto_reset=True, with_legal=True, with_obs=True, obs_dtype=dt_)
+    e16.reset()
+    for _ in range(64):
+        e16.step(None)
+    acts16 = torch.randint(0, 4, (n,), dtype=torch.uint8).cuda()
+    dt = per_call(lambda: e16.step(acts16), 300)
+    out[f'N1_step_legal_obs_{name}'] = {'us_per_step': dt * 1e6, 'GB_per_s': (39 + 32) * n / dt / 1e9, 'bytes_per_board': 71}
+
 # N2: reinforce.game batched_step (one fused kernel) at the reference's batch size and at 2^20
 for nn in (8, 1 << 20):
     keys = np.stack([np.zeros(nn, dtype=np.uint32), np.arange(nn, dtype=np.uint32)], axis=1)
