@@ -342,7 +342,7 @@ def test_error_codes(lib):
         lib.step(DEV, stream(), 8, 0, p(b) + 4, p(a), None, p(d), None, None, 0, 0, 0)
     assert e.value.code == capi.ERR_ALIGNMENT
     with pytest.raises(capi.Env2048Error) as e:
-        lib.step(DEV, stream(), 8, 0, p(b), p(a), None, p(d), None, None, 0, 0, 8)
+        lib.step(DEV, stream(), 8, 0, p(b), p(a), None, p(d), None, None, 0, 0, 0x100)  # unknown flag bit
     assert e.value.code == capi.ERR_INVALID_ARG
     with pytest.raises(capi.Env2048Error) as e:
         lib.step(99, stream(), 8, 0, p(b), p(a), None, p(d), None, None, 0, 0, 0)
