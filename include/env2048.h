@@ -175,6 +175,17 @@ ENV2048_EXPORT int env2048_afterstate(int device, void *stream, uint64_t n, cons
                        uint8_t *boards_out, int32_t *reward, uint8_t *changed);
 
 /*
+ * Afterstates of all four actions of every board in one launch -- the expansion step of a tree search over
+ * the true environment: out_boards[4*i + a] = slide+merge(boards[i], a), out_reward[4*i + a] its merge score,
+ * out_legal[i] bit a set <=> action a changes the board (out_reward / out_legal may be NULL).  Together with
+ * env2048_chance_outcomes on the 4n afterstates this enumerates a full expectimax ply.
+ * [replaces: one latent_state call per (board, action), twentyfortyeight/core/gameboard.py:105-129, and
+ *            legal_actions_mask, gamemove.py:45-83]
+ */
+ENV2048_EXPORT int env2048_afterstates4(int device, void *stream, uint64_t n, const uint8_t *boards, uint8_t *out_boards,
+                                        int32_t *out_reward, uint8_t *out_legal);
+
+/*
  * Chance half of a move with the outcome given by the caller: put exponent spawn_e[i] into the
  * spawn_k[i]-th empty cell (row-major).  placed[i] (may be NULL) = flat cell index, or 0xFF when
  * spawn_k[i] >= number of empty cells (board unchanged).

@@ -46,6 +46,7 @@ PROTOTYPES = {
     'env2048_status_i32': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr]),
     'env2048_rollout': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _u64, _u64, _u32, _ptr, _ptr, _ptr, _u32]),
     'env2048_afterstate': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    'env2048_afterstates4': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr]),
     'env2048_spawn': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr]),
     'env2048_spawn_random': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _u64, _u64, _u32]),
     'env2048_chance_outcomes': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr]),
@@ -133,6 +134,9 @@ class Library:
 
     def afterstate(self, device, stream, n, boards_in, actions, boards_out, reward, changed) -> None:
         self._check(self._dll.env2048_afterstate(device, stream, n, boards_in, actions, boards_out, reward, changed))
+
+    def afterstates4(self, device, stream, n, boards, out_boards, out_reward, out_legal) -> None:
+        self._check(self._dll.env2048_afterstates4(device, stream, n, boards, out_boards, out_reward, out_legal))
 
     def spawn(self, device, stream, n, boards, spawn_k, spawn_e, placed) -> None:
         self._check(self._dll.env2048_spawn(device, stream, n, boards, spawn_k, spawn_e, placed))

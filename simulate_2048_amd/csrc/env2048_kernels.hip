@@ -734,6 +734,52 @@ __global__ __launch_bounds__(BLOCK) void afterstate_kernel(uint64_t n, const uin
     if (changed_out) changed_out[i] = changed ? 1 : 0;
 }
 
+// Afterstates of ALL four actions of every board (the expansion step of a search): the byte transpose is
+// computed once, up/down slide the row dwords as planes, left/right the transposed ones, and the two
+// directions of an axis differ only in the order the planes are handed to slide_merge_planes.
+// out_boards[4*i + a], out_reward[4*i + a]; out_legal[i] bit a = action a changes the board.
+__global__ __launch_bounds__(BLOCK) void afterstates4_kernel(uint64_t n, const uint8_t *boards, uint8_t *out_boards,
+                                                             int32_t *out_reward, uint8_t *out_legal)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const Board bd = load_board(boards, i);
+    uint32_t c0, c1, c2, c3;
+    transpose4x4(bd.r0, bd.r1, bd.r2, bd.r3, c0, c1, c2, c3);
+    uint32_t legal = 0u;
+    int4 rewards;
+    {  // 0 = left: planes are the columns, wall side first
+        uint32_t a = c0, b = c1, c = c2, d = c3, changed;
+        rewards.x = (int32_t)slide_merge_planes(a, b, c, d, changed);
+        Board out;
+        transpose4x4(a, b, c, d, out.r0, out.r1, out.r2, out.r3);
+        store_board(out_boards, 4 * i + 0, out);
+        legal |= changed != 0u ? 1u : 0u;
+    }
+    {  // 1 = up: planes are the rows
+        uint32_t a = bd.r0, b = bd.r1, c = bd.r2, d = bd.r3, changed;
+        rewards.y = (int32_t)slide_merge_planes(a, b, c, d, changed);
+        store_board(out_boards, 4 * i + 1, Board{a, b, c, d});
+        legal |= changed != 0u ? 2u : 0u;
+    }
+    {  // 2 = right: columns, last column is the wall
+        uint32_t a = c3, b = c2, c = c1, d = c0, changed;
+        rewards.z = (int32_t)slide_merge_planes(a, b, c, d, changed);
+        Board out;
+        transpose4x4(d, c, b, a, out.r0, out.r1, out.r2, out.r3);
+        store_board(out_boards, 4 * i + 2, out);
+        legal |= changed != 0u ? 4u : 0u;
+    }
+    {  // 3 = down: rows, last row is the wall
+        uint32_t a = bd.r3, b = bd.r2, c = bd.r1, d = bd.r0, changed;
+        rewards.w = (int32_t)slide_merge_planes(a, b, c, d, changed);
+        store_board(out_boards, 4 * i + 3, Board{d, c, b, a});
+        legal |= changed != 0u ? 8u : 0u;
+    }
+    if (out_reward) reinterpret_cast<int4 *>(out_reward)[i] = rewards;
+    if (out_legal) out_legal[i] = (uint8_t)legal;
+}
+
 __global__ __launch_bounds__(BLOCK) void spawn_kernel(uint64_t n, uint8_t *boards, const uint8_t *spawn_k,
                                                       const uint8_t *spawn_e, uint8_t *placed)
 {
@@ -1178,6 +1224,21 @@ int env2048_afterstate(int device, void *stream, uint64_t n, const uint8_t *boar
     hipLaunchKernelGGL(afterstate_kernel, grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, n, boards_in, actions,
                        boards_out, reward, changed);
     return launched("env2048_afterstate launch");
+}
+
+int env2048_afterstates4(int device, void *stream, uint64_t n, const uint8_t *boards, uint8_t *out_boards, int32_t *out_reward,
+                         uint8_t *out_legal)
+{
+    if (n == 0) return ENV2048_OK;
+    if (!boards || !out_boards) return fail(ENV2048_ERR_INVALID_ARG, "env2048_afterstates4: boards and out_boards are required");
+    if (misaligned(boards, 16) || misaligned(out_boards, 16) || misaligned(out_reward, 16))
+        return fail(ENV2048_ERR_ALIGNMENT, "env2048_afterstates4: boards, out_boards and out_reward must be 16-byte aligned");
+    if (int rc = check_count(4 * n)) return rc;
+    DeviceScope scope(device);
+    if (scope.rc) return scope.rc;
+    hipLaunchKernelGGL(afterstates4_kernel, grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, n, boards, out_boards, out_reward,
+                       out_legal);
+    return launched("env2048_afterstates4 launch");
 }
 
 int env2048_spawn(int device, void *stream, uint64_t n, uint8_t *boards, const uint8_t *spawn_k,

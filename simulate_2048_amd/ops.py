@@ -61,6 +61,18 @@ def afterstate(boards: torch.Tensor, actions, rt=None):
     return out, reward, changed
 
 
+def afterstates4(boards: torch.Tensor, rt=None):
+    """Afterstates of all four actions: (boards (n,4,16) uint8, reward (n,4) int32, legal bitmask (n,) uint8)."""
+    rt = rt or runtime.current()
+    n = boards.shape[0]
+    out = torch.empty((n, 4, 16), dtype=torch.uint8, device=rt.device)
+    reward = torch.empty((n, 4), dtype=torch.int32, device=rt.device)
+    legal = torch.empty((n,), dtype=torch.uint8, device=rt.device)
+    dev, stream = rt.handles()
+    rt.lib.afterstates4(dev, stream, n, _p(boards), _p(out), _p(reward), _p(legal))
+    return out, reward, legal
+
+
 def spawn(boards: torch.Tensor, spawn_k, spawn_e, rt=None) -> torch.Tensor:
     """In place: exponent spawn_e[i] into the spawn_k[i]-th empty cell. Returns placed (uint8, 255 = none)."""
     rt = rt or runtime.current()

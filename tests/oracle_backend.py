@@ -120,6 +120,20 @@ class OracleLibrary:
         if changed is not None:
             _view(changed, n, np.uint8)[:] = res['changed']
 
+    def afterstates4(self, device, stream, n, boards, out_boards, out_reward, out_legal):
+        self.calls.append(('afterstates4', n))
+        b = _view(boards, n * 16, np.uint8).reshape(n, 16).copy()
+        legal = np.zeros(n, dtype=np.uint8)
+        ob = _view(out_boards, n * 64, np.uint8).reshape(n, 4, 16)
+        for a in range(4):
+            res = oracle.afterstate_batch(b, np.full(n, a, dtype=np.uint8))
+            ob[:, a] = res['boards']
+            if out_reward is not None:
+                _view(out_reward, n * 4, np.int32).reshape(n, 4)[:, a] = res['reward']
+            legal |= (res['changed'] << a).astype(np.uint8)
+        if out_legal is not None:
+            _view(out_legal, n, np.uint8)[:] = legal
+
     def spawn(self, device, stream, n, boards, spawn_k, spawn_e, placed):
         self.calls.append(('spawn', n))
         b = _view(boards, n * 16, np.uint8)

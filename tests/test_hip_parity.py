@@ -166,6 +166,16 @@ def test_afterstates_golden(lib, golden):
         np.testing.assert_array_equal(res['boards'], g['after'][:, a])
         np.testing.assert_array_equal(res['reward'], g['reward'][:, a])
         np.testing.assert_array_equal(res['changed'], g['valid'][:, a])
+    # all four afterstates in one launch (the reference's latent_state per action / legal_actions_mask)
+    b = cu(boards)
+    out4 = torch.full((n, 4, 16), 99, dtype=torch.uint8, device='cuda')
+    reward4 = torch.full((n, 4), -1, dtype=torch.int32, device='cuda')
+    legal4 = torch.full((n,), 99, dtype=torch.uint8, device='cuda')
+    lib.afterstates4(DEV, stream(), n, p(b), p(out4), p(reward4), p(legal4))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(out4.cpu().numpy(), g['after'])
+    np.testing.assert_array_equal(reward4.cpu().numpy(), g['reward'])
+    np.testing.assert_array_equal(legal4.cpu().numpy(), g['legal'])
     st = hip_status(lib, boards)
     np.testing.assert_array_equal(st['legal'], g['legal'])
     np.testing.assert_array_equal(st['done'], g['done'])
@@ -443,6 +453,27 @@ def test_spawn_and_status_every_occupancy(lib):
         for key in ('done', 'legal', 'n_empty', 'max_exp'):
             np.testing.assert_array_equal(got[key], ref[key], err_msg=f'{key} [{lo},{hi}]')
         np.testing.assert_array_equal(got['obs'], ref['obs'])
+
+
+def test_afterstates4_matches_oracle_random_boards(lib):
+    rng = np.random.default_rng(41)
+    n = 30_011
+    boards = random_boards(rng, n)
+    b = cu(boards)
+    out4 = torch.zeros((n, 4, 16), dtype=torch.uint8, device='cuda')
+    reward4 = torch.zeros((n, 4), dtype=torch.int32, device='cuda')
+    legal4 = torch.zeros((n,), dtype=torch.uint8, device='cuda')
+    lib.afterstates4(DEV, stream(), n, p(b), p(out4), p(reward4), p(legal4))
+    torch.cuda.synchronize()
+    legal = np.zeros(n, dtype=np.uint8)
+    for a in range(4):
+        ref = oracle.afterstate_batch(boards, np.full(n, a, dtype=np.uint8))
+        np.testing.assert_array_equal(out4.cpu().numpy()[:, a], ref['boards'], err_msg=f'action {a}')
+        np.testing.assert_array_equal(reward4.cpu().numpy()[:, a], ref['reward'])
+        legal |= (ref['changed'] << a).astype(np.uint8)
+    np.testing.assert_array_equal(legal4.cpu().numpy(), legal)
+    np.testing.assert_array_equal(legal, oracle.status_batch(boards)['legal'])
+    np.testing.assert_array_equal(b.cpu().numpy(), boards)  # input untouched
 
 
 def test_chance_outcomes_match_oracle(lib, golden):

@@ -68,6 +68,9 @@ e.rollout(80)
 dt = per_call(lambda: ops.chance_outcomes(e.boards), 50)
 out['N3_chance_outcomes_2^18'] = {'us_per_call': dt * 1e6, 'boards_per_s': (1 << 18) / dt, 'GB_per_s': (16 + 512 + 128 + 1) * (1 << 18) / dt / 1e9}
 
+dt = per_call(lambda: ops.afterstates4(e.boards), 50)
+out['N3_afterstates4_2^18'] = {'us_per_call': dt * 1e6, 'boards_per_s': (1 << 18) / dt, 'GB_per_s': (16 + 64 + 16 + 1) * (1 << 18) / dt / 1e9}
+
 # N4: trajectory recording (legal+obs rows written by the kernel) and the one-hot transform
 e = BatchedEnv2048(n, 3, device='cuda:0', auto_reset=True)
 e.reset()
