@@ -3,18 +3,30 @@
 bench.py -- env board-steps/s of the MI355X-native batched 2048 environment.
 
     python bench.py --gpus N --steps K --warmup W
+
+With N > 1 and no torchrun environment the script starts N fresh worker processes itself (one per
+GPU, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set, rendezvous on 127.0.0.1) and relays rank 0's JSON
+line; the parent never touches a GPU.  It can also be started the classic way:
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A "step" is ONE pass of the hot path over one batch: one env2048_step launch over every board of
 this rank's slice (slide/merge, reward, Philox spawn, terminal check, auto-reset), reading host-
-provided uint8 actions from HBM.  Workload = BASELINE.json configs[2]: 1 048 576 boards per GPU
-(weak scaling: every GPU owns a contiguous slice of 2^20 global environment indices, no collective
-on the hot path), boards brought to mid-game by 64 random warm-up steps.
+provided uint8 actions from HBM.  Workload = BASELINE.json configs[2]: 2^20 boards per GPU (weak
+scaling: every GPU owns a contiguous slice of global environment indices, no collective on the hot
+path), boards brought to mid-game by 64 random warm-up steps.
 
-Timed region: barrier + torch.cuda.synchronize() | K launches | torch.cuda.synchronize() + barrier;
-value = boards stepped by all ranks / max-over-ranks wall time.  The roofline object prices the
-step kernel's ALGORITHMIC bytes (38 B per board-step) against its average launch
-duration measured with HIP events on the launch stream over the same timed region.
+Timed region (one "block"): barrier + torch.cuda.synchronize() | K launches enqueued from C by ONE
+env2048_step_sequence call | torch.cuda.synchronize().  A block of K = 20 steps lasts 0.2 ms, so the
+block is repeated R times (>= --min-ms of GPU time in total); every block is timed on its own (wall
+clock and HIP events on the launch stream), the per-block MAX over ranks is taken, and the MEDIAN
+block gives `value` / `ms_per_step` (min and spread are reported next to it).
+
+The roofline object says what bounds the dominant kernel AT THIS SIZE: at 2^20 boards the working
+set (16 MiB boards + action pool + outputs) lives in the 256 MiB Infinity Cache and the kernel is
+VALU-issue-bound, so `bound` is "valu" and `hbm_resident_equiv` only restates the algorithmic bytes
+over the launch time.  `hbm_cold` is a second timed leg in the same run that defeats cache
+residency at the same launch size (round-robin over enough disjoint buffer sets to exceed twice the
+Infinity Cache): that one is a real HBM fraction.
 
 Prints exactly one JSON line on rank 0.
 """
@@ -23,8 +35,13 @@ from __future__ import annotations
 
 import argparse
 import ctypes
+import hashlib
 import json
+import math
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -34,26 +51,109 @@ sys.path.insert(0, str(REPO))
 
 ALGO_BYTES_PER_STEP = 38  # 16 board in + 1 action in + 16 board out + 4 reward out + 1 done out
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling ~6290
+INFINITY_CACHE_BYTES = 256 << 20
+# VALU issue ceiling: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles per SIMD, 2.4 GHz peak clock
+VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 4
 SEED = 0x2048
+KERNEL_SOURCES = ['simulate_2048_amd/csrc/env2048_kernels.hip', 'simulate_2048_amd/csrc/board_ops.hpp']
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=2000)
     ap.add_argument('--warmup', type=int, default=100)
     ap.add_argument('--boards', type=int, default=1 << 20, help='boards per GPU')
-    ap.add_argument('--mode', choices=['eager', 'graph'], default='eager',
-                    help='eager: one C-ABI call per step; graph: the K launches captured once in a hipGraph')
-    ap.add_argument('--chains', type=int, default=1, help='graph mode only: cut the slice into this many independent chains of '
-                    'launches on separate streams inside the graph (experiment; 1 = one launch per step)')
+    ap.add_argument('--min-ms', type=float, default=60.0, help='repeat the K-step block until this much GPU time is covered')
+    ap.add_argument('--max-blocks', type=int, default=400)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='target duration of the CPU baseline sample')
+    ap.add_argument('--no-cold', action='store_true', help='skip the HBM-cold leg')
+    ap.add_argument('--only-cold', action='store_true', help='profiling aid: run ONLY the HBM-cold leg (so that rocprofv3 counters of '
+                    'step_kernel<false, false> describe cold launches) and print its object')
+    ap.add_argument('--cold-stores', choices=['auto', 'through', 'back'], default='auto', help='store-policy hint of the cold leg')
+    ap.add_argument('--no-other-configs', action='store_true', help='skip the BASELINE configs[1] / configs[4] legs')
     ap.add_argument('--extras', action='store_true', help='also emit legal mask + obs (not the headline)')
     ap.add_argument('--obs-dtype', choices=['f32', 'f16', 'bf16'], default='f32', help='with --extras: element type of obs')
-    ap.add_argument('--dist-backend', default='nccl', help="'nccl' (= RCCL, one GPU per rank); 'gloo' only to rehearse the "
-                    'multi-rank logic on a single-GPU box (all ranks then share device 0)')
-    return ap.parse_args()
+    ap.add_argument('--dist-backend', default='nccl', help="'nccl' (= RCCL, one GPU per rank); 'gloo' = REHEARSAL of the "
+                    'multi-rank logic on a box with fewer GPUs than ranks (all ranks then share device 0; numbers are not a '
+                    'scaling measurement and the JSON says so)')
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` without a torchrun environment
+# ------------------------------------------------------------------------------------------------
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(world: int, worker_cmd: list[str], timeout: float = 1500.0) -> int:
+    """Start `world` worker processes (this process has made no GPU call and makes none), wait for all,
+    relay rank 0's stdout.  Any failing rank => the others are terminated (exact PIDs) and the exit code is
+    non-zero.  Nothing here replaces a running process image (no exec)."""
+    port = free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        env.setdefault('OMP_NUM_THREADS', '1')
+        procs.append(subprocess.Popen(worker_cmd, env=env, stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, text=True))
+    deadline = time.monotonic() + timeout
+    rc = 0
+    pending = set(range(world))
+    out0 = ''
+    while pending:
+        for rank in sorted(pending):
+            p = procs[rank]
+            if rank == 0:
+                try:
+                    out0_part, _ = p.communicate(timeout=0.2)
+                    out0 += out0_part or ''
+                except subprocess.TimeoutExpired:
+                    continue
+            elif p.poll() is None:
+                continue
+            pending.discard(rank)
+            if p.returncode != 0:
+                rc = rc or p.returncode or 1
+                print(f'bench.py: rank {rank} exited with code {p.returncode}', file=sys.stderr)
+        if (rc or time.monotonic() > deadline) and pending:
+            rc = rc or 124
+            for rank in pending:
+                procs[rank].terminate()
+            for rank in pending:
+                try:
+                    procs[rank].wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    procs[rank].kill()
+            break
+        time.sleep(0.05)
+    for line in out0.splitlines():  # exactly the JSON line on stdout; anything else a library printed there goes to stderr
+        print(line, file=sys.stdout if line.startswith('{') else sys.stderr, flush=True)
+    if rc == 0 and not any(line.startswith('{') for line in out0.splitlines()):
+        print('bench.py: rank 0 printed no JSON line', file=sys.stderr)
+        rc = 1
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------
+# helpers
+# ------------------------------------------------------------------------------------------------
+def usable_cores() -> int:
+    """CPU threads this process may really use: affinity mask, capped by the cgroup CPU quota and by
+    the 16-core share a one-GPU box gets (an oversubscribed OpenMP team is slower, not faster)."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = Path('/sys/fs/cgroup/cpu.max').read_text().split()
+        if quota != 'max':
+            cores = min(cores, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(cores, int(os.environ.get('ENV2048_CPU_THREADS', '16'))))
 
 
 def cpu_baseline(boards_np, seconds: float):
@@ -83,6 +183,7 @@ def cpu_baseline(boards_np, seconds: float):
             break
     # the same loop on ONE thread for ~2 s, quoted in the sample text (per-core figure next to the reference's)
     single_steps, t1 = 0, time.perf_counter()
+    single_elapsed = 0.0
     while threads > 1:
         oracle.step_batch_inplace(boards, actions, reward, done, SEED, 500_000 + single_steps, flags=1, threads=1)
         single_steps += 1
@@ -100,34 +201,39 @@ def cpu_baseline(boards_np, seconds: float):
     }
 
 
-def usable_cores() -> int:
-    """CPU threads this process may really use: affinity mask, capped by the cgroup CPU quota and by
-    the 16-core share a one-GPU box gets (an oversubscribed OpenMP team is slower, not faster)."""
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-    try:
-        quota, period = Path('/sys/fs/cgroup/cpu.max').read_text().split()
-        if quota != 'max':
-            cores = min(cores, max(1, int(int(quota) / int(period))))
-    except Exception:
-        pass
-    return max(1, min(cores, int(os.environ.get('ENV2048_CPU_THREADS', '16'))))
+def kernel_source_sha() -> str:
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        h.update((REPO / rel).read_bytes())
+    return h.hexdigest()[:16]
 
 
-def load_traffic(boards: int):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/traffic.json), or None."""
-    path = REPO / 'profiles' / 'traffic.json'
-    if not path.exists():
-        return None
+def load_step_profile(boards: int, leg: str):
+    """Counters of the step kernel from the committed rocprofv3 --pmc passes (profiles/step_pmc.json, written by
+    tools/summarize_profiles.py): {'fabric_bytes_per_launch', 'valu_insts_per_launch', 'source', 'stale'} or None.
+    'stale' = the kernel sources changed since the counters were collected."""
+    path = REPO / 'profiles' / 'step_pmc.json'
     try:
         table = json.loads(path.read_text())
-        entry = table.get(str(boards))
-        return None if entry is None else entry.get('hbm_bytes_per_launch')
+        entry = table['entries'].get(f'{leg}:{boards}')
+        if entry is None:
+            return None
+        return dict(entry, stale=table.get('kernel_source_sha') != kernel_source_sha())
     except Exception:
         return None
 
 
-def main():
-    args = parse_args()
+def workload_text(n: int) -> str:
+    which = {1 << 16: 'BASELINE configs[1]', 1 << 20: 'BASELINE configs[2]'}.get(n, 'BASELINE configs[2] workload at a non-default size')
+    count = f'{n:,}'.replace(',', ' ')
+    return (f'{which}: {count} parallel 4x4 boards per GPU, uint8 log2-packed, uniform random host actions, Philox spawn, '
+            f'terminal check, auto-reset; boards mid-game (64 warm-up steps)')
+
+
+# ------------------------------------------------------------------------------------------------
+# one rank
+# ------------------------------------------------------------------------------------------------
+def run_rank(args) -> None:
     import torch
 
     from simulate_2048_amd import capi
@@ -137,15 +243,14 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit(f'--gpus {args.gpus} needs one process per GPU: launch with torch.distributed.run --nproc-per-node {args.gpus}')
         sys.exit(f'WORLD_SIZE={world} does not match --gpus {args.gpus}')
     if not torch.cuda.is_available():
         sys.exit('bench.py needs a HIP device: the product path has no CPU fallback')
     rehearsal = world > 1 and args.dist_backend != 'nccl'
     device_index = 0 if rehearsal else local_rank
     if device_index >= torch.cuda.device_count():
-        sys.exit(f'rank {rank}: local rank {local_rank} has no GPU (visible devices: {torch.cuda.device_count()})')
+        sys.exit(f'rank {rank}: local rank {local_rank} has no GPU (visible devices: {torch.cuda.device_count()}); '
+                 f'use --dist-backend gloo to REHEARSE the multi-rank logic on fewer GPUs')
     torch.cuda.set_device(device_index)
     device = torch.device('cuda', device_index)
     dist = None
@@ -156,116 +261,148 @@ def main():
             dist.init_process_group('nccl', device_id=device)
         else:
             dist.init_process_group(args.dist_backend)
+    reduce_device = device if (dist is not None and args.dist_backend == 'nccl') else 'cpu'
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    def reduce_max(values):
+        t = torch.tensor(values, dtype=torch.float64, device=reduce_device)
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.cpu().tolist()
+
+    def gather(values):
+        t = torch.tensor(values, dtype=torch.float64, device=reduce_device)
+        if dist is None:
+            return [t.tolist()]
+        out = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(out, t)
+        return [o.cpu().tolist() for o in out]
 
     n = args.boards
     K, W = args.steps, args.warmup
     obs_bytes = 4 if args.obs_dtype == 'f32' else 2
     obs_dtype = {'f32': torch.float32, 'f16': torch.float16, 'bf16': torch.bfloat16}[args.obs_dtype]
-    env = BatchedEnv2048(n, SEED, device=device, env_base=rank * n, auto_reset=True, with_legal=args.extras,
+    env_base = rank * n
+    env = BatchedEnv2048(n, SEED, device=device, env_base=env_base, auto_reset=True, with_legal=args.extras,
                          with_obs=args.extras, obs_dtype=obs_dtype)
     env.reset()
     for _ in range(64):  # bring the boards to mid-game
         env.step(None)
     torch.cuda.synchronize()
-    boards_midgame = env.boards.cpu().numpy() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+    midgame = env.boards.clone()
+    boards_midgame = midgame.cpu().numpy() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
 
     # host-provided actions: a small pool of uint8 arrays, cycled
     gen = torch.Generator(device='cpu').manual_seed(1 + rank)
     pool = [torch.randint(0, 4, (n,), generator=gen, dtype=torch.uint8).to(device) for _ in range(8)]
 
     lib = capi.library()
-    step_fn = lib._dll.env2048_step
     stream = torch.cuda.current_stream(device)
-    fixed = dict(
-        boards=ctypes.c_void_p(env.boards.data_ptr()), reward=ctypes.c_void_p(env.reward.data_ptr()),
-        done=ctypes.c_void_p(env.done.data_ptr()),
-        legal=ctypes.c_void_p(env.legal.data_ptr()) if env.legal is not None else None,
-        obs=ctypes.c_void_p(env.obs.data_ptr()) if env.obs is not None else None,
-    )
-    action_ptrs = [ctypes.c_void_p(a.data_ptr()) for a in pool]
-    env_base = rank * n
-
-    def launch(step_index: int, stream_handle):
-        rc = step_fn(device_index, stream_handle, n, env_base, fixed['boards'], action_ptrs[step_index & 7], fixed['reward'],
-                     fixed['done'], fixed['legal'], fixed['obs'], SEED, step_index, env.flags)
-        if rc != 0:
-            raise capi.Env2048Error(rc, lib.last_error())
-
-    def launch_part(step_index: int, stream_handle, part: int, parts: int):
-        lo = part * (n // parts)
-        cnt = n // parts
-        off = lambda p, scale: None if p is None else ctypes.c_void_p(p.value + lo * scale)
-        rc = step_fn(device_index, stream_handle, cnt, env_base + lo, off(fixed['boards'], 16), off(action_ptrs[step_index & 7], 1),
-                     off(fixed['reward'], 4), off(fixed['done'], 1), off(fixed['legal'], 1), off(fixed['obs'], 16 * obs_bytes), SEED,
-                     step_index, env.flags)
-        if rc != 0:
-            raise capi.Env2048Error(rc, lib.last_error())
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-
-    base_step = env.step_index
-    graph = None
-    if args.mode == 'graph':
-        side = torch.cuda.Stream(device)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.stream(side):
-            for t in range(3):
-                launch(base_step + t, side.cuda_stream)
-            torch.cuda.synchronize()
-            with torch.cuda.graph(graph, stream=side):
-                cap_stream = torch.cuda.current_stream(device)
-                if args.chains <= 1:
-                    for t in range(K):
-                        launch(base_step + W + t, cap_stream.cuda_stream)
-                else:
-                    others = [torch.cuda.Stream(device) for _ in range(args.chains - 1)]
-                    fork = torch.cuda.Event()
-                    fork.record(cap_stream)
-                    for o in others:
-                        o.wait_event(fork)
-                    streams = [cap_stream] + others
-                    for t in range(K):
-                        for c, st in enumerate(streams):
-                            launch_part(base_step + W + t, st.cuda_stream, c, args.chains)
-                    for o in others:
-                        ev = torch.cuda.Event()
-                        ev.record(o)
-                        cap_stream.wait_event(ev)
-        torch.cuda.synchronize()
-
     h = stream.cuda_stream
-    for t in range(W):
-        launch(base_step + t, h)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    if graph is not None:
-        graph.replay()
-    else:
-        for t in range(K):
-            launch(base_step + W + t, h)
-    ev1.record(stream)
-    torch.cuda.synchronize()
-    barrier()
-    wall = time.perf_counter() - t0
-    event_ms = ev0.elapsed_time(ev1)
+    p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+    flags = env.flags
 
-    if dist is not None:
-        tt = torch.tensor([wall, event_ms], dtype=torch.float64, device=device if args.dist_backend == 'nccl' else 'cpu')
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        wall, event_ms = float(tt[0]), float(tt[1])
+    def action_table(count: int, first: int):
+        return (ctypes.c_void_p * count)(*[pool[(first + t) & 7].data_ptr() for t in range(count)])
+
+    step_index = env.step_index
+
+    def run_steps(count: int) -> None:
+        """`count` dependent step launches, enqueued from C by one call."""
+        nonlocal step_index
+        if count <= 0:
+            return
+        lib.step_sequence(device_index, h, n, env_base, p(env.boards), action_table(count, step_index), p(env.reward), p(env.done),
+                          p(env.legal), p(env.obs), 0, SEED, step_index, count, flags)
+        step_index += count
+
+    def timed_block(count: int):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        run_steps(count)
+        ev1.record(stream)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        return wall, ev0.elapsed_time(ev1) * 1e-3
+
+    if args.only_cold:
+        launch_s = 8e-6
+        cold = cold_leg(args, torch, lib, capi, device, device_index, h, stream, n, env_base, world, midgame, pool, flags, launch_s)
+        if rank == 0:
+            print(json.dumps({'hbm_cold': cold}), flush=True)
+        return
+    run_steps(W)
+    torch.cuda.synchronize()
+    # how many blocks: cover --min-ms of GPU time (the same count on every rank: calibrate on the max over ranks)
+    calib = reduce_max([timed_block(K)[1]])[0]
+    blocks = int(min(args.max_blocks, max(3, math.ceil(args.min_ms * 1e-3 / max(calib, 1e-7)))))
+    walls, events = [], []
+    for _ in range(blocks):
+        wall, ev = timed_block(K)
+        walls.append(wall)
+        events.append(ev)
+    barrier()
+    walls_max = reduce_max(walls)      # per block: the slowest rank
+    events_max = reduce_max(events)
+    per_rank = gather([statistics.median(events) / K * 1e6, statistics.median(walls) / K * 1e6])
+    wall = statistics.median(walls_max)
+    launch_s = statistics.median(events_max) / K
+
+    # ---- HBM-cold leg: same launch size, round-robin over disjoint buffer sets that exceed the Infinity Cache -------
+    cold = None
+    if not args.no_cold and not args.extras:
+        cold = cold_leg(args, torch, lib, capi, device, device_index, h, stream, n, env_base, world, midgame, pool, flags, launch_s)
+
+    # ---- BASELINE configs[1] and configs[4], single GPU only (reported next to the headline, not as `value`) ---------
+    other = None
+    if not args.no_other_configs and world == 1 and not args.extras:
+        other = other_configs(torch, lib, device, device_index, h)
 
     if rank == 0:
         total_steps = float(n) * K * world
         value = total_steps / wall
-        launch_s = event_ms * 1e-3 / K
         bytes_per_launch = ALGO_BYTES_PER_STEP * n + (n * (1 + 16 * obs_bytes) if args.extras else 0)
-        achieved = bytes_per_launch / launch_s / 1e9
+        algo_gbs = bytes_per_launch / launch_s / 1e9
+        working_set = n * (16 + 8 + 4 + 1) + (n * (1 + 16 * obs_bytes) if args.extras else 0)  # boards + 8-array action pool + outputs
+        resident = working_set <= INFINITY_CACHE_BYTES
+        prof = None if args.extras else load_step_profile(n, 'resident')
+        kernel = 'step_kernel<false, false>' if not args.extras else 'step_kernel<true, false>'
+        roofline = {
+            'kernel': kernel,
+            'avg_launch_us': launch_s * 1e6,
+            'algorithmic_bytes_per_launch': bytes_per_launch,
+            'traffic': None if prof is None else prof.get('fabric_bytes_per_launch'),
+            'traffic_kind': 'fabric bytes per launch (2*FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes): L2 <-> Infinity '
+                            'Cache/HBM requests -- Infinity-Cache hits are counted, so this is HBM traffic only for the cold leg',
+            'traffic_source': None if prof is None else dict(source=prof.get('source'), stale=prof['stale']),
+        }
+        if resident and prof is not None and prof.get('valu_insts_per_launch'):
+            ginstr = prof['valu_insts_per_launch'] / launch_s / 1e9
+            roofline.update({
+                'bound': 'valu',
+                'achieved': ginstr,
+                'peak': VALU_PEAK_GINSTR,
+                'unit': 'G wave-instr/s',
+                'frac': ginstr / VALU_PEAK_GINSTR,
+                'why': f'working set {working_set / 2**20:.0f} MiB is Infinity-Cache resident at this size: the limiter is VALU issue '
+                       f'({prof["valu_insts_per_launch"] / n:.0f} VALU instructions per board-step, SQ_INSTS_VALU), peak = 1024 SIMDs x '
+                       f'2.4 GHz / 4 cycles per wave64 instruction; the HBM fraction of this kernel is roofline.hbm_cold',
+                'hbm_resident_equiv': {'achieved': algo_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': algo_gbs / HBM_PEAK_GBS,
+                                       'note': 'algorithmic bytes / launch time; NOT an HBM fraction while the working set is cache-resident'},
+            })
+        else:
+            roofline.update({'bound': 'hbm', 'achieved': algo_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': algo_gbs / HBM_PEAK_GBS})
+            if resident:
+                roofline['why'] = ('working set is Infinity-Cache resident and no fresh VALU counter profile is committed for this size: '
+                                   'algorithmic bytes / launch time is given, see hbm_cold for the HBM fraction')
+        if cold is not None:
+            roofline['hbm_cold'] = cold
         out = {
             'metric': 'env_board_steps_per_sec',
             'value': value,
@@ -280,32 +417,190 @@ def main():
             'dtype': 'u8',
             'data': 'synthetic',
             'config': {
-                'workload': 'BASELINE configs[2]: 1 048 576 parallel 4x4 boards per GPU, uint8 log2-packed, uniform random '
-                            'host actions, Philox spawn, terminal check, auto-reset; boards mid-game (64 warm-up steps)',
+                'workload': workload_text(n),
                 'boards_per_gpu': n,
                 'global_boards': n * world,
-                'launch_mode': args.mode,
+                'launch_mode': 'env2048_step_sequence: K launches enqueued from C by one call',
                 'sharding': 'contiguous env-index slices, one process per GPU, no collective on the hot path',
                 'outputs': 'board,reward,done' + (f',legal,obs({args.obs_dtype})' if args.extras else ''),
             },
-            'roofline': {
-                'bound': 'hbm',
-                'achieved': achieved,
-                'peak': HBM_PEAK_GBS,
-                'unit': 'GB/s',
-                'frac': achieved / HBM_PEAK_GBS,
-                'traffic': load_traffic(n),
-                'kernel': 'step_kernel<false, false>' if not args.extras else 'step_kernel<true, false>',
-                'algorithmic_bytes_per_launch': bytes_per_launch,
-                'avg_launch_us': launch_s * 1e6,
+            'timing': {
+                'blocks': blocks,
+                'block_steps': K,
+                'wall_us_per_step': {'median': wall / K * 1e6, 'min': min(walls_max) / K * 1e6, 'max': max(walls_max) / K * 1e6},
+                'event_us_per_step': {'median': launch_s * 1e6, 'min': min(events_max) / K * 1e6, 'max': max(events_max) / K * 1e6},
+                'per_rank_us_per_step': [{'rank': r, 'event': v[0], 'wall': v[1]} for r, v in enumerate(per_rank)],
+                'note': 'value = boards x K x ranks / median over blocks of (max over ranks of the block wall time)',
             },
+            'roofline': roofline,
         }
+        if rehearsal:
+            out['config']['rehearsal'] = (f'{world} gloo ranks SHARING one GPU: exercises the multi-rank code path only; '
+                                          f'not a scaling measurement')
+        if other is not None:
+            out['other_configs'] = other
         if boards_midgame is not None:
             out['cpu_baseline'] = cpu_baseline(boards_midgame, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def cold_leg(args, torch, lib, capi, device, device_index, h, stream, n, env_base, world, midgame, pool, flags, launch_s) -> dict:
+    """The step kernel at the same launch size with cache residency defeated: `sets` disjoint (boards, actions, reward,
+    done) buffer sets whose total exceeds twice the 256 MiB Infinity Cache, stepped round-robin, so every launch reads
+    and writes lines that were last touched `sets` launches ago."""
+    set_bytes = n * (16 + 1 + 4 + 1)
+    sets = max(2, math.ceil(2.5 * INFINITY_CACHE_BYTES / set_bytes))
+    cb = midgame.unsqueeze(0).repeat(sets, 1, 1).contiguous()
+    ca = torch.stack([pool[s & 7] for s in range(sets)]).contiguous()
+    cr = torch.zeros((sets, n), dtype=torch.int32, device=device)
+    cd = torch.zeros((sets, n), dtype=torch.uint8, device=device)
+    records = (capi.StepArgs * sets)()
+    cold_step = 1 << 32
+    hint = {'auto': 0, 'through': capi.FLAG_STORES_WRITE_THROUGH, 'back': capi.FLAG_STORES_WRITE_BACK}[args.cold_stores]
+
+    def cold_pass() -> None:
+        nonlocal cold_step
+        for s in range(sets):
+            records[s] = capi.StepArgs(n, (world + s) * n + env_base, cb[s].data_ptr(), ca[s].data_ptr(), cr[s].data_ptr(),
+                                       cd[s].data_ptr(), None, None, SEED, cold_step, flags | hint, 0)
+        lib.step_many(device_index, h, records)
+        cold_step += 1
+
+    for _ in range(3):
+        cold_pass()
+    torch.cuda.synchronize()
+    passes = max(4, min(64, math.ceil(25e-3 / max(launch_s * sets, 1e-7))))
+    cold_times = []
+    for _ in range(3):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(stream)
+        for _ in range(passes):
+            cold_pass()
+        ev1.record(stream)
+        torch.cuda.synchronize()
+        cold_times.append(ev0.elapsed_time(ev1) * 1e-3 / (passes * sets))
+    cold_s = statistics.median(cold_times)
+    prof = load_step_profile(n, 'cold')
+    return {
+        'bound': 'hbm',
+        'achieved': ALGO_BYTES_PER_STEP * n / cold_s / 1e9,
+        'peak': HBM_PEAK_GBS,
+        'unit': 'GB/s',
+        'frac': ALGO_BYTES_PER_STEP * n / cold_s / 1e9 / HBM_PEAK_GBS,
+        'avg_launch_us': cold_s * 1e6,
+        'buffer_sets': sets,
+        'footprint_bytes': sets * set_bytes,
+        'launches_timed': passes * sets,
+        'stores': args.cold_stores,
+        'traffic': None if prof is None else prof.get('fabric_bytes_per_launch'),
+        'traffic_source': None if prof is None else dict(source=prof.get('source'), stale=prof['stale']),
+        'how': f'{sets} disjoint sets of (boards, actions, reward, done) = {sets * set_bytes / 2**20:.0f} MiB > 2 x Infinity Cache, '
+               f'stepped round-robin by env2048_step_many, so every launch reads and writes lines last touched {sets} launches ago',
+    }
+
+
+def other_configs(torch, lib, device, device_index, h) -> dict:
+    """BASELINE configs[1] (65 536 boards) and configs[4] (2^20 boards x 512-step rollout, Philox spawn, auto-reset,
+    on-device random actions) on this GPU -- measured both as 512 step launches and as one fused env2048_rollout,
+    with the cross-check SURVEY 8(d) config 5 asks for (identical boards, sum of rewards and episode counts)."""
+    from simulate_2048_amd import capi
+    from simulate_2048_amd.batch import BatchedEnv2048
+
+    out = {}
+    # configs[1]
+    n1 = 1 << 16
+    env = BatchedEnv2048(n1, SEED, device=device, auto_reset=True)
+    env.reset()
+    for _ in range(64):
+        env.step(None)
+    gen = torch.Generator(device='cpu').manual_seed(7)
+    pool = [torch.randint(0, 4, (n1,), generator=gen, dtype=torch.uint8).to(device) for _ in range(8)]
+    count = 2000
+    table = (ctypes.c_void_p * count)(*[pool[t & 7].data_ptr() for t in range(count)])
+    stream = torch.cuda.current_stream(device)
+    times = []
+    for rep in range(4):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        lib.step_sequence(device_index, h, n1, 0, env.boards.data_ptr(), table, env.reward.data_ptr(), env.done.data_ptr(), None, None,
+                          0, SEED, 64 + rep * count, count, env.flags)
+        ev1.record(stream)
+        torch.cuda.synchronize()
+        times.append((time.perf_counter() - t0, ev0.elapsed_time(ev1) * 1e-3))
+    wall, ev = sorted(times)[len(times) // 2]
+    out['configs[1]'] = {
+        'workload': '65 536 parallel boards, uint8 log2-packed, uniform random host actions, auto-reset, 1 GPU',
+        'value': n1 * count / wall, 'unit': 'board-steps/s', 'us_per_step_wall': wall / count * 1e6, 'us_per_step_event': ev / count * 1e6,
+        'bound': 'launch/latency: 1 MiB of boards is L2/Infinity-Cache resident and 32 blocks fill an eighth of the chip',
+    }
+    del env, pool
+
+    # configs[4]
+    n4, T = 1 << 20, 512
+    a = BatchedEnv2048(n4, SEED, device=device, auto_reset=True)
+    a.reset()
+    start = a.boards.clone()
+    flags = capi.FLAG_AUTO_RESET | capi.FLAG_RANDOM_ACTIONS
+    reward_rows = torch.zeros((T, n4), dtype=torch.int32, device=device)
+    done_rows = torch.zeros((T, n4), dtype=torch.uint8, device=device)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    lib.step_sequence(device_index, h, n4, 0, a.boards.data_ptr(), None, reward_rows.data_ptr(), done_rows.data_ptr(), None, None,
+                      n4, SEED, 0, T, flags)
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    wall_steps, ev_steps = time.perf_counter() - t0, ev0.elapsed_time(ev1) * 1e-3
+    sum_steps = int(reward_rows.sum(dtype=torch.int64))
+    eps_steps = int(done_rows.sum(dtype=torch.int64))
+    invalid = float(((reward_rows == 0) & (done_rows == 0)).float().mean())  # upper bound on the invalid-move share (valid moves can score 0)
+    del reward_rows, done_rows
+    b = BatchedEnv2048(n4, SEED, device=device, auto_reset=True)
+    b.boards.copy_(start)
+    roll_times = []
+    stats = None
+    for rep in range(3):
+        b.boards.copy_(start)
+        b.step_index = 0
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        stats = b.rollout(T)
+        ev1.record(stream)
+        torch.cuda.synchronize()
+        roll_times.append((time.perf_counter() - t0, ev0.elapsed_time(ev1) * 1e-3))
+    wall_roll, ev_roll = sorted(roll_times)[1]
+    sum_roll = int(stats['return_sum'].sum())
+    eps_roll = int(stats['episodes'].sum(dtype=torch.int64))
+    valid_roll = int(stats['valid_moves'].sum(dtype=torch.int64))
+    same_boards = bool(torch.equal(a.boards, b.boards))
+    out['configs[4]'] = {
+        'workload': '1 048 576 boards x 512-step rollout, Philox tile spawn, on-device uniform random actions, auto-reset on terminal',
+        'as_512_step_launches': {'value': n4 * T / wall_steps, 'unit': 'board-steps/s', 'ms_total_wall': wall_steps * 1e3,
+                                 'us_per_step_event': ev_steps / T * 1e6, 'records': 'reward and done rows [512, 2^20] written in HBM'},
+        'as_one_rollout_kernel': {'value': n4 * T / wall_roll, 'unit': 'board-steps/s', 'ms_total_wall': wall_roll * 1e3,
+                                  'ms_total_event': ev_roll * 1e3, 'bound': 'VALU issue (boards stay in registers: 44 B per env per 512 steps)'},
+        'cross_check': {'boards_identical': same_boards, 'reward_sum': [sum_steps, sum_roll], 'episodes': [eps_steps, eps_roll],
+                        'ok': same_boards and sum_steps == sum_roll and eps_steps == eps_roll},
+        'statistics': {'mean_episode_length': n4 * T / max(eps_roll, 1), 'invalid_move_fraction': 1.0 - valid_roll / (n4 * T),
+                       'zero_reward_nonterminal_fraction': invalid},
+    }
+    return out
+
+
+def main():
+    args = parse_args()
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # no torchrun environment: start one worker per GPU ourselves (children; this process never touches a GPU)
+        sys.exit(spawn_ranks(args.gpus, [sys.executable, str(Path(__file__).resolve())] + sys.argv[1:]))
+    run_rank(args)
 
 
 if __name__ == '__main__':

@@ -56,7 +56,7 @@ extern "C" {
 #define ENV2048_EXPORT
 #endif
 
-#define ENV2048_ABI_VERSION 1
+#define ENV2048_ABI_VERSION 2
 
 #define ENV2048_OK 0
 #define ENV2048_ERR_INVALID_ARG (-1) /* NULL required pointer, bad flag bits */
@@ -70,6 +70,12 @@ extern "C" {
 #define ENV2048_FLAG_RANDOM_ACTIONS 2u /* ignore `actions`; use the low two bits of the step word */
 #define ENV2048_FLAG_OBS_F16 4u        /* env2048_step only: `obs` is n x 16 IEEE binary16 instead of float32 */
 #define ENV2048_FLAG_OBS_BF16 8u       /* env2048_step only: `obs` is n x 16 bfloat16 (excludes OBS_F16)      */
+/* env2048_step* only, tuning hints that change no result: by default a launch of up to 2^23 boards stores
+ * write-through (nothing is left dirty in the XCD L2s for the end-of-kernel write-back; the working set of
+ * back-to-back steps then lives in the 256 MiB Infinity Cache) and a larger one stores write-back.  These two
+ * bits override the size rule (they exclude each other). */
+#define ENV2048_FLAG_STORES_WRITE_THROUGH 16u
+#define ENV2048_FLAG_STORES_WRITE_BACK 32u
 
 ENV2048_EXPORT int env2048_abi_version(void);
 ENV2048_EXPORT const char *env2048_last_error(void);
@@ -110,6 +116,39 @@ ENV2048_EXPORT int env2048_reset(int device, void *stream, uint64_t n, uint64_t 
 ENV2048_EXPORT int env2048_step(int device, void *stream, uint64_t n, uint64_t env_base, uint8_t *boards,
                  const uint8_t *actions, int32_t *reward, uint8_t *done, uint8_t *legal, void *obs,
                  uint64_t seed, uint64_t step_index, uint32_t flags);
+
+/*
+ * Several step launches enqueued by ONE call, in order, on `stream` -- for callers whose per-call host cost
+ * (argument marshalling, device selection) would otherwise rival the 8-microsecond kernel: replaying staged
+ * actions, stepping several independent batches, rotating buffer sets.  Every record is one env2048_step call
+ * with the same meaning and the same checks; all records are validated before the first launch, so a failing
+ * call has enqueued nothing.  `reserved` must be 0.
+ */
+typedef struct env2048_step_args {
+    uint64_t n, env_base;
+    uint8_t *boards;
+    const uint8_t *actions;
+    int32_t *reward;
+    uint8_t *done;
+    uint8_t *legal;
+    void *obs;
+    uint64_t seed, step_index;
+    uint32_t flags, reserved;
+} env2048_step_args;
+ENV2048_EXPORT int env2048_step_many(int device, void *stream, uint64_t count, const env2048_step_args *args);
+
+/*
+ * `count` consecutive transitions of ONE batch: launch t (t = 0 .. count-1) is
+ *     env2048_step(device, stream, n, env_base, boards, actions[t], reward + t*row_stride, done + t*row_stride,
+ *                  legal + t*row_stride, obs + 16*t*row_stride elements, seed, step_index + t, flags)
+ * `actions` is a HOST array of `count` device pointers (NULL with RANDOM_ACTIONS).  row_stride = 0 makes every
+ * step overwrite the same output arrays; row_stride >= n records step t in row t of [count, row_stride] arrays
+ * (the per-step rows of reinforce/training/self_play.py:359-365 without a host round trip).
+ * [replaces: the env.step calls of the move loop, reinforce/training/self_play.py:314-368]
+ */
+ENV2048_EXPORT int env2048_step_sequence(int device, void *stream, uint64_t n, uint64_t env_base, uint8_t *boards,
+                                         const uint8_t *const *actions, int32_t *reward, uint8_t *done, uint8_t *legal, void *obs,
+                                         uint64_t row_stride, uint64_t seed, uint64_t step_index, uint32_t count, uint32_t flags);
 
 /*
  * The reinforce/game form of one transition, fused: boards are int32 tile VALUES (n x 16, in

@@ -12,7 +12,7 @@ from __future__ import annotations
 import ctypes
 from pathlib import Path
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 OK = 0
 ERR_INVALID_ARG = -1
@@ -25,6 +25,8 @@ FLAG_AUTO_RESET = 1
 FLAG_RANDOM_ACTIONS = 2
 FLAG_OBS_F16 = 4
 FLAG_OBS_BF16 = 8
+FLAG_STORES_WRITE_THROUGH = 16
+FLAG_STORES_WRITE_BACK = 32
 
 LIB_PATH = Path(__file__).resolve().parent / 'lib' / 'libenv2048.so'
 
@@ -33,6 +35,15 @@ _u32 = ctypes.c_uint32
 _u64 = ctypes.c_uint64
 _ptr = ctypes.c_void_p
 
+
+
+class StepArgs(ctypes.Structure):
+    """``env2048_step_args`` of include/env2048.h: one env2048_step call as a record (env2048_step_many)."""
+
+    _fields_ = [('n', _u64), ('env_base', _u64), ('boards', _ptr), ('actions', _ptr), ('reward', _ptr), ('done', _ptr),
+                ('legal', _ptr), ('obs', _ptr), ('seed', _u64), ('step_index', _u64), ('flags', _u32), ('reserved', _u32)]
+
+
 # name -> (restype, argtypes): exactly the prototypes of include/env2048.h
 PROTOTYPES = {
     'env2048_abi_version': (_c_int, []),
@@ -40,6 +51,9 @@ PROTOTYPES = {
     'env2048_device_count': (_c_int, []),
     'env2048_reset': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _ptr, _u64, _u64]),
     'env2048_step': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _u64, _u64, _u32]),
+    'env2048_step_many': (_c_int, [_c_int, _ptr, _u64, ctypes.POINTER(StepArgs)]),
+    'env2048_step_sequence': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, ctypes.POINTER(_ptr), _ptr, _ptr, _ptr, _ptr, _u64, _u64, _u64,
+                                        _u32, _u32]),
     'env2048_step_state_i32': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _u64, _u64]),
     'env2048_step_state_i32_to': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _u64,
                                             _u64]),
@@ -112,6 +126,16 @@ class Library:
              flags) -> None:
         self._check(self._dll.env2048_step(device, stream, n, env_base, boards, actions, reward, done, legal, obs,
                                            seed, step_index, flags))
+
+    def step_many(self, device, stream, records) -> None:
+        """``records``: a ctypes array of StepArgs (build it once with ``(StepArgs * k)(...)`` and reuse it)."""
+        self._check(self._dll.env2048_step_many(device, stream, len(records), records))
+
+    def step_sequence(self, device, stream, n, env_base, boards, actions, reward, done, legal, obs, row_stride, seed, step_index,
+                      count, flags) -> None:
+        """``actions``: None or a ctypes array ``(c_void_p * count)`` of device pointers, one per step."""
+        self._check(self._dll.env2048_step_sequence(device, stream, n, env_base, boards, actions, reward, done, legal, obs,
+                                                    row_stride, seed, step_index, count, flags))
 
     def step_state_i32(self, device, stream, n, env_base, boards, actions, step_count, done_io, total_reward, reward, max_tile,
                        seed, step_index) -> None:

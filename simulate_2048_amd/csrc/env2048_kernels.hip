@@ -110,7 +110,7 @@ __device__ __forceinline__ void store_obs_coalesced(float *obs, uint32_t *strip,
 // 16-bit observations (ENV2048_FLAG_OBS_F16 / _BF16): the same values -- e/16 with e <= 31 has five
 // significant bits, exact in both formats -- at half the bytes, which is what bounds the trainer-facing path.
 constexpr uint32_t OBS_F32 = 0u, OBS_BF16 = 2u;  // flags bits 2..3 (1 = f16)
-__device__ __forceinline__ uint32_t obs_format(uint32_t flags) { return (flags >> 2) & 3u; }
+__host__ __device__ __forceinline__ uint32_t obs_format(uint32_t flags) { return (flags >> 2) & 3u; }
 
 __device__ __forceinline__ uint32_t obs_pair16(uint32_t e_lo, uint32_t e_hi, bool bf16)
 {
@@ -995,15 +995,29 @@ int hip_fail(hipError_t e, const char *what)
 
 bool misaligned(const void *p, uintptr_t a) { return p && (reinterpret_cast<uintptr_t>(p) & (a - 1)) != 0; }
 
-// Select `device` for the duration of one entry point and put the caller's device back after.
+// Select `device` for the duration of one entry point and put the caller's device back after.  The device
+// count is read once per process (it cannot change under a running HIP runtime); per call only the calling
+// thread's current device is queried, and nothing is switched when it already is the requested one.
+int visible_devices(hipError_t *err)
+{
+    static hipError_t cached_err = hipSuccess;
+    static const int cached = [] {
+        int count = 0;
+        cached_err = hipGetDeviceCount(&count);
+        return cached_err == hipSuccess ? count : 0;
+    }();
+    *err = cached_err;
+    return cached;
+}
+
 struct DeviceScope {
     int prev = -1;
     int rc = ENV2048_OK;
     explicit DeviceScope(int device)
     {
-        int count = 0;
-        hipError_t e = hipGetDeviceCount(&count);
-        if (e != hipSuccess || count <= 0) {
+        hipError_t e = hipSuccess;
+        const int count = visible_devices(&e);
+        if (count <= 0) {
             rc = fail(ENV2048_ERR_DEVICE, "no usable HIP device (%s); this library has no CPU fallback",
                       e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
             return;
@@ -1060,6 +1074,63 @@ int launched(const char *what)
     return e == hipSuccess ? ENV2048_OK : hip_fail(e, what);
 }
 
+constexpr uint32_t STEP_FLAGS = ENV2048_FLAG_AUTO_RESET | ENV2048_FLAG_RANDOM_ACTIONS | ENV2048_FLAG_OBS_F16 | ENV2048_FLAG_OBS_BF16 |
+                                ENV2048_FLAG_STORES_WRITE_THROUGH | ENV2048_FLAG_STORES_WRITE_BACK;
+// Launches up to this many boards use write-through stores unless a STORES_* flag says otherwise: they win while
+// boards + outputs of one launch stay within the 256 MiB Infinity Cache (measured 2^20..2^23 boards: -5..-13 %)
+// and lose beyond it (2^24: +7 %).
+constexpr uint64_t WRITE_THROUGH_MAX_BOARDS = 1ull << 23;
+
+int validate_step(const env2048_step_args &a, const char *who)
+{
+    if (a.flags & ~STEP_FLAGS) return fail(ENV2048_ERR_INVALID_ARG, "%s: unknown flag bits 0x%x", who, a.flags);
+    if ((a.flags & ENV2048_FLAG_OBS_F16) && (a.flags & ENV2048_FLAG_OBS_BF16))
+        return fail(ENV2048_ERR_INVALID_ARG, "%s: OBS_F16 and OBS_BF16 exclude each other", who);
+    if ((a.flags & ENV2048_FLAG_STORES_WRITE_THROUGH) && (a.flags & ENV2048_FLAG_STORES_WRITE_BACK))
+        return fail(ENV2048_ERR_INVALID_ARG, "%s: STORES_WRITE_THROUGH and STORES_WRITE_BACK exclude each other", who);
+    if (a.n == 0) return ENV2048_OK;
+    if (!a.boards || !a.done) return fail(ENV2048_ERR_INVALID_ARG, "%s: boards and done are required", who);
+    if (!a.actions && !(a.flags & ENV2048_FLAG_RANDOM_ACTIONS))
+        return fail(ENV2048_ERR_INVALID_ARG, "%s: actions is NULL without ENV2048_FLAG_RANDOM_ACTIONS", who);
+    if (misaligned(a.boards, 16)) return fail(ENV2048_ERR_ALIGNMENT, "%s: boards must be 16-byte aligned", who);
+    if (misaligned(a.reward, 4)) return fail(ENV2048_ERR_ALIGNMENT, "%s: reward must be 4-byte aligned", who);
+    if (misaligned(a.obs, 16)) return fail(ENV2048_ERR_ALIGNMENT, "%s: obs must be 16-byte aligned", who);
+    if (int rc = check_range(a.n, a.env_base)) return rc;
+    return check_count(a.n);
+}
+
+// Enqueue one step launch (arguments already validated, device already selected).
+void launch_step(const env2048_step_args &a, hipStream_t stream)
+{
+    uint32_t kernel_flags = a.flags & ~(ENV2048_FLAG_STORES_WRITE_THROUGH | ENV2048_FLAG_STORES_WRITE_BACK);
+    if (!misaligned(a.reward, 16) && !misaligned(a.done, 4)) kernel_flags |= INTERNAL_FLAG_WIDE_OUTPUTS;
+    const bool through = (a.flags & ENV2048_FLAG_STORES_WRITE_THROUGH)  ? true
+                         : (a.flags & ENV2048_FLAG_STORES_WRITE_BACK) ? false
+                                                                      : a.n <= WRITE_THROUGH_MAX_BOARDS;
+    if (through) kernel_flags |= INTERNAL_FLAG_WRITE_THROUGH;
+#ifdef ENV2048_EXP_STAMPS
+    const bool extras = false;
+#else
+    const bool extras = a.legal || a.obs;
+#endif
+    const bool random_actions = (a.flags & ENV2048_FLAG_RANDOM_ACTIONS) != 0u;
+    const dim3 grid = tile_grid_for(a.n), block(BLOCK);
+    const uint32_t seed_lo = (uint32_t)a.seed, seed_hi = (uint32_t)(a.seed >> 32);
+    const uint32_t step_lo = (uint32_t)a.step_index, step_hi = (uint32_t)(a.step_index >> 32);
+#define ENV2048_LAUNCH_STEP(EXTRAS, RANDOM)                                                                                    \
+    hipLaunchKernelGGL((step_kernel<EXTRAS, RANDOM>), grid, block, 0, stream, a.boards, a.actions, a.n, a.env_base, kernel_flags, \
+                       seed_lo, seed_hi, step_lo, step_hi, a.reward, a.done, a.legal, a.obs)
+    if (extras && random_actions)
+        ENV2048_LAUNCH_STEP(true, true);
+    else if (extras)
+        ENV2048_LAUNCH_STEP(true, false);
+    else if (random_actions)
+        ENV2048_LAUNCH_STEP(false, true);
+    else
+        ENV2048_LAUNCH_STEP(false, false);
+#undef ENV2048_LAUNCH_STEP
+}
+
 }  // namespace
 
 extern "C" {
@@ -1070,8 +1141,8 @@ const char *env2048_last_error(void) { return g_error; }
 
 int env2048_device_count(void)
 {
-    int count = 0;
-    hipError_t e = hipGetDeviceCount(&count);
+    hipError_t e = hipSuccess;
+    const int count = visible_devices(&e);
     if (e != hipSuccess) return fail(ENV2048_ERR_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
     return count;
 }
@@ -1096,47 +1167,63 @@ int env2048_step(int device, void *stream, uint64_t n, uint64_t env_base, uint8_
                  const uint8_t *actions, int32_t *reward, uint8_t *done, uint8_t *legal, void *obs,
                  uint64_t seed, uint64_t step_index, uint32_t flags)
 {
+    const env2048_step_args a{n, env_base, boards, actions, reward, done, legal, obs, seed, step_index, flags, 0u};
+    if (int rc = validate_step(a, "env2048_step")) return rc;
     if (n == 0) return ENV2048_OK;
-    if (flags & ~(ENV2048_FLAG_AUTO_RESET | ENV2048_FLAG_RANDOM_ACTIONS | ENV2048_FLAG_OBS_F16 | ENV2048_FLAG_OBS_BF16))
-        return fail(ENV2048_ERR_INVALID_ARG, "env2048_step: unknown flag bits 0x%x", flags);
-    if ((flags & ENV2048_FLAG_OBS_F16) && (flags & ENV2048_FLAG_OBS_BF16))
-        return fail(ENV2048_ERR_INVALID_ARG, "env2048_step: OBS_F16 and OBS_BF16 exclude each other");
-    if (!boards || !done) return fail(ENV2048_ERR_INVALID_ARG, "env2048_step: boards and done are required");
-    if (!actions && !(flags & ENV2048_FLAG_RANDOM_ACTIONS))
-        return fail(ENV2048_ERR_INVALID_ARG, "env2048_step: actions is NULL without ENV2048_FLAG_RANDOM_ACTIONS");
-    if (misaligned(boards, 16)) return fail(ENV2048_ERR_ALIGNMENT, "env2048_step: boards must be 16-byte aligned");
-    if (misaligned(reward, 4)) return fail(ENV2048_ERR_ALIGNMENT, "env2048_step: reward must be 4-byte aligned");
-    if (misaligned(obs, 16)) return fail(ENV2048_ERR_ALIGNMENT, "env2048_step: obs must be 16-byte aligned");
-    if (int rc = check_range(n, env_base)) return rc;
-    if (int rc = check_count(n)) return rc;
     DeviceScope scope(device);
     if (scope.rc) return scope.rc;
-    uint32_t kernel_flags = flags;
-    if (!misaligned(reward, 16) && !misaligned(done, 4)) kernel_flags |= INTERNAL_FLAG_WIDE_OUTPUTS;
-    // Write-through stores win while boards + outputs of one launch stay within the 256 MiB Infinity Cache
-    // (measured 2^20..2^23 boards: -5..-13 %) and lose beyond it (2^24: +7 %).  ENV2048_THROUGH_LIMIT
-    // (boards per launch) overrides the crossover for tuning.
-    static const long through_limit = getenv("ENV2048_THROUGH_LIMIT") ? atol(getenv("ENV2048_THROUGH_LIMIT")) : (1L << 23);
-    if ((long)n <= through_limit) kernel_flags |= INTERNAL_FLAG_WRITE_THROUGH;
-    StepArgs a{n, env_base, boards, actions, reward, done, legal, obs,
-               RngKey{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)step_index, (uint32_t)(step_index >> 32)},
-               kernel_flags};
-#ifdef ENV2048_EXP_STAMPS
-    const bool extras = false;
-#else
-    const bool extras = legal || obs;
-#endif
-    const bool random_actions = (flags & ENV2048_FLAG_RANDOM_ACTIONS) != 0u;
-    const dim3 grid = tile_grid_for(n), block(BLOCK);
-    if (extras && random_actions)
-        hipLaunchKernelGGL((step_kernel<true, true>), grid, block, 0, (hipStream_t)stream, a.boards, a.actions, a.n, a.env_base, a.flags, a.key.seed_lo, a.key.seed_hi, a.key.step_lo, a.key.step_hi, a.reward, a.done, a.legal, a.obs);
-    else if (extras)
-        hipLaunchKernelGGL((step_kernel<true, false>), grid, block, 0, (hipStream_t)stream, a.boards, a.actions, a.n, a.env_base, a.flags, a.key.seed_lo, a.key.seed_hi, a.key.step_lo, a.key.step_hi, a.reward, a.done, a.legal, a.obs);
-    else if (random_actions)
-        hipLaunchKernelGGL((step_kernel<false, true>), grid, block, 0, (hipStream_t)stream, a.boards, a.actions, a.n, a.env_base, a.flags, a.key.seed_lo, a.key.seed_hi, a.key.step_lo, a.key.step_hi, a.reward, a.done, a.legal, a.obs);
-    else
-        hipLaunchKernelGGL((step_kernel<false, false>), grid, block, 0, (hipStream_t)stream, a.boards, a.actions, a.n, a.env_base, a.flags, a.key.seed_lo, a.key.seed_hi, a.key.step_lo, a.key.step_hi, a.reward, a.done, a.legal, a.obs);
+    launch_step(a, (hipStream_t)stream);
     return launched("env2048_step launch");
+}
+
+int env2048_step_many(int device, void *stream, uint64_t count, const env2048_step_args *args)
+{
+    if (count == 0) return ENV2048_OK;
+    if (!args) return fail(ENV2048_ERR_INVALID_ARG, "env2048_step_many: args is NULL");
+    for (uint64_t k = 0; k < count; ++k)  // all or nothing: a bad record enqueues no launch at all
+        if (int rc = validate_step(args[k], "env2048_step_many")) return rc;
+    DeviceScope scope(device);
+    if (scope.rc) return scope.rc;
+    for (uint64_t k = 0; k < count; ++k)
+        if (args[k].n) launch_step(args[k], (hipStream_t)stream);
+    return launched("env2048_step_many launch");
+}
+
+int env2048_step_sequence(int device, void *stream, uint64_t n, uint64_t env_base, uint8_t *boards,
+                          const uint8_t *const *actions, int32_t *reward, uint8_t *done, uint8_t *legal, void *obs,
+                          uint64_t row_stride, uint64_t seed, uint64_t step_index, uint32_t count, uint32_t flags)
+{
+    if (count == 0) return ENV2048_OK;
+    if (!actions && !(flags & ENV2048_FLAG_RANDOM_ACTIONS))
+        return fail(ENV2048_ERR_INVALID_ARG, "env2048_step_sequence: actions is NULL without ENV2048_FLAG_RANDOM_ACTIONS");
+    if (step_index + count < step_index) return fail(ENV2048_ERR_RANGE, "env2048_step_sequence: step_index + count overflows");
+    if (row_stride && row_stride < n)
+        return fail(ENV2048_ERR_INVALID_ARG, "env2048_step_sequence: row_stride %llu is smaller than n = %llu (rows would overlap)",
+                    (unsigned long long)row_stride, (unsigned long long)n);
+    const uint32_t fmt = obs_format(flags);
+    const uint64_t obs_bytes = fmt == OBS_F32 ? 4u : 2u;
+    auto record = [&](uint32_t t) {
+        const uint64_t off = (uint64_t)t * row_stride;  // in boards
+        return env2048_step_args{n,
+                                 env_base,
+                                 boards,
+                                 (flags & ENV2048_FLAG_RANDOM_ACTIONS) || !actions ? nullptr : actions[t],
+                                 reward ? reward + off : nullptr,
+                                 done ? done + off : nullptr,
+                                 legal ? legal + off : nullptr,
+                                 obs ? static_cast<uint8_t *>(obs) + 16u * obs_bytes * off : nullptr,
+                                 seed,
+                                 step_index + t,
+                                 flags,
+                                 0u};
+    };
+    for (uint32_t t = 0; t < count; ++t)
+        if (int rc = validate_step(record(t), "env2048_step_sequence")) return rc;
+    if (n == 0) return ENV2048_OK;
+    DeviceScope scope(device);
+    if (scope.rc) return scope.rc;
+    for (uint32_t t = 0; t < count; ++t) launch_step(record(t), (hipStream_t)stream);
+    return launched("env2048_step_sequence launch");
 }
 
 int env2048_step_state_i32_to(int device, void *stream, uint64_t n, uint64_t env_base, const int32_t *boards_in,

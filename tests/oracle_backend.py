@@ -31,7 +31,7 @@ class OracleLibrary:
         self.calls = []  # (name, n) log, handy for asserting launch counts in host-logic tests
 
     def abi_version(self):
-        return 1
+        return 2
 
     def device_count(self):
         return 1
@@ -65,6 +65,19 @@ class OracleLibrary:
                 _view(obs, n * 16, np.uint16)[:] = (res['obs'].reshape(-1).view(np.uint32) >> 16).astype(np.uint16)
             else:
                 _view(obs, n * 16, np.float32)[:] = res['obs'].reshape(-1)
+
+    def step_many(self, device, stream, records):
+        for r in records:
+            self.step(device, stream, r.n, r.env_base, r.boards, r.actions, r.reward, r.done, r.legal, r.obs, r.seed, r.step_index,
+                      r.flags & 15)
+
+    def step_sequence(self, device, stream, n, env_base, boards, actions, reward, done, legal, obs, row_stride, seed, step_index,
+                      count, flags):
+        obs_bytes = 2 if flags & 12 else 4
+        off = lambda p, t, scale: None if p is None else int(p) + t * row_stride * scale
+        for t in range(count):
+            self.step(device, stream, n, env_base, boards, None if actions is None else actions[t], off(reward, t, 4),
+                      off(done, t, 1), off(legal, t, 1), off(obs, t, 16 * obs_bytes), seed, step_index + t, flags & 15)
 
     def step_state_i32(self, device, stream, n, env_base, boards, actions, step_count, done_io, total_reward, reward, max_tile,
                        seed, step_index):

@@ -1,5 +1,10 @@
 #!/usr/bin/env python3
-"""Turn gpurun_out/<tag>/ (written by tools/profile_step.sh) into the committed profiles/ files."""
+"""Turn gpurun_out/<tag>/ (written by tools/profile_step.sh) into the committed profiles/ files:
+    profiles/<label>_{resident,cold}_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the bench command
+    profiles/<label>_pmc_summary.json                   counter means per launch of step_kernel<false, false>, both legs
+    profiles/<label>_bench.json, _bench_driver_shape.json
+    profiles/step_pmc.json                              what bench.py reads (keyed by leg:boards, stamped with the kernel-source hash)
+usage: tools/summarize_profiles.py <gpurun_out tag> <label>"""
 import csv
 import glob
 import json
@@ -9,47 +14,73 @@ import sys
 from pathlib import Path
 
 REPO = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO))
+import bench  # noqa: E402  (kernel_source_sha only; nothing touches a GPU)
+
+KERNEL = 'step_kernel<false, false>'
+BOARDS = 1 << 20
 
 
-def main(tag, label):
-    src = REPO / 'gpurun_out' / tag
-    dst = REPO / 'profiles'
-    dst.mkdir(exist_ok=True)
-    stats = glob.glob(str(src / 'stats' / '*' / '*kernel_stats.csv'))
-    if stats:
-        shutil.copy(stats[0], dst / f'{label}_kernel_stats.csv')
+def leg_counters(src: Path, leg: str) -> dict:
     counters = {}
-    for path in glob.glob(str(src / 'pmc_*' / '*' / '*counter_collection.csv')):
-        rows = [r for r in csv.DictReader(open(path)) if 'step_kernel' in r['Kernel_Name']]
+    for path in glob.glob(str(src / f'pmc_{leg}_*' / '*' / '*counter_collection.csv')):
+        rows = [r for r in csv.DictReader(open(path)) if KERNEL in r['Kernel_Name']]
         by_name = {}
         for r in rows:
             by_name.setdefault(r['Counter_Name'], []).append(float(r['Counter_Value']))
         for name, vals in by_name.items():
             vals = vals[len(vals) // 4:]  # skip the warm-up launches
             counters[name] = {'mean': statistics.mean(vals), 'launches': len(vals)}
-    summary = {'kernel': 'step_kernel<false>', 'boards_per_launch': 1 << 20, 'counters': counters}
-    if 'FETCH_SIZE' in counters and 'WRITE_SIZE' in counters:
-        # rocprofv3 reports KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide coalesced
-        # reads -> double it (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact for 16-B stores.
-        fetch = counters['FETCH_SIZE']['mean'] * 1024 * 2
-        write = counters['WRITE_SIZE']['mean'] * 1024
-        summary['hbm_bytes_per_launch'] = fetch + write
-        summary['hbm_read_bytes'] = fetch
-        summary['hbm_write_bytes'] = write
-        summary['algorithmic_bytes_per_launch'] = 38 * (1 << 20)
-        traffic_path = dst / 'traffic.json'
-        table = json.loads(traffic_path.read_text()) if traffic_path.exists() else {}
-        table[str(1 << 20)] = {'hbm_bytes_per_launch': fetch + write, 'source': f'profiles/{label}_pmc_summary.json',
-                               'formula': '(2*FETCH_SIZE + WRITE_SIZE) KiB, separate --pmc passes'}
-        traffic_path.write_text(json.dumps(table, indent=1) + '\n')
-    if 'SQ_INSTS_VALU' in counters and 'SQ_WAVES' in counters:
-        summary['valu_instructions_per_board'] = counters['SQ_INSTS_VALU']['mean'] * 64 / (1 << 20) / 64 * 64 / 64 * 1.0
-        summary['valu_instructions_per_board'] = counters['SQ_INSTS_VALU']['mean'] / counters['SQ_WAVES']['mean'] / 4
+    return counters
+
+
+def kernel_avg_us(stats_csv: Path):
+    for r in csv.DictReader(open(stats_csv)):
+        if KERNEL in r['Name']:
+            return {'calls': int(r['Calls']), 'avg_us': float(r['AverageNs']) / 1e3, 'min_us': float(r['MinNs']) / 1e3,
+                    'max_us': float(r['MaxNs']) / 1e3}
+    return None
+
+
+def main(tag, label):
+    src = REPO / 'gpurun_out' / tag
+    dst = REPO / 'profiles'
+    dst.mkdir(exist_ok=True)
+    summary = {'kernel': KERNEL, 'boards_per_launch': BOARDS, 'kernel_source_sha': bench.kernel_source_sha(),
+               'algorithmic_bytes_per_launch': 38 * BOARDS, 'legs': {}}
+    table_path = dst / 'step_pmc.json'
+    table = {'kernel_source_sha': bench.kernel_source_sha(), 'entries': {},
+             'formula': 'fabric bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB from separate rocprofv3 --pmc passes (gfx950: FETCH_SIZE counts '
+                        'wide coalesced reads at half their bytes; MI355X_MICROARCH.md, HBM section); counts Infinity-Cache hits'}
+    for leg in ('resident', 'cold'):
+        stats = glob.glob(str(src / f'stats_{leg}' / '*' / '*kernel_stats.csv'))
+        entry = {}
+        if stats:
+            shutil.copy(stats[0], dst / f'{label}_{leg}_kernel_stats.csv')
+            entry['rocprof_kernel_stats'] = kernel_avg_us(Path(stats[0]))
+        counters = leg_counters(src, leg)
+        entry['counters'] = counters
+        if 'FETCH_SIZE' in counters and 'WRITE_SIZE' in counters:
+            fetch = counters['FETCH_SIZE']['mean'] * 1024 * 2
+            write = counters['WRITE_SIZE']['mean'] * 1024
+            entry.update(fabric_read_bytes=fetch, fabric_write_bytes=write, fabric_bytes_per_launch=fetch + write,
+                         traffic_over_algorithmic=(fetch + write) / (38 * BOARDS))
+            row = {'fabric_bytes_per_launch': fetch + write, 'source': f'profiles/{label}_pmc_summary.json'}
+            if 'SQ_INSTS_VALU' in counters:
+                row['valu_insts_per_launch'] = counters['SQ_INSTS_VALU']['mean']
+            table['entries'][f'{leg}:{BOARDS}'] = row
+        if 'SQ_INSTS_VALU' in counters and 'SQ_WAVES' in counters:
+            entry['valu_instructions_per_board'] = counters['SQ_INSTS_VALU']['mean'] / counters['SQ_WAVES']['mean'] / 4
+        summary['legs'][leg] = entry
     (dst / f'{label}_pmc_summary.json').write_text(json.dumps(summary, indent=1) + '\n')
-    bench = src / 'bench_default.json'
-    if bench.exists() and bench.stat().st_size:
-        shutil.copy(bench, dst / f'{label}_bench.json')
-    print(json.dumps(summary, indent=1)[:1500])
+    if table['entries']:
+        table_path.write_text(json.dumps(table, indent=1) + '\n')
+    for name in ('bench_default', 'bench_driver_shape'):
+        f = src / f'{name}.json'
+        if f.exists() and f.stat().st_size:
+            shutil.copy(f, dst / f'{label}_{name}.json')
+    brief = {leg: {k: v for k, v in e.items() if k != 'counters'} for leg, e in summary['legs'].items()}
+    print(json.dumps(brief, indent=1))
 
 
 if __name__ == '__main__':
