@@ -20,6 +20,7 @@ Fixture sets:
   trajectories.npz  G4  full games under the build's Philox contract replayed by the reference engine
   resets.npz        G5  reset boards under the Philox contract (two sequential injected spawns)
   transforms.npz        encode_flatten(...,31) one-hot observations and normalize_reward values
+  chance_outcomes.npz   after_state(board): every (empty cell, value) outcome in the reference's order + float64 probabilities
 """
 
 from __future__ import annotations
@@ -290,6 +291,36 @@ def gen_transforms(rng):
     return n
 
 
+def gen_chance_outcomes():
+    """The reference's after_state (gameboard.py:132-171) itself: enumeration order and float64 probabilities.
+    Own generator, so the older fixture sets keep their bytes."""
+    rng = np.random.default_rng(20481)
+    boards = mixture(rng, n_play=420, n_uniform=60, n_dense=80, n_big=40)
+    extra = []
+    for _ in range(60):  # exactly one empty cell / full boards / one tile only
+        b = rng.integers(1, 12, size=16).astype(np.uint8)
+        if rng.random() < 0.6:
+            b[int(rng.integers(0, 16))] = 0
+        extra.append(b)
+    for c in range(16):
+        b = np.zeros(16, dtype=np.uint8)
+        b[c] = int(rng.integers(1, MAX_E + 1))
+        extra.append(b)
+    boards = np.concatenate([boards, np.stack(extra)]).astype(np.uint8)
+    n = boards.shape[0]
+    out = np.zeros((n, 32, 16), dtype=np.uint8)
+    prob = np.zeros((n, 32), dtype=np.float64)
+    count = np.zeros(n, dtype=np.uint8)
+    for i in range(n):
+        outcomes = ref_board.after_state(to_values(boards[i]).reshape(4, 4))
+        count[i] = len(outcomes)
+        for s, (state, pr) in enumerate(outcomes):
+            out[i, s] = to_exps(state).reshape(16)
+            prob[i, s] = pr
+    np.savez_compressed(OUT / 'chance_outcomes.npz', boards=boards, outcomes=out, prob=prob, count=count)
+    return n, int(count.max()), int((count == 1).sum())
+
+
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
     rng = np.random.default_rng(20480)
@@ -299,6 +330,7 @@ def main():
     print('trajectories', gen_trajectories())
     print('resets', gen_resets())
     print('transforms', gen_transforms(rng))
+    print('chance_outcomes', gen_chance_outcomes())
     with open(OUT / 'SHA256SUMS', 'w') as fh:
         for p in sorted(OUT.glob('*.npz')):
             fh.write(f'{hashlib.sha256(p.read_bytes()).hexdigest()}  {p.name}\n')

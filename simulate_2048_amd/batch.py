@@ -22,10 +22,10 @@ _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)  # int handle
 
 
 def _stream_handle(device: torch.device):
-    """(device ordinal, hipStream_t) of torch's CURRENT stream on `device`."""
+    """(device ordinal, hipStream_t) of torch's CURRENT stream on `device` (whose index is fixed at construction)."""
     if device.type != 'cuda':
         return -1, None
-    index = device.index if device.index is not None else torch.cuda.current_device()
+    index = device.index
     if _raw_stream is not None:
         return index, _raw_stream(index)
     return index, torch.cuda.current_stream(device).cuda_stream
@@ -74,6 +74,10 @@ class BatchedEnv2048:
             lib = capi.library()
             if lib.device_count() <= 0:
                 raise RuntimeError('no HIP device visible to libenv2048')
+        if self.device.type == 'cuda' and self.device.index is None:
+            # resolve 'cuda' ONCE: the buffers live on the device that is current now, and every later launch must
+            # go to that device and one of its streams even if the process switches devices in between
+            self.device = torch.device('cuda', torch.cuda.current_device())
         self.lib = lib
         self.num_envs = int(num_envs)
         self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF

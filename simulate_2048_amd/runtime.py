@@ -10,8 +10,8 @@ host-side logic of the shims against an oracle-backed stand-in on CPU tensors.
 from __future__ import annotations
 
 import contextlib
-import itertools
 import os
+import threading
 
 import torch
 
@@ -64,12 +64,21 @@ def use(lib, device):
 # (twentyfortyeight/core/gameboard.py:20) and are not reproducible; here they walk a Philox stream
 # keyed by OS entropy.
 _entropy_seed = int.from_bytes(os.urandom(8), 'little')
-_entropy_counter = itertools.count()
+_entropy_lock = threading.Lock()
+_entropy_next = 0
 
 
-def entropy_stream() -> tuple[int, int]:
-    """(seed, step_index) for one unseeded draw."""
-    return _entropy_seed, next(_entropy_counter)
+def entropy_stream(count: int = 1) -> tuple[int, int]:
+    """(seed, first step_index) for one unseeded call that consumes ``count`` consecutive step words
+    (``fill_cells(state, number_tile=k)`` spawns with steps c .. c+k-1): the counter advances by ``count``,
+    so no two unseeded calls ever share a (seed, step_index, env) word -- like the reference's continuing
+    module-level generator (gameboard.py:20), every draw is fresh."""
+    global _entropy_next
+    count = max(1, int(count))
+    with _entropy_lock:
+        first = _entropy_next
+        _entropy_next += count
+    return _entropy_seed, first
 
 
 def seed_to_u64(seed) -> int:

@@ -14,8 +14,9 @@ def require_4x4(board: np.ndarray, what: str) -> None:
         )
 
 
-def rng_for(seed):
-    """(seed, step_index) of the Philox stream a call with `seed` draws from."""
+def rng_for(seed, count: int = 1):
+    """(seed, first step_index) of the Philox stream a call with `seed` draws from; ``count`` = how many
+    consecutive step words the call consumes (reserved on the process-wide entropy stream when unseeded)."""
     if seed is None:
-        return runtime.entropy_stream()
+        return runtime.entropy_stream(count)
     return runtime.seed_to_u64(seed), 0

@@ -86,7 +86,7 @@ def fill_cells(state: ndarray, number_tile: int, seed: int | None = None) -> nda
         return state
     number_tile = min(int(number_tile), num_available)
     require_4x4(np.asarray(state), 'board')
-    stream_seed, step = rng_for(seed)
+    stream_seed, step = rng_for(seed, number_tile)
     state[...] = scalar.current().spawn_random(state, stream_seed, step, number_tile, state.dtype)
     return state
 

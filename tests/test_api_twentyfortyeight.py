@@ -6,6 +6,8 @@ stand-in (host logic, CPU) and, on the GPU box, with the real HIP library.
 """
 
 import numpy as np
+
+import oracle
 import pytest
 
 from simulate_2048_amd.twentyfortyeight.core.gameboard import (
@@ -132,6 +134,22 @@ def test_after_state_enumeration():
     assert after_state(full)[0][1] == 1.0
     with pytest.raises(ValueError):
         generate_outcome(full, (0, 0), 2, 0)
+
+
+def test_after_state_equals_the_reference_fixture(golden):
+    """gameboard.after_state against outcomes the reference's own after_state produced (tests/golden/chance_outcomes.npz):
+    same order, same boards, the SAME float64 probabilities (the mirror divides in float64 like the reference)."""
+    g = golden['chance_outcomes']
+    rng = np.random.default_rng(0)
+    picks = np.concatenate([rng.choice(g['boards'].shape[0], size=60, replace=False), np.flatnonzero(g['count'] == 1)[:5],
+                            np.flatnonzero(g['count'] == 2)[:5], np.flatnonzero(g['count'] == 32)[:2]])
+    for i in picks:
+        board = oracle.unpack_values(g['boards'][i]).reshape(4, 4)
+        outcomes = after_state(board)
+        assert len(outcomes) == int(g['count'][i])
+        for s, (state, prob) in enumerate(outcomes):
+            np.testing.assert_array_equal(oracle.pack_values(state).reshape(16), g['outcomes'][i, s])
+            assert prob == g['prob'][i, s]
 
 
 def test_fill_cells_mutates_in_place():

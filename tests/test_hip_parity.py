@@ -493,6 +493,22 @@ def test_chance_outcomes_match_oracle(lib, golden):
     np.testing.assert_allclose(sums, 1.0, atol=1e-6)
 
 
+def test_chance_outcomes_vs_reference_after_state(lib, golden):
+    """env2048_chance_outcomes against the reference's own after_state outputs (tests/golden/chance_outcomes.npz):
+    order and boards bit-exact; probabilities are float32 on device vs float64 in the reference: 2 ulp f32."""
+    g = golden['chance_outcomes']
+    n = g['boards'].shape[0]
+    b = cu(g['boards'])
+    out = torch.full((n, 32, 16), 99, dtype=torch.uint8, device='cuda')
+    prob = torch.full((n, 32), -1.0, dtype=torch.float32, device='cuda')
+    count = torch.zeros((n,), dtype=torch.uint8, device='cuda')
+    lib.chance_outcomes(DEV, stream(), n, p(b), p(out), p(prob), p(count))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(count.cpu().numpy(), g['count'])
+    np.testing.assert_array_equal(out.cpu().numpy(), g['outcomes'])
+    np.testing.assert_allclose(prob.cpu().numpy().astype(np.float64), g['prob'], rtol=2.4e-7, atol=0.0)
+
+
 def test_spawn_random_and_onehot_match_oracle(lib, golden):
     boards = golden['afterstates']['boards']
     n = boards.shape[0]

@@ -264,3 +264,44 @@ def test_trajectory_buffer_records_in_place():
         traj.step(None)
     with pytest.raises(ValueError):
         env.step(None, out_reward=torch.zeros(n, dtype=torch.int64))
+
+
+def test_unseeded_calls_never_share_a_philox_word():
+    """fill_cells(state, number_tile=k, seed=None) consumes k consecutive step words, so the entropy
+    stream must reserve k indices -- otherwise the first unseeded step after reset() re-used the word of the
+    second start tile (its spawn was then fully determined by that tile)."""
+    from simulate_2048_amd import runtime
+    from simulate_2048_amd.twentyfortyeight.core import _device
+
+    seed_a, first = runtime.entropy_stream(2)
+    seed_b, after = runtime.entropy_stream()
+    assert seed_a == seed_b and after == first + 2
+    assert runtime.entropy_stream(5)[1] == after + 1 and runtime.entropy_stream()[1] == after + 6
+    assert _device.rng_for(None, 3)[1] == after + 7 and _device.rng_for(None)[1] == after + 10
+    assert _device.rng_for(123, 4) == (123, 0)  # a seeded call always starts its own stream at 0
+
+
+def test_unseeded_reset_then_step_draw_independent_words():
+    """Behavioural form of the same fix, through the mirror on the oracle stand-in: after an unseeded
+    fill_cells(zeros, 2) the next unseeded single spawn on a 15-empty board must NOT repeat the (rank, value)
+    of the second start tile every time."""
+    from simulate_2048_amd import runtime
+    from simulate_2048_amd.twentyfortyeight.core import gameboard
+
+    with runtime.use(OracleLibrary(), 'cpu'):
+        same = 0
+        trials = 300
+        for _ in range(trials):
+            a = gameboard.fill_cells(np.zeros((4, 4), dtype=np.int64), 2, None)
+            first_cells = np.argwhere(a != 0)
+            b = np.zeros((4, 4), dtype=np.int64)
+            b[tuple(first_cells[0])] = 2  # any board with 15 empties
+            before = b.copy()
+            gameboard.fill_cells(b, 1, None)
+            new_cell = np.argwhere((b != 0) & (before == 0))[0]
+            rank = int(((before == 0).reshape(-1)[: 4 * new_cell[0] + new_cell[1]]).sum())
+            # the second start tile's rank among the 15 cells left after the first one, and its value
+            flat = (a != 0).reshape(-1)
+            idx = np.flatnonzero(flat)
+            same += int(rank in (idx[1] - 1, idx[0]) and b[tuple(new_cell)] in a)
+        assert same < trials * 0.5  # before the fix: 100 %

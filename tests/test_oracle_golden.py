@@ -178,6 +178,20 @@ def test_resets(golden):
     assert set(np.unique(boards).tolist()) <= {0, 1, 2}
 
 
+def test_chance_outcomes_vs_reference_after_state(golden):
+    """The reference's after_state itself (gameboard.py:132-171, called by oracle/gen_golden.py): enumeration order
+    (empty cells row-major, value 2 then 4), outcome boards, float64 probabilities P(value)/n_empty, the full-board
+    case.  The oracle (and the kernel it checks) emits float32 probabilities: (float)0.9 or 0.1 divided by n in
+    float32 -- tolerance 2 ulp of float32 (2.4e-7 relative) against the reference's float64 value."""
+    g = golden['chance_outcomes']
+    res = oracle.chance_outcomes(g['boards'])
+    np.testing.assert_array_equal(res['count'], g['count'])
+    np.testing.assert_array_equal(res['boards'], g['outcomes'])
+    np.testing.assert_allclose(res['prob'].astype(np.float64), g['prob'], rtol=2.4e-7, atol=0.0)
+    assert int(g['count'].max()) == 32 and int((g['count'] == 1).sum()) > 50  # 16 empties down to none at all
+    np.testing.assert_allclose(g['prob'].sum(axis=1), 1.0, atol=1e-12)
+
+
 def test_batch_is_independent_of_slicing(golden):
     """Multi-GPU determinism: slices with the right env_base equal the whole."""
     g = golden['trajectories']
