@@ -181,6 +181,28 @@ ENV2048_EXPORT int env2048_step_state_i32_to(int device, void *stream, uint64_t 
                                              int32_t *max_tile, uint64_t seed, uint64_t step_index);
 
 /*
+ * The same transition with ONE PRNG KEY PER ENVIRONMENT -- what jax.vmap(step)(states, actions, keys) means in the
+ * reference (reinforce/game/env.py:193-211; the caller splits a fresh key for every environment and move,
+ * reinforce/training/self_play.py:351-354): keys is n x 2 uint32, and environment i draws exactly what the scalar
+ * form draws for a batch of one with seed = (keys[i][0] << 32) | keys[i][1], env_base 0, step_index 0.  Row i of
+ * the result therefore equals the single-environment step with keys[i], and it does not depend on i or on the
+ * other rows.
+ * [replaces: reinforce/game/env.py:79-133 step under jax.vmap, :193-211 batched_step]
+ */
+ENV2048_EXPORT int env2048_step_state_i32_keyed(int device, void *stream, uint64_t n, const uint32_t *keys, const int32_t *boards_in,
+                                                int32_t *boards_out, const int32_t *actions, const int32_t *step_count_in,
+                                                int32_t *step_count_out, const uint8_t *done_in, uint8_t *done_out,
+                                                const float *total_reward_in, float *total_reward_out, float *reward,
+                                                int32_t *max_tile);
+
+/*
+ * Fresh int32 VALUE boards (n x 16), one PRNG key per environment: board i = the board env2048_reset gives a batch of
+ * one with seed = (keys[i][0] << 32) | keys[i][1], env_base 0, step_index 0 (zeros + two sequential spawns).
+ * [replaces: reinforce/game/core.py:324-343 create_initial_board under jax.vmap; reinforce/game/env.py:176-190 batched_reset]
+ */
+ENV2048_EXPORT int env2048_reset_keyed_i32(int device, void *stream, uint64_t n, const uint32_t *keys, int32_t *boards);
+
+/*
  * Per-move queries of the reinforce/game callers on int32 tile VALUE boards (n x 16), one launch, each
  * output optional:
  *     obs[16*i..]    float32 log2(tile)/16, 0 for empty      (encode_observation, core.py:346-377)

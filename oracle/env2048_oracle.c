@@ -426,6 +426,33 @@ ORACLE_API int oracle_step_state_i32(uint64_t n, uint64_t env_base, int32_t *boa
     return 0;
 }
 
+/* The same under jax.vmap with one key per environment [ref: reinforce/game/env.py:193-211 batched_step =
+ * vmap(step); the caller hands every environment its own key, reinforce/training/self_play.py:351-354]: row i is BY
+ * DEFINITION the single-environment step with seed (keys[i][0] << 32) | keys[i][1] -- the composition below. */
+ORACLE_API int oracle_step_state_i32_keyed(uint64_t n, const uint32_t *keys, int32_t *boards, const int32_t *actions,
+                                           int32_t *step_count, uint8_t *done_io, float *total_reward, float *reward,
+                                           int32_t *max_tile)
+{
+    for (uint64_t i = 0; i < n; ++i) {
+        uint64_t seed = ((uint64_t)keys[2 * i] << 32) | keys[2 * i + 1];
+        oracle_step_state_i32(1, 0, boards + 16 * i, actions + i, step_count ? step_count + i : NULL, done_io + i,
+                              total_reward ? total_reward + i : NULL, reward + i, max_tile ? max_tile + i : NULL, seed, 0);
+    }
+    return 0;
+}
+
+/* [ref: reinforce/game/core.py:324-343 create_initial_board under vmap; env.py:176-190 batched_reset]  fresh int32
+ * value boards, board i from the reset block of environment 0, step 0 of the stream seeded with keys[i]. */
+ORACLE_API int oracle_reset_keyed_i32(uint64_t n, const uint32_t *keys, int32_t *boards)
+{
+    for (uint64_t i = 0; i < n; ++i) {
+        uint8_t b[16];
+        oracle_reset_board(((uint64_t)keys[2 * i] << 32) | keys[2 * i + 1], 0, 0, b);
+        for (int c = 0; c < 16; ++c) boards[16 * i + c] = b[c] ? (int32_t)1 << b[c] : 0;
+    }
+    return 0;
+}
+
 /* Afterstate only [ref: gameboard.py:105-129 latent_state; reinforce/game/core.py:129-170]:
  * out = slide/merge of in under action; reward = score (NOT zeroed for invalid moves: an
  * invalid move merges nothing, so it is 0 anyway); changed = (out != in)

@@ -57,6 +57,9 @@ PROTOTYPES = {
     'env2048_step_state_i32': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _u64, _u64]),
     'env2048_step_state_i32_to': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _u64,
                                             _u64]),
+    'env2048_step_state_i32_keyed': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
+                                               _ptr]),
+    'env2048_reset_keyed_i32': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr]),
     'env2048_status_i32': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr]),
     'env2048_rollout': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _u64, _u64, _u32, _ptr, _ptr, _ptr, _u32]),
     'env2048_afterstate': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr, _ptr]),
@@ -147,6 +150,15 @@ class Library:
         self._check(self._dll.env2048_step_state_i32_to(device, stream, n, env_base, boards_in, boards_out, actions, step_count_in,
                                                         step_count_out, done_in, done_out, total_in, total_out, reward, max_tile,
                                                         seed, step_index))
+
+    def step_state_i32_keyed(self, device, stream, n, keys, boards_in, boards_out, actions, step_count_in, step_count_out,
+                             done_in, done_out, total_in, total_out, reward, max_tile) -> None:
+        self._check(self._dll.env2048_step_state_i32_keyed(device, stream, n, keys, boards_in, boards_out, actions, step_count_in,
+                                                           step_count_out, done_in, done_out, total_in, total_out, reward,
+                                                           max_tile))
+
+    def reset_keyed_i32(self, device, stream, n, keys, boards) -> None:
+        self._check(self._dll.env2048_reset_keyed_i32(device, stream, n, keys, boards))
 
     def status_i32(self, device, stream, n, boards, obs, legal4, done) -> None:
         self._check(self._dll.env2048_status_i32(device, stream, n, boards, obs, legal4, done))

@@ -643,7 +643,7 @@ __global__ __launch_bounds__(BLOCK) void step_state_i32_kernel(uint64_t n, uint6
                                                                const int32_t *step_count_in, int32_t *step_count_out,
                                                                const uint8_t *done_in, uint8_t *done_out,
                                                                const float *total_in, float *total_out, float *reward_out,
-                                                               int32_t *max_tile, RngKey key)
+                                                               int32_t *max_tile, RngKey key, const uint2 *keys)
 {
     const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
@@ -653,7 +653,13 @@ __global__ __launch_bounds__(BLOCK) void step_state_i32_kernel(uint64_t n, uint6
     Board bd{pack4(v0), pack4(v1), pack4(v2), pack4(v3)};
     const bool was_done = done_in[i] != 0;
     const bool in_place = boards_in == boards_out && done_in == done_out && step_count_in == step_count_out && total_in == total_out;
-    const uint64_t env = env_base + i;
+    // keyed form: environment i draws from ITS OWN key, as environment 0 at step 0 of the stream seeded with
+    // (keys[i][0] << 32) | keys[i][1] -- row i of the batch equals the single-environment call with keys[i]
+    const uint64_t env = keys ? 0u : env_base + i;
+    if (keys) {
+        const uint2 k = keys[i];
+        key = RngKey{k.y, k.x, 0u, 0u};
+    }
     uint32_t w[4];
     env_block(key, env >> 2, STREAM_STEP, w[0], w[1], w[2], w[3]);
     const uint32_t sel = (uint32_t)env & 3u;
@@ -699,6 +705,23 @@ __global__ __launch_bounds__(BLOCK) void step_state_i32_kernel(uint64_t n, uint6
         }
         max_tile[i] = m ? (int32_t)(1u << (m & 31u)) : 0;
     }
+}
+
+// batched_reset with one PRNG key per environment, straight to int32 value boards: board i = the fresh board of
+// environment 0 at step 0 of the stream seeded with keys[i] (= create_initial_board(keys[i])).
+__global__ __launch_bounds__(BLOCK) void reset_keyed_i32_kernel(uint64_t n, const uint2 *keys, int32_t *boards)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint2 k = keys[i];
+    uint32_t w0, w1, w2, w3;
+    env_block(RngKey{k.y, k.x, 0u, 0u}, 0u, STREAM_RESET, w0, w1, w2, w3);
+    const Board bd = fresh_board(w0, w1, w2, w3);
+    int4 *rows = reinterpret_cast<int4 *>(boards) + 4 * i;
+    rows[0] = unpack4(bd.r0);
+    rows[1] = unpack4(bd.r1);
+    rows[2] = unpack4(bd.r2);
+    rows[3] = unpack4(bd.r3);
 }
 
 // What the reinforce/game callers ask about a batch of int32 value boards, in one launch: the f32
@@ -1226,21 +1249,21 @@ int env2048_step_sequence(int device, void *stream, uint64_t n, uint64_t env_bas
     return launched("env2048_step_sequence launch");
 }
 
-int env2048_step_state_i32_to(int device, void *stream, uint64_t n, uint64_t env_base, const int32_t *boards_in,
-                              int32_t *boards_out, const int32_t *actions, const int32_t *step_count_in, int32_t *step_count_out,
-                              const uint8_t *done_in, uint8_t *done_out, const float *total_reward_in, float *total_reward_out,
-                              float *reward, int32_t *max_tile, uint64_t seed, uint64_t step_index)
+static int step_state_i32_common(const char *who, int device, void *stream, uint64_t n, uint64_t env_base, const uint32_t *keys,
+                                 const int32_t *boards_in, int32_t *boards_out, const int32_t *actions, const int32_t *step_count_in,
+                                 int32_t *step_count_out, const uint8_t *done_in, uint8_t *done_out, const float *total_reward_in,
+                                 float *total_reward_out, float *reward, int32_t *max_tile, uint64_t seed, uint64_t step_index)
 {
     if (n == 0) return ENV2048_OK;
     if (!boards_in || !boards_out || !actions || !done_in || !done_out || !reward)
-        return fail(ENV2048_ERR_INVALID_ARG, "env2048_step_state_i32: boards, actions, done and reward are required");
+        return fail(ENV2048_ERR_INVALID_ARG, "%s: boards, actions, done and reward are required", who);
     if ((step_count_in == nullptr) != (step_count_out == nullptr) || (total_reward_in == nullptr) != (total_reward_out == nullptr))
-        return fail(ENV2048_ERR_INVALID_ARG, "env2048_step_state_i32: step_count / total_reward need both their in and out array");
-    if (misaligned(boards_in, 16) || misaligned(boards_out, 16))
-        return fail(ENV2048_ERR_ALIGNMENT, "env2048_step_state_i32: boards must be 16-byte aligned");
+        return fail(ENV2048_ERR_INVALID_ARG, "%s: step_count / total_reward need both their in and out array", who);
+    if (misaligned(boards_in, 16) || misaligned(boards_out, 16)) return fail(ENV2048_ERR_ALIGNMENT, "%s: boards must be 16-byte aligned", who);
     if (misaligned(actions, 4) || misaligned(step_count_in, 4) || misaligned(step_count_out, 4) || misaligned(total_reward_in, 4) ||
         misaligned(total_reward_out, 4) || misaligned(reward, 4) || misaligned(max_tile, 4))
-        return fail(ENV2048_ERR_ALIGNMENT, "env2048_step_state_i32: misaligned 4-byte array");
+        return fail(ENV2048_ERR_ALIGNMENT, "%s: misaligned 4-byte array", who);
+    if (misaligned(keys, 8)) return fail(ENV2048_ERR_ALIGNMENT, "%s: keys must be 8-byte aligned", who);
     if (int rc = check_range(n, env_base)) return rc;
     if (int rc = check_count(n)) return rc;
     DeviceScope scope(device);
@@ -1248,8 +1271,43 @@ int env2048_step_state_i32_to(int device, void *stream, uint64_t n, uint64_t env
     const RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)step_index, (uint32_t)(step_index >> 32)};
     hipLaunchKernelGGL(step_state_i32_kernel, grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, n, env_base, boards_in, boards_out,
                        actions, step_count_in, step_count_out, done_in, done_out, total_reward_in, total_reward_out, reward,
-                       max_tile, key);
-    return launched("env2048_step_state_i32 launch");
+                       max_tile, key, reinterpret_cast<const uint2 *>(keys));
+    return launched(who);
+}
+
+int env2048_step_state_i32_to(int device, void *stream, uint64_t n, uint64_t env_base, const int32_t *boards_in,
+                              int32_t *boards_out, const int32_t *actions, const int32_t *step_count_in, int32_t *step_count_out,
+                              const uint8_t *done_in, uint8_t *done_out, const float *total_reward_in, float *total_reward_out,
+                              float *reward, int32_t *max_tile, uint64_t seed, uint64_t step_index)
+{
+    return step_state_i32_common("env2048_step_state_i32", device, stream, n, env_base, nullptr, boards_in, boards_out, actions,
+                                 step_count_in, step_count_out, done_in, done_out, total_reward_in, total_reward_out, reward, max_tile,
+                                 seed, step_index);
+}
+
+int env2048_step_state_i32_keyed(int device, void *stream, uint64_t n, const uint32_t *keys, const int32_t *boards_in,
+                                 int32_t *boards_out, const int32_t *actions, const int32_t *step_count_in, int32_t *step_count_out,
+                                 const uint8_t *done_in, uint8_t *done_out, const float *total_reward_in, float *total_reward_out,
+                                 float *reward, int32_t *max_tile)
+{
+    if (n && !keys) return fail(ENV2048_ERR_INVALID_ARG, "env2048_step_state_i32_keyed: keys is NULL");
+    return step_state_i32_common("env2048_step_state_i32_keyed", device, stream, n, 0, keys, boards_in, boards_out, actions,
+                                 step_count_in, step_count_out, done_in, done_out, total_reward_in, total_reward_out, reward, max_tile,
+                                 0, 0);
+}
+
+int env2048_reset_keyed_i32(int device, void *stream, uint64_t n, const uint32_t *keys, int32_t *boards)
+{
+    if (n == 0) return ENV2048_OK;
+    if (!keys || !boards) return fail(ENV2048_ERR_INVALID_ARG, "env2048_reset_keyed_i32: keys and boards are required");
+    if (misaligned(keys, 8) || misaligned(boards, 16))
+        return fail(ENV2048_ERR_ALIGNMENT, "env2048_reset_keyed_i32: keys must be 8-byte, boards 16-byte aligned");
+    if (int rc = check_count(n)) return rc;
+    DeviceScope scope(device);
+    if (scope.rc) return scope.rc;
+    hipLaunchKernelGGL(reset_keyed_i32_kernel, grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, n, reinterpret_cast<const uint2 *>(keys),
+                       boards);
+    return launched("env2048_reset_keyed_i32 launch");
 }
 
 int env2048_step_state_i32(int device, void *stream, uint64_t n, uint64_t env_base, int32_t *boards, const int32_t *actions,

@@ -4,8 +4,13 @@ per function): ``GameState``, ``reset``/``step``, the ``batched_*`` forms and th
 ``Environment`` wrapper.  State fields are ``torch`` tensors on the GPU.
 
 The batched forms are what ``reinforce/training/self_play.py:300,316-317,354`` calls once per
-move; each is one pack + one fused step kernel + one unpack here.  For throughput work use
-``simulate_2048_amd.BatchedEnv2048``, which keeps boards packed and skips the conversions.
+move; each is ONE kernel launch here (int32 value boards in, int32 value boards out).  Everything
+returned is an ``interop.DeviceArray`` -- a GPU-resident torch tensor that ``np.array(...)`` copies to
+the host in one go -- and every argument may be a torch tensor, a NumPy array or any ``__dlpack__`` /
+``__array__`` producer (JAX ``(N, 2)`` uint32 keys, ``(N,)`` int32 actions), so the caller's loop runs
+unchanged.  Randomness follows the reference's contract ``batched_step == vmap(step)``: environment i
+draws from ``keys[i]`` only, so row i equals ``step(states[i], actions[i], keys[i])``.
+For throughput work use ``simulate_2048_amd.BatchedEnv2048``, which keeps boards packed.
 """
 
 from __future__ import annotations
@@ -14,7 +19,8 @@ from typing import NamedTuple
 
 import torch
 
-from ... import ops, runtime
+from ... import runtime
+from ...interop import key_words, keys_on_device, to_tensor, wrap
 from .core import _board_tensor
 
 
@@ -28,32 +34,26 @@ class GameState(NamedTuple):
     total_reward: torch.Tensor
 
 
-def _keys_to_seed(keys) -> int:
-    t = torch.as_tensor(keys)
-    return runtime.seed_to_u64(t.reshape(-1, 2)[0] if t.numel() >= 2 else t)
-
-
-def _max_tile_values(packed: torch.Tensor) -> torch.Tensor:
-    e = ops.status(packed, done=False, legal=False, max_exp=True)['max_exp'].to(torch.int32)
-    return torch.where(e > 0, torch.ones_like(e) << e, torch.zeros_like(e))
-
-
 def batched_reset(keys) -> GameState:
-    """[ref env.py:176-190] fresh games for every key row: keys (N, 2) -> GameState with leading N."""
+    """[ref env.py:176-190] fresh games, one per key row: keys (N, 2) -> GameState with leading N.
+    One launch (env2048_reset_keyed_i32); board i depends on keys[i] only (= reset(keys[i]))."""
     rt = runtime.current()
-    n = int(torch.as_tensor(keys).reshape(-1, 2).shape[0])
-    packed = ops.reset(n, _keys_to_seed(keys))
+    k = keys_on_device(keys, rt.device)
+    n = int(k.shape[0])
+    board = torch.empty((n, 4, 4), dtype=torch.int32, device=rt.device)
+    dev, stream = rt.handles()
+    rt.lib.reset_keyed_i32(dev, stream, n, k.data_ptr(), board.data_ptr())
     return GameState(
-        board=ops.unpack(packed, dtype=torch.int32).reshape(n, 4, 4),
-        step_count=torch.zeros((n,), dtype=torch.int32, device=rt.device),
-        done=torch.zeros((n,), dtype=torch.bool, device=rt.device),
-        total_reward=torch.zeros((n,), dtype=torch.float32, device=rt.device),
+        board=wrap(board),
+        step_count=wrap(torch.zeros((n,), dtype=torch.int32, device=rt.device)),
+        done=wrap(torch.zeros((n,), dtype=torch.bool, device=rt.device)),
+        total_reward=wrap(torch.zeros((n,), dtype=torch.float32, device=rt.device)),
     )
 
 
 def _dev(x, dtype, n, rt) -> torch.Tensor:
     """`x` as a contiguous (n,) device tensor of `dtype`; no copy when it already is one."""
-    t = x if isinstance(x, torch.Tensor) else torch.as_tensor(x)
+    t = to_tensor(x)
     if t.dtype != dtype or t.device != rt.device:
         t = t.to(device=rt.device, dtype=dtype)
     return t.reshape(n).contiguous()
@@ -62,18 +62,21 @@ def _dev(x, dtype, n, rt) -> torch.Tensor:
 def batched_step(states: GameState, actions, keys):
     """[ref env.py:193-211] one move per environment -> (GameState, reward (N,) f32, done (N,) bool, info).
 
-    One fused, out-of-place kernel (env2048_step_state_i32_to): the input state is only read (functional
+    One fused, out-of-place kernel (env2048_step_state_i32_keyed): the input state is only read (functional
     API) and the new state is written to fresh tensors -- no copies on either side.  Finished games are
     frozen exactly like the reference's done-guard (env.py:103-104): state unchanged, reward 0.0, done True,
-    step_count not advanced.
+    step_count not advanced.  Environment i draws its tile from keys[i] alone (vmap semantics).
     """
     rt = runtime.current()
     board_in = _board_tensor(states.board).reshape(-1, 4, 4)
     n = board_in.shape[0]
+    k = keys_on_device(keys, rt.device)
+    if k.shape[0] != n:
+        raise ValueError(f'batched_step: {n} environments but {k.shape[0]} keys')
     steps_in = _dev(states.step_count, torch.int32, n, rt)
     total_in = _dev(states.total_reward, torch.float32, n, rt)
     acts = _dev(actions, torch.int32, n, rt)
-    d = states.done if isinstance(states.done, torch.Tensor) else torch.as_tensor(states.done)
+    d = to_tensor(states.done)
     if d.dtype == torch.bool and d.device == rt.device:
         done_in = d.reshape(n).contiguous().view(torch.uint8)  # same bytes, no copy
     else:
@@ -82,13 +85,13 @@ def batched_step(states: GameState, actions, keys):
     i32 = torch.empty((2, n), dtype=torch.int32, device=rt.device)   # step_count, max_tile
     f32 = torch.empty((2, n), dtype=torch.float32, device=rt.device)  # total_reward, reward
     done_u8 = torch.empty((n,), dtype=torch.uint8, device=rt.device)
-    step_count, max_tile, total, reward = i32[0], i32[1], f32[0], f32[1]
+    step_count, max_tile, total, reward = wrap(i32[0]), wrap(i32[1]), wrap(f32[0]), wrap(f32[1])
     dev, stream = rt.handles()
-    rt.lib.step_state_i32_to(dev, stream, n, 0, board_in.data_ptr(), board.data_ptr(), acts.data_ptr(), steps_in.data_ptr(),
-                             step_count.data_ptr(), done_in.data_ptr(), done_u8.data_ptr(), total_in.data_ptr(), total.data_ptr(),
-                             reward.data_ptr(), max_tile.data_ptr(), _keys_to_seed(keys), 0)
-    done = done_u8.view(torch.bool)
-    new_state = GameState(board=board, step_count=step_count, done=done, total_reward=total)
+    rt.lib.step_state_i32_keyed(dev, stream, n, k.data_ptr(), board_in.data_ptr(), board.data_ptr(), acts.data_ptr(),
+                                steps_in.data_ptr(), step_count.data_ptr(), done_in.data_ptr(), done_u8.data_ptr(),
+                                total_in.data_ptr(), total.data_ptr(), reward.data_ptr(), max_tile.data_ptr())
+    done = wrap(done_u8.view(torch.bool))
+    new_state = GameState(board=wrap(board), step_count=step_count, done=done, total_reward=total)
     info = {'max_tile': max_tile, 'step_count': step_count, 'total_reward': total}
     return new_state, reward, done, info
 
@@ -101,7 +104,7 @@ def batched_get_observation(states: GameState) -> torch.Tensor:
     obs = torch.empty((n, 16), dtype=torch.float32, device=rt.device)
     dev, stream = rt.handles()
     rt.lib.status_i32(dev, stream, n, boards.data_ptr(), obs.data_ptr(), None, None)
-    return obs
+    return wrap(obs)
 
 
 def batched_get_legal_actions(states: GameState) -> torch.Tensor:
@@ -112,7 +115,7 @@ def batched_get_legal_actions(states: GameState) -> torch.Tensor:
     legal = torch.empty((n, 4), dtype=torch.uint8, device=rt.device)
     dev, stream = rt.handles()
     rt.lib.status_i32(dev, stream, n, boards.data_ptr(), None, legal.data_ptr(), None)
-    return legal.view(torch.bool)
+    return wrap(legal.view(torch.bool))
 
 
 def _squeeze(state: GameState) -> GameState:
@@ -123,20 +126,26 @@ def _unsqueeze(state: GameState) -> GameState:
     rt = runtime.current()
     return GameState(
         _board_tensor(state.board).reshape(1, 4, 4),
-        torch.as_tensor(state.step_count).to(device=rt.device, dtype=torch.int32).reshape(1),
-        torch.as_tensor(state.done).to(device=rt.device, dtype=torch.bool).reshape(1),
-        torch.as_tensor(state.total_reward).to(device=rt.device, dtype=torch.float32).reshape(1),
+        to_tensor(state.step_count).to(device=rt.device, dtype=torch.int32).reshape(1),
+        to_tensor(state.done).to(device=rt.device, dtype=torch.bool).reshape(1),
+        to_tensor(state.total_reward).to(device=rt.device, dtype=torch.float32).reshape(1),
     )
+
+
+def _one_key(key) -> torch.Tensor:
+    """A single PRNG key ((2,) uint32 array-like or a plain integer seed) as a (1, 2) int32 host tensor."""
+    k0, k1 = key_words(key)
+    return torch.tensor([[k0 - (1 << 32) if k0 >= 1 << 31 else k0, k1 - (1 << 32) if k1 >= 1 << 31 else k1]], dtype=torch.int32)
 
 
 def reset(key) -> GameState:
     """[ref env.py:55-76] new game: board with two tiles, step_count 0, done False, total_reward 0."""
-    return _squeeze(batched_reset(torch.as_tensor(key).reshape(1, 2) if torch.as_tensor(key).numel() == 2 else [[0, int(key)]]))
+    return _squeeze(batched_reset(_one_key(key)))
 
 
 def step(state: GameState, action, key):
     """[ref env.py:79-133] -> (GameState, reward f32, done bool, info dict)."""
-    new_state, reward, done, info = batched_step(_unsqueeze(state), [int(action)], key)
+    new_state, reward, done, info = batched_step(_unsqueeze(state), [int(action)], _one_key(key))
     return _squeeze(new_state), reward[0], done[0], {k: v[0] for k, v in info.items()}
 
 

@@ -82,10 +82,9 @@ def entropy_stream(count: int = 1) -> tuple[int, int]:
 
 
 def seed_to_u64(seed) -> int:
-    """Reference seeds (Python ints for NumPy, 2 x uint32 PRNGKeys for JAX) -> 64-bit Philox key."""
-    if hasattr(seed, '__len__') or isinstance(seed, torch.Tensor):
-        flat = [int(x) for x in torch.as_tensor(seed).reshape(-1)[:2].tolist()]
-        if len(flat) == 1:
-            flat = [0, flat[0]]
-        return ((flat[0] & 0xFFFFFFFF) << 32) | (flat[1] & 0xFFFFFFFF)
-    return int(seed) & 0xFFFFFFFFFFFFFFFF
+    """Reference seeds (Python ints for NumPy, 2 x uint32 PRNGKeys for JAX -- any array-like) -> 64-bit Philox key
+    (k0 << 32) | k1, the same mapping the keyed C-ABI entry points apply to a key row."""
+    from .interop import key_words
+
+    k0, k1 = key_words(seed)
+    return (k0 << 32) | k1

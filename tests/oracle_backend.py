@@ -112,6 +112,29 @@ class OracleLibrary:
         self.step_state_i32(device, stream, n, env_base, boards_out, actions, step_count_out, done_out, total_out, reward,
                             max_tile, seed, step_index)
 
+    def step_state_i32_keyed(self, device, stream, n, keys, boards_in, boards_out, actions, step_count_in, step_count_out,
+                             done_in, done_out, total_in, total_out, reward, max_tile):
+        self.calls.append(('step_state_i32_keyed', n))
+        zeros_i = np.zeros(n, dtype=np.int32)
+        zeros_f = np.zeros(n, dtype=np.float32)
+        res = oracle.step_state_i32_keyed(_view(boards_in, n * 16, np.int32).reshape(n, 16), _view(actions, n, np.int32),
+                                          zeros_i if step_count_in is None else _view(step_count_in, n, np.int32),
+                                          _view(done_in, n, np.uint8), zeros_f if total_in is None else _view(total_in, n, np.float32),
+                                          _view(keys, 2 * n, np.uint32))
+        _view(boards_out, n * 16, np.int32)[:] = res['boards'].reshape(-1)
+        _view(done_out, n, np.uint8)[:] = res['done']
+        _view(reward, n, np.float32)[:] = res['reward']
+        if step_count_out is not None:
+            _view(step_count_out, n, np.int32)[:] = res['step_count']
+        if total_out is not None:
+            _view(total_out, n, np.float32)[:] = res['total_reward']
+        if max_tile is not None:
+            _view(max_tile, n, np.int32)[:] = res['max_tile']
+
+    def reset_keyed_i32(self, device, stream, n, keys, boards):
+        self.calls.append(('reset_keyed_i32', n))
+        _view(boards, n * 16, np.int32)[:] = oracle.reset_keyed_i32(_view(keys, 2 * n, np.uint32)).reshape(-1)
+
     def rollout(self, device, stream, n, env_base, boards, seed, step0, T, return_sum, episodes, valid_moves, flags):
         self.calls.append(('rollout', n))
         b = _view(boards, n * 16, np.uint8)

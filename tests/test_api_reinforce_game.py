@@ -176,7 +176,7 @@ def test_done_guard_freezes_finished_games():
         done=torch.tensor([True, False, True]),  # third: flagged done although its board could move
         total_reward=torch.tensor([100.0, 8.0, 5.0]),
     )
-    new_states, rewards, dones, _ = batched_step(states, [0, 0, 0], KEY)
+    new_states, rewards, dones, _ = batched_step(states, [0, 0, 0], np.array([[0, 1], [0, 2], [0, 3]], dtype=np.uint32))
     assert L(new_states.step_count) == [7, 4, 9] and L(dones) == [True, False, True]
     assert L(rewards) == [0.0, 4.0, 0.0] and L(new_states.total_reward) == [100.0, 12.0, 5.0]
     assert torch.equal(new_states.board[0].cpu(), checker) and torch.equal(new_states.board[2].cpu(), live)

@@ -1,0 +1,222 @@
+"""
+Boundary row b2: the reference's CALLERS run on the mirrors without edits.
+
+The env-side statements of ``play_parallel_games`` (reinforce/training/self_play.py:298-300, 316-317, 346-356, 368,
+374-375, 389 of the reference) and of the ``evaluate.py`` game loop (:89-128) are restated here in their own form --
+``np.array(observations)``, ``np.array(dones)``, ``active_mask & ~dones_np``, ``bool(state.done)``,
+``state._replace(...)``, ``float(reward)``, ``int(max_tile(...))`` -- with the MCTS policy replaced by a NumPy
+random-legal choice and ``jax.random`` by a NumPy stand-in that hands out ``(N, 2)`` uint32 keys wrapped in an object
+that offers ONLY ``__array__`` (what a JAX array on another backend looks like to us).  Every test runs on the
+oracle-backed stand-in (host logic, CPU) and on the GPU box with the real HIP library, and is checked step by step
+against the oracle's restatement of reinforce/game/env.py:79-133 under per-environment keys.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from simulate_2048_amd.interop import DeviceArray
+from simulate_2048_amd.reinforce.game import core as game_core
+from simulate_2048_amd.reinforce.game.core import encode_observation, is_done, legal_actions_mask, max_tile, next_state
+from simulate_2048_amd.reinforce.game.env import (
+    GameState,
+    batched_get_legal_actions,
+    batched_get_observation,
+    batched_reset,
+    batched_step,
+    reset,
+    step,
+)
+
+
+class ForeignArray:
+    """An array from another framework: converts through ``__array__`` only (no torch, no DLPack)."""
+
+    def __init__(self, a):
+        self._a = np.asarray(a)
+
+    def __array__(self, dtype=None, copy=None):
+        return self._a if dtype is None else self._a.astype(dtype)
+
+    def __getitem__(self, i):
+        return ForeignArray(self._a[i])
+
+    @property
+    def shape(self):
+        return self._a.shape
+
+
+class FakeJaxRandom:
+    """Just enough of jax.random for the callers' key plumbing: split(key, n) -> (n, 2) uint32 keys."""
+
+    @staticmethod
+    def PRNGKey(seed):
+        return ForeignArray(np.array([0, seed], dtype=np.uint32))
+
+    @staticmethod
+    def split(key, num=2):
+        k = np.asarray(key).astype(np.uint64)
+        rng = np.random.default_rng([int(k[0]), int(k[1]), 0x2048])
+        return ForeignArray(rng.integers(0, 1 << 32, size=(num, 2), dtype=np.uint64).astype(np.uint32))
+
+
+jrandom = FakeJaxRandom
+
+
+def test_returns_are_numpy_convertible_device_arrays(api_runtime):
+    keys = jrandom.split(jrandom.PRNGKey(1), 5)
+    states = batched_reset(keys)
+    for x in (states.board, states.done, states.step_count, states.total_reward, batched_get_observation(states),
+              batched_get_legal_actions(states)):
+        assert isinstance(x, DeviceArray) and isinstance(x, torch.Tensor)
+        host = np.array(x)  # the caller's conversion; on the GPU this is the one device-to-host copy
+        assert isinstance(host, np.ndarray) and host.shape == tuple(x.shape)
+        assert isinstance(x[0], DeviceArray) and np.asarray(x[0]).shape == host.shape[1:]
+    assert np.array(states.done).dtype == np.bool_ and np.array(states.board).dtype == np.int32
+    assert hasattr(states.board, '__dlpack__')
+    back = torch.from_dlpack(states.board.as_subclass(torch.Tensor))
+    assert back.data_ptr() == states.board.data_ptr()  # zero-copy hand-over of the device buffer
+
+
+def test_batched_step_is_vmap_of_step(api_runtime):
+    """reinforce/game/env.py:193-211: batched_step = vmap(step) -- row i depends on (states[i], actions[i], keys[i])
+    only, and equals the single-environment call with that key (keys[1:] were ignored)."""
+    n = 24
+    keys = np.asarray(jrandom.split(jrandom.PRNGKey(7), n))
+    states = batched_reset(ForeignArray(keys))
+    for i in (0, 5, n - 1):
+        single = reset(keys[i])
+        assert np.array_equal(np.array(single.board), np.array(states.board[i]))
+    rng = np.random.default_rng(3)
+    for _ in range(6):
+        actions = rng.integers(0, 4, size=n).astype(np.int32)
+        step_keys = np.asarray(jrandom.split(ForeignArray(keys[0]), n))
+        new_states, rewards, dones, info = batched_step(states, ForeignArray(actions), ForeignArray(step_keys))
+        for i in (0, 3, 11, n - 1):
+            one = GameState(states.board[i], states.step_count[i], states.done[i], states.total_reward[i])
+            s1, r1, d1, info1 = step(one, int(actions[i]), step_keys[i])
+            assert np.array_equal(np.array(s1.board), np.array(new_states.board[i]))
+            assert float(r1) == float(rewards[i]) and bool(d1) == bool(dones[i])
+            assert int(info1['max_tile']) == int(info['max_tile'][i]) and int(s1.step_count) == int(new_states.step_count[i])
+        # other rows' keys do not leak: change every key but row 2's, row 2 is unchanged, and a permutation of the
+        # batch permutes the result
+        other = step_keys.copy()
+        other[np.arange(n) != 2] ^= 0xA5A5
+        alt, _, _, _ = batched_step(states, actions, other)
+        assert np.array_equal(np.array(alt.board[2]), np.array(new_states.board[2]))
+        perm = rng.permutation(n)
+        sp = GameState(states.board[perm], states.step_count[perm], states.done[perm], states.total_reward[perm])
+        pst, pr, _, _ = batched_step(sp, actions[perm], step_keys[perm])
+        assert np.array_equal(np.array(pst.board), np.array(new_states.board)[perm])
+        assert np.array_equal(np.array(pr), np.array(rewards)[perm])
+        # and the whole batch equals the oracle's restatement under the same keys
+        ref = oracle.step_state_i32_keyed(np.array(states.board).reshape(n, 16), actions, np.array(states.step_count),
+                                          np.array(states.done), np.array(states.total_reward), step_keys)
+        assert np.array_equal(np.array(new_states.board).reshape(n, 16), ref['boards'])
+        assert np.array_equal(np.array(rewards), ref['reward']) and np.array_equal(np.array(dones), ref['done'].astype(bool))
+        states, keys = new_states, step_keys
+    with pytest.raises(ValueError):
+        batched_step(states, actions, step_keys[:3])  # vmap would refuse mismatched leading axes too
+
+
+def test_play_parallel_games_env_side_runs_unchanged(api_runtime):
+    """The env-side statements of play_parallel_games, restated; the policy is a NumPy random-legal choice."""
+    num_parallel, max_trajectory_length = 16, 600
+    key = jrandom.PRNGKey(42)
+    policy_rng = np.random.default_rng(0)
+
+    # :298-300
+    keys = jrandom.split(key, num_parallel + 1)
+    key, game_keys = keys[0], keys[1:]
+    states = batched_reset(game_keys)
+    ref_boards = oracle.reset_keyed_i32(np.asarray(game_keys))
+    assert np.array_equal(np.array(states.board).reshape(num_parallel, 16), ref_boards)
+    ref_state = dict(step_count=np.zeros(num_parallel, np.int32), done=np.zeros(num_parallel, np.uint8),
+                     total_reward=np.zeros(num_parallel, np.float32))
+
+    all_observations = [[] for _ in range(num_parallel)]
+    all_actions = [[] for _ in range(num_parallel)]
+    all_rewards = [[] for _ in range(num_parallel)]
+    active_mask = np.ones(num_parallel, dtype=bool)
+    step_count = 0
+    while np.any(active_mask) and step_count < max_trajectory_length:
+        # :316-317
+        observations = batched_get_observation(states)
+        legal_masks = batched_get_legal_actions(states)
+        # (MCTS + action selection replaced: uniformly random legal action, 0 where nothing is legal)
+        legal_np = np.array(legal_masks)
+        actions = np.array([policy_rng.choice(np.flatnonzero(m)) if m.any() else 0 for m in legal_np], dtype=np.int32)
+        # :346-349
+        observations_np = np.array(observations)
+        actions_np = np.array(actions)
+        # :351-356
+        key, step_key = jrandom.split(key)[0], jrandom.split(key)[1]
+        step_keys = jrandom.split(step_key, num_parallel)
+        states, rewards, dones, _ = batched_step(states, ForeignArray(actions), step_keys)
+        rewards_np = np.array(rewards)
+        dones_np = np.array(dones)
+        # the same move through the oracle's restatement of env.py:79-133
+        ref = oracle.step_state_i32_keyed(ref_boards, actions, ref_state['step_count'], ref_state['done'],
+                                          ref_state['total_reward'], np.asarray(step_keys))
+        ref_boards = ref['boards']
+        ref_state = dict(step_count=ref['step_count'], done=ref['done'], total_reward=ref['total_reward'])
+        assert np.array_equal(rewards_np, ref['reward']) and np.array_equal(dones_np, ref['done'].astype(bool))
+        assert np.array_equal(observations_np.dtype, np.float32) and observations_np.shape == (num_parallel, 16)
+        # :359-365
+        for i in range(num_parallel):
+            if active_mask[i]:
+                all_observations[i].append(observations_np[i])
+                all_actions[i].append(int(actions_np[i]))
+                all_rewards[i].append(float(rewards_np[i]))
+        # :368
+        active_mask = active_mask & ~dones_np
+        step_count += 1
+
+    # :374-375, :389
+    final_boards = np.array(states.board)
+    final_dones = np.array(states.done)
+    assert np.array_equal(final_boards.reshape(num_parallel, 16), ref_boards)
+    assert final_dones.all() and not active_mask.any()  # random play ends well before 600 moves
+    for i in range(num_parallel):
+        assert len(all_observations[i]) == int(np.array(states.step_count)[i]) > 20
+        assert float(sum(all_rewards[i])) == float(np.array(states.total_reward)[i])
+        assert int(max_tile(final_boards[i])) == int(final_boards[i].max()) >= 16
+        assert np.stack(all_observations[i], axis=0).shape == (len(all_actions[i]), 16)
+
+
+def test_evaluate_game_loop_runs_unchanged(api_runtime):
+    """The game loop of reinforce/evaluate.py:89-128, restated; two games."""
+    key = jrandom.PRNGKey(5)
+    policy_rng = np.random.default_rng(1)
+    max_tiles, total_rewards, episode_lengths = [], [], []
+    for game_num in range(2):
+        key, game_key = jrandom.split(key)[0], jrandom.split(key)[1]
+        state = reset(game_key)
+        cumulative_reward = 0.0
+        steps = 0
+        while not bool(state.done):
+            k4 = jrandom.split(key, 4)
+            key, mcts_key, action_key, step_key = k4[0], k4[1], k4[2], k4[3]
+            obs = encode_observation(state.board)
+            legal_mask = legal_actions_mask(state.board)
+            assert np.array(obs).shape == (16,) and np.array(legal_mask).dtype == np.bool_
+            action = int(policy_rng.choice(np.flatnonzero(np.array(legal_mask))))
+            before = np.array(state.board).copy()
+            new_board, reward = next_state(state.board, action, step_key)
+            done = is_done(new_board)
+            cumulative_reward += float(reward)
+            steps += 1
+            # the transition against the oracle: afterstate of the chosen (legal) action + exactly one new 2/4 tile
+            after, score = oracle.latent_state(oracle.pack_values(before).reshape(16), action)
+            diff = np.flatnonzero(oracle.pack_values(np.array(new_board)).reshape(16) != after)
+            assert len(diff) == 1 and after[diff[0]] == 0 and int(np.array(new_board).reshape(16)[diff[0]]) in (2, 4)
+            assert float(reward) == float(score)
+            state = state._replace(board=new_board, done=done)
+            current_max = int(max_tile(state.board))
+            assert current_max == int(np.array(state.board).max())
+        max_tiles.append(int(max_tile(state.board)))
+        total_rewards.append(cumulative_reward)
+        episode_lengths.append(steps)
+        assert not np.array(game_core.legal_actions_mask(state.board)).any()
+    assert all(t >= 16 for t in max_tiles) and all(n > 20 for n in episode_lengths) and all(r > 0 for r in total_rewards)
