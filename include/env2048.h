@@ -76,6 +76,11 @@ extern "C" {
  * bits override the size rule (they exclude each other). */
 #define ENV2048_FLAG_STORES_WRITE_THROUGH 16u
 #define ENV2048_FLAG_STORES_WRITE_BACK 32u
+/* env2048_step* only: `reward` is an n-float32 array receiving the LOG-NORMALISED reward log2(score) / 16 (0 for a
+ * score of 0) -- normalize_reward of the reference (twentyfortyeight/utils/normalize.py:6-33, the `normalize=True`
+ * constructor flag, twentyfortyeight/envs/twentyfortyeight.py:80-81) for a whole batch; within 1 ulp (float32) of the
+ * reference's float64 value. */
+#define ENV2048_FLAG_REWARD_LOG2_F32 64u
 
 ENV2048_EXPORT int env2048_abi_version(void);
 ENV2048_EXPORT const char *env2048_last_error(void);
@@ -134,6 +139,9 @@ typedef struct env2048_step_args {
     void *obs;
     uint64_t seed, step_index;
     uint32_t flags, reserved;
+    uint8_t *max_exp; /* optional, records only: max_exp[i] = log2(max tile) of board i after move + spawn and BEFORE an
+                         auto-reset replaces it -- for a game that ends in this step, the max tile it reached
+                         (info.max_tile, reinforce/game/env.py:127-131; Trajectory.max_tile, self_play.py:389) */
 } env2048_step_args;
 ENV2048_EXPORT int env2048_step_many(int device, void *stream, uint64_t count, const env2048_step_args *args);
 
@@ -224,6 +232,59 @@ ENV2048_EXPORT int env2048_status_i32(int device, void *stream, uint64_t n, cons
 ENV2048_EXPORT int env2048_rollout(int device, void *stream, uint64_t n, uint64_t env_base, uint8_t *boards, uint64_t seed,
                     uint64_t step0, uint32_t T, int64_t *return_sum, uint32_t *episodes, uint32_t *valid_moves,
                     uint32_t flags);
+
+/*
+ * The same rollout reporting per-EPISODE statistics, accumulated on device -- what evaluate_games computes from a list
+ * of trajectories (reinforce/training/self_play.py:503-521: mean/std/min/max of the total reward, mean and max of the
+ * max tile, mean length, "reached 2048/4096/..." counts) for millions of games without moving a trajectory.
+ * stats: ENV2048_ROLLOUT_STATS_WORDS uint64 words that the call ADDS to (so several calls / slices / GPUs accumulate;
+ * the caller zeroes them first and sets word 4 to UINT64_MAX):
+ *     [0] finished games   [1] sum of their lengths (moves, invalid ones included)   [2] sum of their total rewards
+ *     [3] sum of squared total rewards   [4] min total reward   [5] max total reward   [6] sum of squared lengths
+ *     [7] unused   [8 + e] finished games whose largest tile was 2^e  (e = 0 .. 31)
+ * ep_length / ep_return (each may be NULL): the length / reward so far of the game every environment is IN, read at the
+ * start and written at the end, so that games spanning several calls are counted whole (NULL: games in progress at the
+ * start of the call count from that point).
+ * [replaces: evaluate_games, reinforce/training/self_play.py:476-521, on random-action rollouts]
+ */
+#define ENV2048_ROLLOUT_STATS_WORDS 40
+ENV2048_EXPORT int env2048_rollout_episodes(int device, void *stream, uint64_t n, uint64_t env_base, uint8_t *boards, uint64_t seed,
+                                            uint64_t step0, uint32_t T, uint32_t flags, uint32_t *ep_length, int64_t *ep_return,
+                                            uint64_t *stats);
+
+/*
+ * Episodes out of recorded step rows -- the device form of reinforce/training/self_play.py:359-392 (per-game lists,
+ * "store only for still-active games", Trajectory(..., done, total_reward, max_tile)).  Input: the [*, row_stride]
+ * row arrays env2048_step / env2048_step_sequence / env2048_step_many wrote, one row per step: `done` (required),
+ * `reward` (int32 scores, or float32 with ENV2048_EPISODES_REWARD_F32; may be NULL) and `max_exp` (may be NULL).
+ * `rows` logical rows are considered, logical row r living in physical row (first_row + r) % ring_rows (a plain
+ * [T, N] recording: first_row = 0, ring_rows = rows = T).  An episode of environment i is a maximal run of rows ending
+ * with done = 1; a run cut by the end of the recording is reported with terminated = 0.
+ *   ENV2048_EPISODES_FROZEN  the recording was made WITHOUT auto-reset (the reference's loop): a finished game stays
+ *                            finished, so only its first episode exists and later rows belong to no episode
+ * Two calls: env2048_count_episodes gives counts[i] = episodes of environment i; the caller forms the exclusive prefix
+ * sum `offsets` (and its total = number of records) and env2048_segment_episodes writes the records of environment i at
+ * episodes[offsets[i] ...] in time order -- so the output order is deterministic: by environment, then by start.
+ * episode_of (may be NULL; [*, row_stride] int32, same physical layout as the rows): index of the record a row belongs
+ * to, -1 for rows after the end of a frozen game.
+ */
+#define ENV2048_EPISODES_FROZEN 1u
+#define ENV2048_EPISODES_REWARD_F32 2u
+typedef struct env2048_episode {
+    uint32_t env;       /* column of the recording (environment index within the batch) */
+    uint32_t start;     /* first logical row */
+    uint32_t length;    /* rows = moves of the episode, invalid ones included (env.py:116 counts them too) */
+    uint8_t terminated; /* 1: ended by done (Trajectory.done); 0: cut by the end of the recording */
+    uint8_t max_exp;    /* log2(max tile) reached -- max over the episode's max_exp rows; 0 without them */
+    uint16_t reserved;
+    double total_reward; /* sum of the episode's reward rows (exact for int32 scores) */
+} env2048_episode;
+ENV2048_EXPORT int env2048_count_episodes(int device, void *stream, uint64_t n, uint64_t row_stride, uint32_t rows, uint32_t first_row,
+                                          uint32_t ring_rows, const uint8_t *done, uint32_t flags, uint32_t *counts);
+ENV2048_EXPORT int env2048_segment_episodes(int device, void *stream, uint64_t n, uint64_t row_stride, uint32_t rows,
+                                            uint32_t first_row, uint32_t ring_rows, const uint8_t *done, const void *reward,
+                                            const uint8_t *max_exp, uint32_t flags, const uint64_t *offsets,
+                                            env2048_episode *episodes, int32_t *episode_of);
 
 /*
  * Afterstate only (deterministic half of a move): boards_out = slide+merge(boards_in, action),

@@ -21,6 +21,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <string.h>
+#include <math.h>
 
 #define ORACLE_API __attribute__((visibility("default")))
 
@@ -293,8 +294,19 @@ ORACLE_API void oracle_reset_board(uint64_t seed, uint64_t env, uint64_t step, u
  *  reward = score; else: board unchanged, reward 0, no spawn.  done = is_done(new board).
  *  With FLAG_AUTO_RESET a terminal board is replaced by a fresh one (done still reports 1).
  *  action is taken mod 4, as rot90 does (gameboard.py:316). */
+static int64_t step_one_ex(uint8_t board[16], int action, uint64_t seed, uint64_t env, uint64_t step,
+                           uint32_t flags, uint32_t word, int *done_out, int *changed_out, int *max_exp_out);
+
 static int64_t step_one(uint8_t board[16], int action, uint64_t seed, uint64_t env, uint64_t step,
                         uint32_t flags, uint32_t word, int *done_out, int *changed_out)
+{
+    return step_one_ex(board, action, seed, env, step, flags, word, done_out, changed_out, NULL);
+}
+
+/* max_exp_out: log2(max tile) of the board after move + spawn, BEFORE an auto-reset replaces it -- for a game that ends
+ * here, the max tile it reached [ref: reinforce/game/env.py:127-131 info.max_tile; self_play.py:389]. */
+static int64_t step_one_ex(uint8_t board[16], int action, uint64_t seed, uint64_t env, uint64_t step,
+                           uint32_t flags, uint32_t word, int *done_out, int *changed_out, int *max_exp_out)
 {
     uint8_t rotated[16];
     int64_t reward = 0;
@@ -311,6 +323,7 @@ static int64_t step_one(uint8_t board[16], int action, uint64_t seed, uint64_t e
         changed = 1;
     }                                                            /* :325 else: state, 0 */
     int done = oracle_is_done(board);                            /* twentyfortyeight.py:133 */
+    if (max_exp_out) *max_exp_out = oracle_max_exponent(board);
     if (done && (flags & FLAG_AUTO_RESET))
         oracle_reset_board(seed, env, step, board);
     *done_out = done;
@@ -346,6 +359,36 @@ ORACLE_API int oracle_step_batch(uint64_t n, uint64_t env_base, uint8_t *boards,
         if (done) done[i] = (uint8_t)d;
         if (legal) legal[i] = oracle_legal_actions_mask(b);
         if (obs) encode_obs(b, obs + 16 * (size_t)i);
+    }
+    return 0;
+}
+
+/* [ref: twentyfortyeight/utils/normalize.py:6-33 normalize_reward, default max_tile = 2^16]
+ * 0 -> 0.0, else log2(reward) / log2(65536), computed in double like the reference and rounded to float32. */
+ORACLE_API float oracle_normalize_reward(int64_t reward)
+{
+    if (reward == 0) return 0.0f;                                 /* :31-32 */
+    return (float)(log2((double)reward) / 16.0);                  /* :33 */
+}
+
+/* oracle_step_batch plus the two recording outputs of the step kernel: max_exp (see step_one_ex) and the
+ * log-normalised reward as float32 (ENV2048_FLAG_REWARD_LOG2_F32). */
+ORACLE_API int oracle_step_batch_ex(uint64_t n, uint64_t env_base, uint8_t *boards, const uint8_t *actions,
+                                    int32_t *reward, uint8_t *done, uint8_t *legal, float *obs, uint8_t *max_exp,
+                                    float *reward_norm, uint64_t seed, uint64_t step_index, uint32_t flags)
+{
+    for (uint64_t i = 0; i < n; ++i) {
+        uint8_t *b = boards + 16 * (size_t)i;
+        uint32_t w = step_word(seed, env_base + i, step_index);
+        int action = (flags & FLAG_RANDOM_ACTIONS) ? (int)(w & 3u) : (int)actions[i];
+        int d = 0, m = 0;
+        int64_t r = step_one_ex(b, action, seed, env_base + i, step_index, flags, w, &d, NULL, &m);
+        if (reward) reward[i] = (int32_t)r;
+        if (reward_norm) reward_norm[i] = oracle_normalize_reward(r);
+        if (done) done[i] = (uint8_t)d;
+        if (legal) legal[i] = oracle_legal_actions_mask(b);
+        if (obs) encode_obs(b, obs + 16 * (size_t)i);
+        if (max_exp) max_exp[i] = (uint8_t)m;
     }
     return 0;
 }
@@ -390,6 +433,80 @@ ORACLE_API int oracle_rollout_batch(uint64_t n, uint64_t env_base, uint8_t *boar
         if (valid_moves) valid_moves[i] = moves;
     }
     return 0;
+}
+
+/* Rollout with per-EPISODE statistics [ref: reinforce/training/self_play.py:503-521 evaluate_games: rewards, max tiles and
+ * lengths of finished games].  stats[40] is ADDED to: [0] games, [1] sum length, [2] sum return, [3] sum return^2,
+ * [4] min return, [5] max return, [6] sum length^2, [8+e] games whose largest tile was 2^e.  ep_length / ep_return carry
+ * the game in progress across calls (may be NULL). */
+ORACLE_API int oracle_rollout_episodes(uint64_t n, uint64_t env_base, uint8_t *boards, uint64_t seed, uint64_t step0,
+                                       uint32_t T, uint32_t flags, uint32_t *ep_length, int64_t *ep_return, uint64_t *stats)
+{
+    for (uint64_t i = 0; i < n; ++i) {
+        uint8_t *b = boards + 16 * (size_t)i;
+        uint64_t len = ep_length ? ep_length[i] : 0, sum = ep_return ? (uint64_t)ep_return[i] : 0;
+        for (uint32_t t = 0; t < T; ++t) {
+            uint64_t step = step0 + t;
+            uint32_t w = step_word(seed, env_base + i, step);
+            int d = 0, m = 0;
+            sum += (uint64_t)step_one_ex(b, (int)(w & 3u), seed, env_base + i, step, flags, w, &d, NULL, &m);
+            len += 1;
+            if (d) {
+                stats[0] += 1; stats[1] += len; stats[2] += sum; stats[3] += sum * sum;
+                if (sum < stats[4]) stats[4] = sum;
+                if (sum > stats[5]) stats[5] = sum;
+                stats[6] += len * len;
+                stats[8 + (m & 31)] += 1;
+                len = 0; sum = 0;
+            }
+        }
+        if (ep_length) ep_length[i] = (uint32_t)len;
+        if (ep_return) ep_return[i] = (int64_t)sum;
+    }
+    return 0;
+}
+
+/* Episode records out of recorded step rows [ref: reinforce/training/self_play.py:359-392]: per game, the rows recorded
+ * while it was active (:359-365; active_mask &= ~done, :368), then Trajectory(done, total_reward = sum(rewards),
+ * max_tile) (:381-390).  Rows are [*, row_stride]; logical row r is physical row (first_row + r) % ring_rows.
+ * flags bit 0 (FROZEN): no auto-reset, only the first episode of a game exists; bit 1: reward rows are float32.
+ * Records come out by environment, then by start.  Layout of one record = env2048_episode (24 bytes). */
+typedef struct {
+    uint32_t env, start, length;
+    uint8_t terminated, max_exp;
+    uint16_t reserved;
+    double total_reward;
+} oracle_episode;
+
+ORACLE_API uint64_t oracle_segment_episodes(uint64_t n, uint64_t row_stride, uint32_t rows, uint32_t first_row, uint32_t ring_rows,
+                                            const uint8_t *done, const void *reward, const uint8_t *max_exp, uint32_t flags,
+                                            oracle_episode *episodes, int32_t *episode_of)
+{
+    uint64_t count = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        uint32_t start = 0, length = 0, best = 0, r = 0;
+        double total = 0.0;
+        for (; r < rows; ++r) {
+            uint64_t at = (uint64_t)((first_row + r) % ring_rows) * row_stride + i;
+            if (reward) total += (flags & 2u) ? (double)((const float *)reward)[at] : (double)((const int32_t *)reward)[at];
+            if (max_exp && max_exp[at] > best) best = max_exp[at];
+            ++length;
+            if (episode_of) episode_of[at] = (int32_t)count;
+            if (done[at]) {
+                if (episodes) episodes[count] = (oracle_episode){(uint32_t)i, start, length, 1, (uint8_t)best, 0, total};
+                ++count;
+                start = r + 1; length = 0; best = 0; total = 0.0;
+                if (flags & 1u) { ++r; break; }
+            }
+        }
+        if (length) {
+            if (episodes) episodes[count] = (oracle_episode){(uint32_t)i, start, length, 0, (uint8_t)best, 0, total};
+            ++count;
+        }
+        if (episode_of)
+            for (; r < rows; ++r) episode_of[(uint64_t)((first_row + r) % ring_rows) * row_stride + i] = -1;
+    }
+    return count;
 }
 
 /* [ref: reinforce/game/env.py:79-133 step]  the JAX-shaped transition on int32 value boards:

@@ -125,13 +125,18 @@ class BatchedEnv2048:
         self.lib.status(dev, stream, self.num_envs, _p(self.boards), None, _p(legal), _p(tmp), None, None)
         obs.copy_(tmp)
 
-    def step(self, actions: torch.Tensor | None = None, *, out_reward=None, out_done=None, out_legal=None, out_obs=None):
+    def step(self, actions: torch.Tensor | None = None, *, out_reward=None, out_done=None, out_legal=None, out_obs=None,
+             out_max_exp=None, normalized_reward: bool = False):
         """One transition per board, in place; asynchronous on torch's current stream.
 
         ``actions``: uint8 tensor (N,) on the same device, values taken mod 4 (0 left, 1 up,
         2 right, 3 down); ``None`` draws uniform random actions on device (low two bits of each step word).
         ``out_*``: optional caller-owned tensors the kernel writes INSTEAD of the persistent buffers
         (e.g. slices of a ``[T, N]`` trajectory buffer -- see ``trajectory.TrajectoryBuffer``).
+        ``out_max_exp``: optional uint8 (N,) tensor receiving log2(max tile) of every board after the move and BEFORE an
+        auto-reset replaces it (the max tile of a game that ends in this step).
+        ``normalized_reward``: write the log-normalised reward log2(score)/16 as float32 (``normalize_reward`` of the
+        reference, twentyfortyeight/utils/normalize.py:6-33) -- ``out_reward`` must then be a float32 tensor.
         Returns ``(boards, reward, done)`` -- views of the buffers that were written.
         """
         flags = self.flags
@@ -148,12 +153,24 @@ class BatchedEnv2048:
                           self._ptr_done, self._ptr_legal, self._ptr_obs, self.seed, self.step_index, flags)
             self.step_index += 1
             return self.boards, self.reward, self.done
-        reward = self.reward if out_reward is None else self._check_out(out_reward, torch.int32, (self.num_envs,))
+        if normalized_reward:
+            if out_reward is None:
+                raise ValueError('normalized_reward=True needs a float32 out_reward tensor (the persistent reward buffer is int32)')
+            reward = self._check_out(out_reward, torch.float32, (self.num_envs,))
+            flags |= capi.FLAG_REWARD_LOG2_F32
+        else:
+            reward = self.reward if out_reward is None else self._check_out(out_reward, torch.int32, (self.num_envs,))
         done = self.done if out_done is None else self._check_out(out_done, torch.uint8, (self.num_envs,))
         legal = self.legal if out_legal is None else self._check_out(out_legal, torch.uint8, (self.num_envs,))
         obs = self.obs if out_obs is None else self._check_out(out_obs, self.obs_dtype, (self.num_envs, 16))
-        self.lib.step(dev, stream, self.num_envs, self.env_base, self._ptr_boards, _p(actions), _p(reward),
-                      _p(done), _p(legal), _p(obs), self.seed, self.step_index, flags)
+        if out_max_exp is None and not normalized_reward:
+            self.lib.step(dev, stream, self.num_envs, self.env_base, self._ptr_boards, _p(actions), _p(reward),
+                          _p(done), _p(legal), _p(obs), self.seed, self.step_index, flags)
+        else:  # the record form carries the extra recording output
+            max_exp = None if out_max_exp is None else self._check_out(out_max_exp, torch.uint8, (self.num_envs,))
+            record = (capi.StepArgs * 1)(capi.StepArgs(self.num_envs, self.env_base, self._ptr_boards, _p(actions), _p(reward), _p(done),
+                                                       _p(legal), _p(obs), self.seed, self.step_index, flags, 0, _p(max_exp)))
+            self.lib.step_many(dev, stream, record)
         self.step_index += 1
         return self.boards, reward, done
 
@@ -175,6 +192,50 @@ class BatchedEnv2048:
                          _p(ret), _p(eps), _p(moves), (capi.FLAG_AUTO_RESET if self.auto_reset else 0) | capi.FLAG_RANDOM_ACTIONS)
         self.step_index += int(num_steps)
         return {'return_sum': ret, 'episodes': eps, 'valid_moves': moves}
+
+    def rollout_episodes(self, num_steps: int, stats: torch.Tensor | None = None) -> torch.Tensor:
+        """``num_steps`` random-action transitions in one kernel, with per-EPISODE statistics accumulated on device
+        (env2048_rollout_episodes): returns the 40-word uint64 block as an int64 tensor (see ``episode_statistics``).
+        The game every environment is in is carried across calls, so games spanning calls are counted whole.  Pass the
+        tensor of a previous call as ``stats`` to keep accumulating."""
+        n = self.num_envs
+        if not hasattr(self, '_ep_length'):
+            self._ep_length = torch.zeros((n,), dtype=torch.int32, device=self.device)
+            self._ep_return = torch.zeros((n,), dtype=torch.int64, device=self.device)
+        if stats is None:
+            stats = torch.zeros((capi.ROLLOUT_STATS_WORDS,), dtype=torch.int64, device=self.device)
+            stats[4] = -1  # = UINT64_MAX: the running minimum
+        dev, stream = _stream_handle(self.device)
+        self.lib.rollout_episodes(dev, stream, n, self.env_base, _p(self.boards), self.seed, self.step_index, int(num_steps),
+                                  (capi.FLAG_AUTO_RESET if self.auto_reset else 0) | capi.FLAG_RANDOM_ACTIONS, _p(self._ep_length),
+                                  _p(self._ep_return), _p(stats))
+        self.step_index += int(num_steps)
+        return stats
+
+    @staticmethod
+    def episode_statistics(stats) -> dict:
+        """The report of evaluate_games (reinforce/training/self_play.py:503-521) from a statistics block."""
+        w = [int(x) & 0xFFFFFFFFFFFFFFFF for x in torch.as_tensor(stats).cpu().tolist()]
+        games = w[0]
+        hist = {1 << e if e else 0: w[8 + e] for e in range(32) if w[8 + e]}
+        if games == 0:
+            return {'games': 0}
+        mean_r, mean_l = w[2] / games, w[1] / games
+        out = {
+            'games': games,
+            'mean_reward': mean_r,
+            'std_reward': max(w[3] / games - mean_r * mean_r, 0.0) ** 0.5,
+            'max_reward': float(w[5]),
+            'min_reward': float(w[4]),
+            'mean_max_tile': sum(t * c for t, c in hist.items()) / games,
+            'max_tile': max(hist),
+            'mean_length': mean_l,
+            'std_length': max(w[6] / games - mean_l * mean_l, 0.0) ** 0.5,
+            'max_tile_histogram': hist,
+        }
+        for tile in (2048, 4096, 8192, 16384, 32768):
+            out[f'reached_{tile}'] = sum(c for t, c in hist.items() if t >= tile)
+        return out
 
     def status(self):
         """done / legal bitmask / f32 obs / max exponent / empty count of the current boards."""

@@ -27,6 +27,7 @@ FLAG_OBS_F16 = 4
 FLAG_OBS_BF16 = 8
 FLAG_STORES_WRITE_THROUGH = 16
 FLAG_STORES_WRITE_BACK = 32
+FLAG_REWARD_LOG2_F32 = 64
 
 LIB_PATH = Path(__file__).resolve().parent / 'lib' / 'libenv2048.so'
 
@@ -41,8 +42,20 @@ class StepArgs(ctypes.Structure):
     """``env2048_step_args`` of include/env2048.h: one env2048_step call as a record (env2048_step_many)."""
 
     _fields_ = [('n', _u64), ('env_base', _u64), ('boards', _ptr), ('actions', _ptr), ('reward', _ptr), ('done', _ptr),
-                ('legal', _ptr), ('obs', _ptr), ('seed', _u64), ('step_index', _u64), ('flags', _u32), ('reserved', _u32)]
+                ('legal', _ptr), ('obs', _ptr), ('seed', _u64), ('step_index', _u64), ('flags', _u32), ('reserved', _u32),
+                ('max_exp', _ptr)]
 
+
+class Episode(ctypes.Structure):
+    """``env2048_episode`` of include/env2048.h (24 bytes): one record of env2048_segment_episodes."""
+
+    _fields_ = [('env', _u32), ('start', _u32), ('length', _u32), ('terminated', ctypes.c_uint8), ('max_exp', ctypes.c_uint8),
+                ('reserved', ctypes.c_uint16), ('total_reward', ctypes.c_double)]
+
+
+EPISODES_FROZEN = 1
+EPISODES_REWARD_F32 = 2
+ROLLOUT_STATS_WORDS = 40
 
 # name -> (restype, argtypes): exactly the prototypes of include/env2048.h
 PROTOTYPES = {
@@ -62,6 +75,9 @@ PROTOTYPES = {
     'env2048_reset_keyed_i32': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr]),
     'env2048_status_i32': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr]),
     'env2048_rollout': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _u64, _u64, _u32, _ptr, _ptr, _ptr, _u32]),
+    'env2048_rollout_episodes': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _u64, _u64, _u32, _u32, _ptr, _ptr, _ptr]),
+    'env2048_count_episodes': (_c_int, [_c_int, _ptr, _u64, _u64, _u32, _u32, _u32, _ptr, _u32, _ptr]),
+    'env2048_segment_episodes': (_c_int, [_c_int, _ptr, _u64, _u64, _u32, _u32, _u32, _ptr, _ptr, _ptr, _u32, _ptr, _ptr, _ptr]),
     'env2048_afterstate': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr, _ptr]),
     'env2048_afterstates4': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr]),
     'env2048_spawn': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr]),
@@ -167,6 +183,18 @@ class Library:
                 flags) -> None:
         self._check(self._dll.env2048_rollout(device, stream, n, env_base, boards, seed, step0, T, return_sum,
                                               episodes, valid_moves, flags))
+
+    def rollout_episodes(self, device, stream, n, env_base, boards, seed, step0, T, flags, ep_length, ep_return, stats) -> None:
+        self._check(self._dll.env2048_rollout_episodes(device, stream, n, env_base, boards, seed, step0, T, flags, ep_length,
+                                                       ep_return, stats))
+
+    def count_episodes(self, device, stream, n, row_stride, rows, first_row, ring_rows, done, flags, counts) -> None:
+        self._check(self._dll.env2048_count_episodes(device, stream, n, row_stride, rows, first_row, ring_rows, done, flags, counts))
+
+    def segment_episodes(self, device, stream, n, row_stride, rows, first_row, ring_rows, done, reward, max_exp, flags, offsets,
+                         episodes, episode_of) -> None:
+        self._check(self._dll.env2048_segment_episodes(device, stream, n, row_stride, rows, first_row, ring_rows, done, reward,
+                                                       max_exp, flags, offsets, episodes, episode_of))
 
     def afterstate(self, device, stream, n, boards_in, actions, boards_out, reward, changed) -> None:
         self._check(self._dll.env2048_afterstate(device, stream, n, boards_in, actions, boards_out, reward, changed))

@@ -12,7 +12,8 @@
 
 #if defined(ENV2048_HOST_EMULATION)
 // CPU build of the SAME per-board arithmetic, used only by tests/host_emu to unit-test the SWAR
-// logic against the oracle (and under -fsanitize) without a GPU.  Not a product path.
+// logic against the oracle (UBSan on the shared object, ASan + UBSan on a standalone driver) without a GPU.  Not a
+// product path.
 #define ENV2048_DEV static inline
 namespace env2048 {
 static inline uint32_t emu_perm(uint32_t hi, uint32_t lo, uint32_t sel)
@@ -499,6 +500,40 @@ ENV2048_DEV uint32_t legal_mask(const Board &bd)
 }
 
 ENV2048_DEV uint32_t count_empty(const Board &bd) { return ENV2048_POPC(empty_mask(bd)); }
+
+// Largest exponent on the board = log2(max_tile) [ref: reinforce/game/core.py:427-442 max_tile].
+ENV2048_DEV uint32_t max_exponent(const Board &bd)
+{
+    const uint32_t rows[4] = {bd.r0, bd.r1, bd.r2, bd.r3};
+    uint32_t m = 0;
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t x = rows[r];
+        const uint32_t lo = (x & 0xFFu) > ((x >> 8) & 0xFFu) ? (x & 0xFFu) : ((x >> 8) & 0xFFu);
+        const uint32_t hi = ((x >> 16) & 0xFFu) > (x >> 24) ? ((x >> 16) & 0xFFu) : (x >> 24);
+        const uint32_t rm = lo > hi ? lo : hi;
+        m = rm > m ? rm : m;
+    }
+    return m;
+}
+
+// Log-normalised reward [ref: twentyfortyeight/utils/normalize.py:6-33 normalize_reward with the default
+// max_tile = 2^16]: log2(reward) / 16, 0 for reward 0, as float32.  reward is an integer below 2^24, so with
+// e = floor(log2 reward) and m = reward / 2^e in [1, 2) (exact in float32) the result is (e + log2 m) / 16: the
+// hardware logarithm is only applied to m, where its 1-ulp error is an absolute 2^-24 -- at most 1 ulp of the result
+// against the reference's float64 value rounded to float32.
+ENV2048_DEV float normalized_reward(uint32_t reward)
+{
+    if (reward == 0u) return 0.0f;
+#if defined(ENV2048_HOST_EMULATION)
+    const int e = 31 - __builtin_clz(reward);
+    const float m = (float)reward / (float)(1u << e);
+    return ((float)e + __builtin_log2f(m)) * 0.0625f;
+#else
+    const int e = 31 - __clz((int)reward);
+    const float m = __uint_as_float((uint32_t)__float_as_uint((float)reward) - ((uint32_t)e << 23));  // exponent field -> 0
+    return ((float)e + __log2f(m)) * 0.0625f;
+#endif
+}
 
 // 32 x 32 -> 64-bit product, both halves.  On gfx950 one v_mad_u64_u32 delivers them for the price of
 // one multiply (measured: a Philox round is 24 % faster than with v_mul_hi_u32 + v_mul_lo_u32, which

@@ -219,6 +219,7 @@ struct StepArgs {
     void *obs;  // f32, or f16 / bf16 with ENV2048_FLAG_OBS_F16 / _BF16
     RngKey key;
     uint32_t flags;
+    uint8_t *max_exp;  // log2(max tile) of the board after move + spawn, BEFORE an auto-reset replaces it
 };
 
 __device__ __forceinline__ DirSelectors load_selectors(const uint4 *dir_lds, uint32_t action)
@@ -390,7 +391,10 @@ __device__ __forceinline__ void step_block(const StepArgs &a, uint4 *dir_lds, ui
     };
     auto emit = [&](int j) {
         const uint64_t i = tile0 + 64u * j + lane;
+        if (EXTRAS && (a.flags & ENV2048_FLAG_REWARD_LOG2_F32))  // wave-uniform: the reward array then holds float32
+            reward[j] = __float_as_uint(normalized_reward(reward[j]));
         if (FULL || i < a.n) {
+            if (EXTRAS && a.max_exp) a.max_exp[i] = (uint8_t)max_exponent(bd[j]);  // of a finished game: its last board
             const bool pending_reset = auto_reset && done[j];
             if (pending_reset) {
                 const uint32_t slot = atomicAdd(queue_state, 1u) & 0xFFFFu;
@@ -503,9 +507,10 @@ __device__ __forceinline__ void step_block(const StepArgs &a, uint4 *dir_lds, ui
 template <bool EXTRAS, bool RANDOM>
 __global__ __launch_bounds__(BLOCK) void step_kernel(uint8_t *boards, const uint8_t *actions, uint64_t n, uint64_t env_base,
                                                      uint32_t flags, uint32_t seed_lo, uint32_t seed_hi, uint32_t step_lo,
-                                                     uint32_t step_hi, int32_t *reward, uint8_t *done, uint8_t *legal, void *obs)
+                                                     uint32_t step_hi, int32_t *reward, uint8_t *done, uint8_t *legal, void *obs,
+                                                     uint8_t *max_exp)
 {
-    const StepArgs a{n, env_base, boards, actions, reward, done, legal, obs, RngKey{seed_lo, seed_hi, step_lo, step_hi}, flags};
+    const StepArgs a{n, env_base, boards, actions, reward, done, legal, obs, RngKey{seed_lo, seed_hi, step_lo, step_hi}, flags, max_exp};
     __shared__ uint4 dir_lds[8];
     __shared__ __attribute__((aligned(16))) uint32_t word_lds[WAVES_PER_BLOCK][WORD_STRIP];
     __shared__ uint32_t queue_state;
@@ -546,13 +551,27 @@ struct RolloutArgs {
     uint64_t step0;
     uint32_t T;
     uint32_t flags;
+    // STATS only: running (length, return) of the game each environment is in, carried across calls (may be NULL), and
+    // the 40-word accumulator block of env2048_rollout_episodes
+    uint32_t *ep_length;
+    int64_t *ep_return;
+    unsigned long long *stats;
 };
 
 // T steps with the boards resident in registers; same tile layout and RNG words as step_kernel.
+// STATS: per-EPISODE statistics (what evaluate_games reports, reinforce/training/self_play.py:503-521): every lane keeps
+// the running length/return of its four games; a finished game (rare: 0.7 % of steps) updates block-wide accumulators in
+// LDS (count, sums, sums of squares, min/max return, histogram of the final max tile), which the block adds to the
+// caller's 40-word block with one global atomic per word when it retires.
+template <bool STATS>
 __global__ __launch_bounds__(BLOCK) void rollout_kernel(RolloutArgs a)
 {
     __shared__ uint4 dir_lds[8];
     __shared__ __attribute__((aligned(16))) uint32_t word_lds[WAVES_PER_BLOCK][WORD_STRIP];
+    __shared__ unsigned long long stats_lds[STATS ? ENV2048_ROLLOUT_STATS_WORDS : 1];
+    if (STATS) {
+        if (threadIdx.x < ENV2048_ROLLOUT_STATS_WORDS) stats_lds[threadIdx.x] = threadIdx.x == 4u ? ~0ull : 0ull;  // [4] = min
+    }
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -570,6 +589,8 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(RolloutArgs a)
     bool valid[BOARDS_PER_LANE];
     int64_t ret[BOARDS_PER_LANE];
     uint32_t eps[BOARDS_PER_LANE], moves[BOARDS_PER_LANE];
+    uint32_t cur_len[BOARDS_PER_LANE];
+    unsigned long long cur_ret[BOARDS_PER_LANE];
 #pragma unroll
     for (int j = 0; j < BOARDS_PER_LANE; ++j) {
         const uint64_t i = tile0 + 64u * j + lane;
@@ -578,6 +599,8 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(RolloutArgs a)
         ret[j] = 0;
         eps[j] = 0u;
         moves[j] = 0u;
+        cur_len[j] = (STATS && valid[j] && a.ep_length) ? a.ep_length[i] : 0u;
+        cur_ret[j] = (STATS && valid[j] && a.ep_return) ? (unsigned long long)a.ep_return[i] : 0ull;
     }
 
     for (uint32_t t = 0; t < a.T; ++t) {
@@ -597,6 +620,23 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(RolloutArgs a)
             eps[j] += done ? 1u : 0u;
             moves[j] += changed ? 1u : 0u;
             pending |= (done ? 1u : 0u) << j;
+            if (STATS) {
+                cur_len[j] += 1u;
+                cur_ret[j] += reward;
+                if (done && valid[j]) {  // the game of this board slot ended with this move: bd[j] is its last board
+                    const unsigned long long len = cur_len[j], sum = cur_ret[j];
+                    atomicAdd(&stats_lds[0], 1ull);
+                    atomicAdd(&stats_lds[1], len);
+                    atomicAdd(&stats_lds[2], sum);
+                    atomicAdd(&stats_lds[3], sum * sum);
+                    atomicMin(&stats_lds[4], sum);
+                    atomicMax(&stats_lds[5], sum);
+                    atomicAdd(&stats_lds[6], len * len);
+                    atomicAdd(&stats_lds[8u + (max_exponent(bd[j]) & 31u)], 1ull);
+                    cur_len[j] = 0u;
+                    cur_ret[j] = 0ull;
+                }
+            }
         }
         if (auto_reset) {
             // one reset block per finished board; usually at most one lane of the wave has one
@@ -621,7 +661,103 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(RolloutArgs a)
         if (a.return_sum) a.return_sum[i] = ret[j];
         if (a.episodes) a.episodes[i] = eps[j];
         if (a.valid_moves) a.valid_moves[i] = moves[j];
+        if (STATS && a.ep_length) a.ep_length[i] = cur_len[j];
+        if (STATS && a.ep_return) a.ep_return[i] = (int64_t)cur_ret[j];
     }
+    if (STATS) {
+        __syncthreads();  // every wave of the block has finished its games' updates
+        if (tid < ENV2048_ROLLOUT_STATS_WORDS && tid != 7u) {
+            const unsigned long long v = stats_lds[tid];
+            if (tid == 4u) {
+                if (v != ~0ull) atomicMin(&a.stats[4], v);
+            } else if (tid == 5u) {
+                atomicMax(&a.stats[5], v);
+            } else if (v) {
+                atomicAdd(&a.stats[tid], v);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Episode segmentation of recorded step rows: what reinforce/training/self_play.py:359-392 does
+// with per-game Python lists.  Rows are the [rows, row_stride] arrays the step kernel wrote (done, reward, max_exp),
+// possibly a ring: logical row r lives in physical row (first_row + r) % ring_rows.  One lane per environment walks
+// its column (a wave reads 64 adjacent environments of a row: coalesced).
+// ------------------------------------------------------------------------------------------
+struct EpisodeRows {
+    uint64_t n, row_stride;
+    uint32_t rows, first_row, ring_rows, flags;
+    const uint8_t *done;
+    const void *reward;  // int32 scores, or float32 with ENV2048_EPISODES_REWARD_F32; may be NULL
+    const uint8_t *max_exp;  // may be NULL
+};
+
+__global__ __launch_bounds__(256) void count_episodes_kernel(EpisodeRows a, uint32_t *counts)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    const bool frozen = (a.flags & ENV2048_EPISODES_FROZEN) != 0u;
+    uint32_t count = 0u, open = 0u, phys = a.first_row;
+    for (uint32_t r = 0; r < a.rows; ++r) {
+        const uint8_t d = a.done[(uint64_t)phys * a.row_stride + i];
+        phys = phys + 1u == a.ring_rows ? 0u : phys + 1u;
+        ++open;
+        if (d) {
+            ++count;
+            open = 0u;
+            if (frozen) break;  // a finished game stops recording (self_play.py:359,368)
+        }
+    }
+    counts[i] = count + (open ? 1u : 0u);
+}
+
+__global__ __launch_bounds__(256) void segment_episodes_kernel(EpisodeRows a, const uint64_t *offsets, env2048_episode *episodes,
+                                                               int32_t *episode_of)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    const bool frozen = (a.flags & ENV2048_EPISODES_FROZEN) != 0u;
+    const bool reward_f32 = (a.flags & ENV2048_EPISODES_REWARD_F32) != 0u;
+    uint64_t slot = offsets[i];
+    uint32_t start = 0u, length = 0u, best = 0u, phys = a.first_row, r = 0u;
+    double total = 0.0;
+    auto emit = [&](bool terminated) {
+        env2048_episode e;
+        e.env = (uint32_t)i;
+        e.start = start;
+        e.length = length;
+        e.terminated = terminated ? 1 : 0;
+        e.max_exp = (uint8_t)best;
+        e.reserved = 0;
+        e.total_reward = total;
+        episodes[slot++] = e;
+    };
+    for (; r < a.rows; ++r) {
+        const uint64_t at = (uint64_t)phys * a.row_stride + i;
+        phys = phys + 1u == a.ring_rows ? 0u : phys + 1u;
+        if (a.reward) total += reward_f32 ? (double)static_cast<const float *>(a.reward)[at] : (double)static_cast<const int32_t *>(a.reward)[at];
+        if (a.max_exp) best = max(best, (uint32_t)a.max_exp[at]);
+        ++length;
+        if (episode_of) episode_of[at] = (int32_t)slot;
+        if (a.done[at]) {
+            emit(true);
+            start = r + 1u;
+            length = 0u;
+            best = 0u;
+            total = 0.0;
+            if (frozen) {
+                ++r;
+                break;
+            }
+        }
+    }
+    if (length) emit(false);
+    if (episode_of)  // frozen: the rows after the end of the game belong to no episode
+        for (; r < a.rows; ++r) {
+            episode_of[(uint64_t)phys * a.row_stride + i] = -1;
+            phys = phys + 1u == a.ring_rows ? 0u : phys + 1u;
+        }
 }
 
 // reinforce/game step on int32 value boards, everything of env.py:79-133 in one launch (one board
@@ -1098,7 +1234,7 @@ int launched(const char *what)
 }
 
 constexpr uint32_t STEP_FLAGS = ENV2048_FLAG_AUTO_RESET | ENV2048_FLAG_RANDOM_ACTIONS | ENV2048_FLAG_OBS_F16 | ENV2048_FLAG_OBS_BF16 |
-                                ENV2048_FLAG_STORES_WRITE_THROUGH | ENV2048_FLAG_STORES_WRITE_BACK;
+                                ENV2048_FLAG_STORES_WRITE_THROUGH | ENV2048_FLAG_STORES_WRITE_BACK | ENV2048_FLAG_REWARD_LOG2_F32;
 // Launches up to this many boards use write-through stores unless a STORES_* flag says otherwise: they win while
 // boards + outputs of one launch stay within the 256 MiB Infinity Cache (measured 2^20..2^23 boards: -5..-13 %)
 // and lose beyond it (2^24: +7 %).
@@ -1111,6 +1247,9 @@ int validate_step(const env2048_step_args &a, const char *who)
         return fail(ENV2048_ERR_INVALID_ARG, "%s: OBS_F16 and OBS_BF16 exclude each other", who);
     if ((a.flags & ENV2048_FLAG_STORES_WRITE_THROUGH) && (a.flags & ENV2048_FLAG_STORES_WRITE_BACK))
         return fail(ENV2048_ERR_INVALID_ARG, "%s: STORES_WRITE_THROUGH and STORES_WRITE_BACK exclude each other", who);
+    if (a.reserved) return fail(ENV2048_ERR_INVALID_ARG, "%s: reserved must be 0", who);
+    if ((a.flags & ENV2048_FLAG_REWARD_LOG2_F32) && !a.reward)
+        return fail(ENV2048_ERR_INVALID_ARG, "%s: REWARD_LOG2_F32 without a reward array", who);
     if (a.n == 0) return ENV2048_OK;
     if (!a.boards || !a.done) return fail(ENV2048_ERR_INVALID_ARG, "%s: boards and done are required", who);
     if (!a.actions && !(a.flags & ENV2048_FLAG_RANDOM_ACTIONS))
@@ -1134,7 +1273,7 @@ void launch_step(const env2048_step_args &a, hipStream_t stream)
 #ifdef ENV2048_EXP_STAMPS
     const bool extras = false;
 #else
-    const bool extras = a.legal || a.obs;
+    const bool extras = a.legal || a.obs || a.max_exp || (a.flags & ENV2048_FLAG_REWARD_LOG2_F32);
 #endif
     const bool random_actions = (a.flags & ENV2048_FLAG_RANDOM_ACTIONS) != 0u;
     const dim3 grid = tile_grid_for(a.n), block(BLOCK);
@@ -1142,7 +1281,7 @@ void launch_step(const env2048_step_args &a, hipStream_t stream)
     const uint32_t step_lo = (uint32_t)a.step_index, step_hi = (uint32_t)(a.step_index >> 32);
 #define ENV2048_LAUNCH_STEP(EXTRAS, RANDOM)                                                                                    \
     hipLaunchKernelGGL((step_kernel<EXTRAS, RANDOM>), grid, block, 0, stream, a.boards, a.actions, a.n, a.env_base, kernel_flags, \
-                       seed_lo, seed_hi, step_lo, step_hi, a.reward, a.done, a.legal, a.obs)
+                       seed_lo, seed_hi, step_lo, step_hi, a.reward, a.done, a.legal, a.obs, a.max_exp)
     if (extras && random_actions)
         ENV2048_LAUNCH_STEP(true, true);
     else if (extras)
@@ -1190,7 +1329,7 @@ int env2048_step(int device, void *stream, uint64_t n, uint64_t env_base, uint8_
                  const uint8_t *actions, int32_t *reward, uint8_t *done, uint8_t *legal, void *obs,
                  uint64_t seed, uint64_t step_index, uint32_t flags)
 {
-    const env2048_step_args a{n, env_base, boards, actions, reward, done, legal, obs, seed, step_index, flags, 0u};
+    const env2048_step_args a{n, env_base, boards, actions, reward, done, legal, obs, seed, step_index, flags, 0u, nullptr};
     if (int rc = validate_step(a, "env2048_step")) return rc;
     if (n == 0) return ENV2048_OK;
     DeviceScope scope(device);
@@ -1238,7 +1377,8 @@ int env2048_step_sequence(int device, void *stream, uint64_t n, uint64_t env_bas
                                  seed,
                                  step_index + t,
                                  flags,
-                                 0u};
+                                 0u,
+                                 nullptr};
     };
     for (uint32_t t = 0; t < count; ++t)
         if (int rc = validate_step(record(t), "env2048_step_sequence")) return rc;
@@ -1332,6 +1472,48 @@ int env2048_status_i32(int device, void *stream, uint64_t n, const int32_t *boar
     return launched("env2048_status_i32 launch");
 }
 
+static int check_episode_rows(const char *who, uint64_t n, uint64_t row_stride, uint32_t rows, uint32_t first_row, uint32_t ring_rows,
+                              const uint8_t *done, const void *reward, uint32_t flags)
+{
+    if (flags & ~(ENV2048_EPISODES_FROZEN | ENV2048_EPISODES_REWARD_F32)) return fail(ENV2048_ERR_INVALID_ARG, "%s: unknown flag bits 0x%x", who, flags);
+    if (!done) return fail(ENV2048_ERR_INVALID_ARG, "%s: done rows are required", who);
+    if (row_stride < n) return fail(ENV2048_ERR_INVALID_ARG, "%s: row_stride %llu is smaller than n = %llu", who, (unsigned long long)row_stride, (unsigned long long)n);
+    if (rows > ring_rows || (ring_rows && first_row >= ring_rows))
+        return fail(ENV2048_ERR_INVALID_ARG, "%s: rows %u / first_row %u do not fit a ring of %u rows", who, rows, first_row, ring_rows);
+    if (misaligned(reward, 4)) return fail(ENV2048_ERR_ALIGNMENT, "%s: reward must be 4-byte aligned", who);
+    return check_count(n);
+}
+
+int env2048_count_episodes(int device, void *stream, uint64_t n, uint64_t row_stride, uint32_t rows, uint32_t first_row,
+                           uint32_t ring_rows, const uint8_t *done, uint32_t flags, uint32_t *counts)
+{
+    if (n == 0) return ENV2048_OK;
+    if (int rc = check_episode_rows("env2048_count_episodes", n, row_stride, rows, first_row, ring_rows, done, nullptr, flags)) return rc;
+    if (!counts || misaligned(counts, 4)) return fail(ENV2048_ERR_INVALID_ARG, "env2048_count_episodes: counts is NULL or misaligned");
+    DeviceScope scope(device);
+    if (scope.rc) return scope.rc;
+    const EpisodeRows a{n, row_stride, rows, first_row, ring_rows, flags, done, nullptr, nullptr};
+    hipLaunchKernelGGL(count_episodes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, counts);
+    return launched("env2048_count_episodes launch");
+}
+
+int env2048_segment_episodes(int device, void *stream, uint64_t n, uint64_t row_stride, uint32_t rows, uint32_t first_row,
+                             uint32_t ring_rows, const uint8_t *done, const void *reward, const uint8_t *max_exp, uint32_t flags,
+                             const uint64_t *offsets, env2048_episode *episodes, int32_t *episode_of)
+{
+    if (n == 0) return ENV2048_OK;
+    if (int rc = check_episode_rows("env2048_segment_episodes", n, row_stride, rows, first_row, ring_rows, done, reward, flags)) return rc;
+    if (!offsets || !episodes) return fail(ENV2048_ERR_INVALID_ARG, "env2048_segment_episodes: offsets and episodes are required");
+    if (misaligned(offsets, 8) || misaligned(episodes, 8) || misaligned(episode_of, 4))
+        return fail(ENV2048_ERR_ALIGNMENT, "env2048_segment_episodes: misaligned offsets / episodes / episode_of");
+    DeviceScope scope(device);
+    if (scope.rc) return scope.rc;
+    const EpisodeRows a{n, row_stride, rows, first_row, ring_rows, flags, done, reward, max_exp};
+    hipLaunchKernelGGL(segment_episodes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, offsets,
+                       episodes, episode_of);
+    return launched("env2048_segment_episodes launch");
+}
+
 int env2048_rollout(int device, void *stream, uint64_t n, uint64_t env_base, uint8_t *boards, uint64_t seed,
                     uint64_t step0, uint32_t T, int64_t *return_sum, uint32_t *episodes, uint32_t *valid_moves,
                     uint32_t flags)
@@ -1349,9 +1531,30 @@ int env2048_rollout(int device, void *stream, uint64_t n, uint64_t env_base, uin
     DeviceScope scope(device);
     if (scope.rc) return scope.rc;
     RolloutArgs a{n, env_base, boards, return_sum, episodes, valid_moves, (uint32_t)seed, (uint32_t)(seed >> 32),
-                  step0, T, flags};
-    hipLaunchKernelGGL(rollout_kernel, tile_grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, a);
+                  step0, T, flags, nullptr, nullptr, nullptr};
+    hipLaunchKernelGGL(rollout_kernel<false>, tile_grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, a);
     return launched("env2048_rollout launch");
+}
+
+int env2048_rollout_episodes(int device, void *stream, uint64_t n, uint64_t env_base, uint8_t *boards, uint64_t seed, uint64_t step0,
+                             uint32_t T, uint32_t flags, uint32_t *ep_length, int64_t *ep_return, uint64_t *stats)
+{
+    if (n == 0) return ENV2048_OK;
+    if (flags & ~(ENV2048_FLAG_AUTO_RESET | ENV2048_FLAG_RANDOM_ACTIONS))
+        return fail(ENV2048_ERR_INVALID_ARG, "env2048_rollout_episodes: unknown flag bits 0x%x", flags);
+    if (!boards || !stats) return fail(ENV2048_ERR_INVALID_ARG, "env2048_rollout_episodes: boards and stats are required");
+    if (misaligned(boards, 16)) return fail(ENV2048_ERR_ALIGNMENT, "env2048_rollout_episodes: boards must be 16-byte aligned");
+    if (misaligned(stats, 8) || misaligned(ep_return, 8) || misaligned(ep_length, 4))
+        return fail(ENV2048_ERR_ALIGNMENT, "env2048_rollout_episodes: misaligned stats / ep_return / ep_length");
+    if (step0 + T < step0) return fail(ENV2048_ERR_RANGE, "env2048_rollout_episodes: step0 + T overflows");
+    if (int rc = check_range(n, env_base)) return rc;
+    if (int rc = check_count(n)) return rc;
+    DeviceScope scope(device);
+    if (scope.rc) return scope.rc;
+    RolloutArgs a{n, env_base, boards, nullptr, nullptr, nullptr, (uint32_t)seed, (uint32_t)(seed >> 32), step0, T, flags,
+                  ep_length, ep_return, reinterpret_cast<unsigned long long *>(stats)};
+    hipLaunchKernelGGL(rollout_kernel<true>, tile_grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, a);
+    return launched("env2048_rollout_episodes launch");
 }
 
 int env2048_afterstate(int device, void *stream, uint64_t n, const uint8_t *boards_in, const uint8_t *actions,

@@ -1,6 +1,7 @@
 // tests/host_emu/emu.cpp -- CPU build of simulate_2048_amd/csrc/board_ops.hpp (ENV2048_HOST_EMULATION).
 // TEST HARNESS ONLY: lets the per-board SWAR arithmetic of the HIP kernels be checked against the
-// oracle and run under -fsanitize=address,undefined without a GPU.  Never loaded by the product.
+// oracle under UBSan (the shared object, tests/test_host_emulation.py) and under ASan + UBSan (the standalone
+// driver tests/host_emu/asan_main.cpp, which includes this file) without a GPU.  Never loaded by the product.
 #define ENV2048_HOST_EMULATION 1
 #include "board_ops.hpp"
 
@@ -119,6 +120,16 @@ void emu_spawn(uint64_t n, uint8_t *boards, const uint8_t *k, const uint8_t *e, 
         store(boards + 16 * i, b);
         placed[i] = ok ? (uint8_t)cell_index(bit) : (uint8_t)0xFF;
     }
+}
+
+void emu_normalized_reward(uint64_t n, const uint32_t *reward, float *out)
+{
+    for (uint64_t i = 0; i < n; ++i) out[i] = normalized_reward(reward[i]);
+}
+
+void emu_max_exponent(uint64_t n, const uint8_t *boards, uint8_t *out)
+{
+    for (uint64_t i = 0; i < n; ++i) out[i] = (uint8_t)max_exponent(load(boards + 16 * i));
 }
 
 }  // extern "C"

@@ -46,18 +46,22 @@ class OracleLibrary:
         if done is not None:
             _view(done, n, np.uint8)[:] = 0
 
-    def step(self, device, stream, n, env_base, boards, actions, reward, done, legal, obs, seed, step_index, flags):
+    def step(self, device, stream, n, env_base, boards, actions, reward, done, legal, obs, seed, step_index, flags, max_exp=None):
         self.calls.append(('step', n))
         b = _view(boards, n * 16, np.uint8)
         a = None if actions is None else _view(actions, n, np.uint8).copy()
-        res = oracle.step_batch(b.reshape(n, 16), a, seed, step_index, env_base=env_base, flags=flags & 3,
-                                want_legal=legal is not None, want_obs=obs is not None)
+        res = oracle.step_batch_ex(b.reshape(n, 16), a, seed, step_index, env_base=env_base, flags=flags & 3)
         b[:] = res['boards'].reshape(-1)
         if reward is not None:
-            _view(reward, n, np.int32)[:] = res['reward']
+            if flags & 64:  # REWARD_LOG2_F32
+                _view(reward, n, np.float32)[:] = res['reward_norm']
+            else:
+                _view(reward, n, np.int32)[:] = res['reward']
         _view(done, n, np.uint8)[:] = res['done']
         if legal is not None:
             _view(legal, n, np.uint8)[:] = res['legal']
+        if max_exp is not None:
+            _view(max_exp, n, np.uint8)[:] = res['max_exp']
         if obs is not None:
             if flags & 4:  # OBS_F16
                 _view(obs, n * 16, np.float16)[:] = res['obs'].reshape(-1).astype(np.float16)
@@ -69,7 +73,7 @@ class OracleLibrary:
     def step_many(self, device, stream, records):
         for r in records:
             self.step(device, stream, r.n, r.env_base, r.boards, r.actions, r.reward, r.done, r.legal, r.obs, r.seed, r.step_index,
-                      r.flags & 15)
+                      r.flags & (15 | 64), max_exp=r.max_exp)
 
     def step_sequence(self, device, stream, n, env_base, boards, actions, reward, done, legal, obs, row_stride, seed, step_index,
                       count, flags):
@@ -77,7 +81,7 @@ class OracleLibrary:
         off = lambda p, t, scale: None if p is None else int(p) + t * row_stride * scale
         for t in range(count):
             self.step(device, stream, n, env_base, boards, None if actions is None else actions[t], off(reward, t, 4),
-                      off(done, t, 1), off(legal, t, 1), off(obs, t, 16 * obs_bytes), seed, step_index + t, flags & 15)
+                      off(done, t, 1), off(legal, t, 1), off(obs, t, 16 * obs_bytes), seed, step_index + t, flags & (15 | 64))
 
     def step_state_i32(self, device, stream, n, env_base, boards, actions, step_count, done_io, total_reward, reward, max_tile,
                        seed, step_index):
@@ -146,6 +150,46 @@ class OracleLibrary:
             _view(episodes, n, np.uint32)[:] = res['episodes']
         if valid_moves is not None:
             _view(valid_moves, n, np.uint32)[:] = res['valid_moves']
+
+    def rollout_episodes(self, device, stream, n, env_base, boards, seed, step0, T, flags, ep_length, ep_return, stats):
+        self.calls.append(('rollout_episodes', n))
+        b = _view(boards, n * 16, np.uint8)
+        st = _view(stats, oracle.ROLLOUT_STATS_WORDS, np.uint64)
+        res = oracle.rollout_episodes(b.reshape(n, 16), seed, step0, T, env_base=env_base, flags=flags,
+                                      ep_length=None if ep_length is None else _view(ep_length, n, np.uint32),
+                                      ep_return=None if ep_return is None else _view(ep_return, n, np.int64), stats=st)
+        b[:] = res['boards'].reshape(-1)
+        st[:] = res['stats']
+        if ep_length is not None:
+            _view(ep_length, n, np.uint32)[:] = res['ep_length']
+        if ep_return is not None:
+            _view(ep_return, n, np.int64)[:] = res['ep_return']
+
+    def _rows(self, ptr, ring_rows, row_stride, dtype):
+        return None if ptr is None else _view(ptr, ring_rows * row_stride, dtype).reshape(ring_rows, row_stride)
+
+    def count_episodes(self, device, stream, n, row_stride, rows, first_row, ring_rows, done, flags, counts):
+        self.calls.append(('count_episodes', n))
+        eps = oracle.segment_episodes(self._rows(done, ring_rows, row_stride, np.uint8), n=n, rows=rows, first_row=first_row,
+                                      ring_rows=ring_rows, flags=flags)
+        _view(counts, n, np.uint32)[:] = np.bincount(eps['env'], minlength=n).astype(np.uint32)
+
+    def segment_episodes(self, device, stream, n, row_stride, rows, first_row, ring_rows, done, reward, max_exp, flags, offsets,
+                         episodes, episode_of):
+        self.calls.append(('segment_episodes', n))
+        eps, eo = oracle.segment_episodes(self._rows(done, ring_rows, row_stride, np.uint8),
+                                          self._rows(reward, ring_rows, row_stride, np.float32 if flags & 2 else np.int32),
+                                          self._rows(max_exp, ring_rows, row_stride, np.uint8), n=n, rows=rows, first_row=first_row,
+                                          ring_rows=ring_rows, flags=flags, want_episode_of=True)
+        # the C-ABI writes environment i's records at offsets[i]: with the exclusive prefix sum of the counts that is the
+        # oracle's own (environment, start) order
+        off = _view(offsets, n, np.uint64)
+        assert np.array_equal(off, np.concatenate([[0], np.cumsum(np.bincount(eps['env'], minlength=n))[:-1]]).astype(np.uint64))
+        _view(episodes, len(eps) * 24, np.uint8)[:] = eps.view(np.uint8).reshape(-1)
+        if episode_of is not None:
+            out = self._rows(episode_of, ring_rows, row_stride, np.int32)
+            touched = [(first_row + r) % ring_rows for r in range(rows)]
+            out[touched, :n] = eo[touched, :n]
 
     def afterstate(self, device, stream, n, boards_in, actions, boards_out, reward, changed):
         self.calls.append(('afterstate', n))

@@ -570,6 +570,49 @@ def test_trajectory_buffer_on_gpu(lib):
     np.testing.assert_array_equal(traj.reward[T - 1].cpu().numpy(), res['reward'])
 
 
+def test_keyed_step_and_reset_match_oracle(lib):
+    """One PRNG key per environment (vmap semantics): env2048_reset_keyed_i32 / env2048_step_state_i32_keyed vs the
+    oracle, and row i == the scalar-seed entry point with seed (k0 << 32) | k1 on a batch of one."""
+    rng = np.random.default_rng(12)
+    n = 20_003
+    keys = rng.integers(0, 1 << 32, size=(n, 2), dtype=np.uint64).astype(np.uint32)
+    keys[0] = (0, 0)
+    keys[1] = (0xFFFFFFFF, 0xFFFFFFFF)
+    k = cu(keys.view(np.int32))
+    fresh = torch.full((n, 16), -1, dtype=torch.int32, device='cuda')
+    lib.reset_keyed_i32(DEV, stream(), n, p(k), p(fresh))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(fresh.cpu().numpy(), oracle.reset_keyed_i32(keys))
+    values = oracle.unpack_values(random_boards(rng, n)).astype(np.int32)
+    actions = rng.integers(-3, 9, size=n).astype(np.int32)
+    step_count = rng.integers(0, 500, size=n).astype(np.int32)
+    done = (rng.random(n) < 0.2).astype(np.uint8)
+    total = rng.integers(0, 5000, size=n).astype(np.float32)
+    ref = oracle.step_state_i32_keyed(values, actions, step_count, done, total, keys)
+    b_in, a, sc_in, d_in, tr_in = cu(values), cu(actions), cu(step_count), cu(done), cu(total)
+    b_out = torch.full((n, 16), -5, dtype=torch.int32, device='cuda')
+    sc_out = torch.full((n,), -5, dtype=torch.int32, device='cuda')
+    d_out = torch.full((n,), 9, dtype=torch.uint8, device='cuda')
+    tr_out = torch.full((n,), -5.0, dtype=torch.float32, device='cuda')
+    reward = torch.full((n,), -1.0, dtype=torch.float32, device='cuda')
+    max_tile = torch.full((n,), -1, dtype=torch.int32, device='cuda')
+    lib.step_state_i32_keyed(DEV, stream(), n, p(k), p(b_in), p(b_out), p(a), p(sc_in), p(sc_out), p(d_in), p(d_out), p(tr_in),
+                             p(tr_out), p(reward), p(max_tile))
+    torch.cuda.synchronize()
+    for got, key in ((b_out, 'boards'), (sc_out, 'step_count'), (d_out, 'done'), (tr_out, 'total_reward'), (reward, 'reward'),
+                     (max_tile, 'max_tile')):
+        np.testing.assert_array_equal(got.cpu().numpy(), ref[key], err_msg=key)
+    np.testing.assert_array_equal(b_in.cpu().numpy(), values)  # input only read
+    for i in (0, 1, 777, n - 1):  # the scalar-seed form on a batch of one gives the same row
+        seed = (int(keys[i, 0]) << 32) | int(keys[i, 1])
+        one = oracle.step_state_i32(values[i:i + 1], actions[i:i + 1], step_count[i:i + 1], done[i:i + 1], total[i:i + 1], seed, 0)
+        np.testing.assert_array_equal(one['boards'][0], ref['boards'][i])
+    with pytest.raises(capi.Env2048Error) as e:
+        lib.step_state_i32_keyed(DEV, stream(), n, None, p(b_in), p(b_out), p(a), None, None, p(d_in), p(d_out), None, None,
+                                 p(reward), None)
+    assert e.value.code == capi.ERR_INVALID_ARG
+
+
 def test_step_state_i32_matches_oracle(lib):
     """Fused reinforce/game step on int32 value boards: done-guard, bookkeeping, JAX is_done."""
     rng = np.random.default_rng(11)

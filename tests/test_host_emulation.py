@@ -1,7 +1,9 @@
 """
 CPU unit tests of the HIP kernels' per-board arithmetic: simulate_2048_amd/csrc/board_ops.hpp is
-compiled for the host (ENV2048_HOST_EMULATION: v_perm_b32 / popcount / mulhi emulated) with
--fsanitize=address,undefined and compared bit-for-bit with the oracle and the golden fixtures.
+compiled for the host (ENV2048_HOST_EMULATION: v_perm_b32 / popcount / mulhi emulated), compared bit-for-bit with
+the oracle and the golden fixtures as a shared object built with -fsanitize=undefined (UBSan), and run once more as a
+standalone executable under -fsanitize=address,undefined (tests/host_emu/asan_main.cpp: the batch loops over caller
+buffers on exactly-sized heap blocks).  Sanitizers run on this CPU build only (none are available for the GPU here).
 This is a test harness (tests/host_emu), not a CPU backend: the product never loads it.
 """
 
@@ -201,3 +203,38 @@ def test_random_boards_vs_oracle(emu):
     np.testing.assert_array_equal(reward, ref['reward'])
     np.testing.assert_array_equal(done, ref['done'])
     np.testing.assert_array_equal(legal, ref['legal'])
+
+
+def test_batch_loops_under_asan_and_ubsan(tmp_path):
+    """ASan + UBSan over every batch function of the host build (the shared object only had UBSan)."""
+    exe = tmp_path / 'emu_asan'
+    main = REPO / 'tests' / 'host_emu' / 'asan_main.cpp'
+    subprocess.run(['g++', '-O1', '-g', '-std=c++17', '-fsanitize=address,undefined', '-fno-sanitize-recover=all', '-Wall', '-Wextra',
+                    f'-I{HDR.parent}', f'-I{main.parent}', str(main), '-o', str(exe)], check=True)
+    proc = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300, env={'ASAN_OPTIONS': 'detect_leaks=1'})
+    assert proc.returncode == 0 and proc.stdout.startswith('asan+ubsan ok'), proc.stderr[-3000:]
+
+
+def test_normalized_reward_and_max_exponent(emu, golden):
+    """The device formula of ENV2048_FLAG_REWARD_LOG2_F32 (board_ops.hpp normalized_reward) against the reference's own
+    normalize_reward values (tests/golden/transforms.npz, float64): tolerance 1 ulp of float32; and against the oracle for
+    every score below 2^17 plus random ones below 2^24.  max_exponent against the oracle's board maximum."""
+    g = golden['transforms']
+    rewards = g['rewards'].astype(np.uint32)
+    out = np.zeros(len(rewards), dtype=np.float32)
+    emu.emu_normalized_reward(ctypes.c_uint64(len(rewards)), ptr(rewards, ctypes.c_uint32), ptr(out, ctypes.c_float))
+    want = g['normalized'].astype(np.float32)
+    ulp = np.spacing(np.maximum(np.abs(want), np.float32(1e-30)))
+    assert np.all(np.abs(out - want) <= ulp), (out, want)
+    assert out[0] == 0.0 and out[1] == 0.125
+    rng = np.random.default_rng(0)
+    scores = np.concatenate([np.arange(1 << 17, dtype=np.uint32), rng.integers(1, 1 << 24, size=200_000).astype(np.uint32)])
+    got = np.zeros(len(scores), dtype=np.float32)
+    emu.emu_normalized_reward(ctypes.c_uint64(len(scores)), ptr(scores, ctypes.c_uint32), ptr(got, ctypes.c_float))
+    ref = np.where(scores == 0, 0.0, np.log2(np.maximum(scores, 1).astype(np.float64)) / 16.0).astype(np.float32)
+    assert np.all(np.abs(got - ref) <= np.spacing(np.maximum(ref, np.float32(1e-30))))
+    assert float(np.mean(got == ref)) > 0.9  # and almost always the correctly rounded value itself
+    boards = rng.integers(0, 18, size=(5000, 16)).astype(np.uint8)
+    mx = np.zeros(5000, dtype=np.uint8)
+    emu.emu_max_exponent(ctypes.c_uint64(5000), u8(boards), u8(mx))
+    np.testing.assert_array_equal(mx, boards.max(axis=1))

@@ -1,0 +1,204 @@
+"""
+SURVEY 8(f) N4 -- device-side trajectory recording, episode segmentation, batched normalised reward, on-device
+evaluation statistics.  Each test runs on the oracle-backed stand-in (host logic, CPU) and on the GPU with the HIP
+library.  What is restated from the reference: the per-move recording and the cut into Trajectory objects of
+reinforce/training/self_play.py:359-392, normalize_reward (twentyfortyeight/utils/normalize.py:6-33) and the report of
+evaluate_games (self_play.py:503-521).
+"""
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle_backend import OracleLibrary
+from simulate_2048_amd import BatchedEnv2048, capi
+from simulate_2048_amd.trajectory import TrajectoryBuffer
+
+
+@pytest.fixture(params=['host-logic', pytest.param('hip', marks=pytest.mark.gpu)])
+def make_env(request):
+    if request.param == 'hip':
+        return lambda n, seed, **kw: BatchedEnv2048(n, seed, device='cuda:0', **kw)
+    return lambda n, seed, **kw: BatchedEnv2048(n, seed, device='cpu', lib=OracleLibrary(), **kw)
+
+
+def host(t):
+    return t.cpu().numpy()
+
+
+def test_recorded_rows_match_oracle(make_env):
+    """Every row the step kernel writes into the [T, N] arrays -- incl. max_exp (pre-reset) and, with
+    normalize_reward, the float32 log-normalised reward (<= 1 ulp from the oracle's double-precision value)."""
+    n, T, seed = 700, 40, 5
+    for normalize in (False, True):
+        env = make_env(n, seed, env_base=3, auto_reset=True, with_legal=True, with_obs=True)
+        env.reset()
+        env.rollout(150)  # mid/late game: games end inside the recording
+        traj = TrajectoryBuffer(env, T, record_policy=True, record_value=True, normalize_reward=normalize)
+        traj.begin()
+        ref = host(env.boards).copy()
+        rng = np.random.default_rng(1)
+        finished = 0
+        for t in range(T):
+            acts = torch.from_numpy(rng.integers(0, 4, size=n).astype(np.uint8)).to(env.device)
+            pol = torch.from_numpy(rng.random((n, 4)).astype(np.float32)).to(env.device)
+            val = torch.from_numpy(rng.random(n).astype(np.float32)).to(env.device)
+            traj.step(acts, policy=pol, value=val)
+            r = oracle.step_batch_ex(ref, host(acts), seed, 150 + t, env_base=3, flags=1)
+            ref = r['boards']
+            finished += int(r['done'].sum())
+            assert np.array_equal(host(traj.done[t]), r['done']) and np.array_equal(host(traj.max_exp[t]), r['max_exp'])
+            assert np.array_equal(host(traj.legal[t + 1]), r['legal']) and np.array_equal(host(traj.obs[t + 1]), r['obs'])
+            assert np.array_equal(host(traj.actions[t]), host(acts))
+            assert torch.equal(traj.policy[t], pol) and torch.equal(traj.value[t], val)
+            if normalize:
+                got, want = host(traj.reward[t]), r['reward_norm']
+                assert got.dtype == np.float32
+                assert np.all(np.abs(got - want) <= np.spacing(np.maximum(want, np.float32(1e-30)))), 'normalised reward: > 1 ulp'
+                assert np.all((got == 0) == (r['reward'] == 0))
+            else:
+                assert np.array_equal(host(traj.reward[t]), r['reward'])
+        assert np.array_equal(host(env.boards), ref) and finished > 20
+        # a finished game's max_exp row is its LAST board's max tile, not the fresh board's (which is <= 2)
+        ended = host(traj.done) == 1
+        assert host(traj.max_exp)[ended].min() >= 4
+
+
+def reference_style_cut(obs, actions, rewards, dones, max_steps):
+    """self_play.py:359-392 restated over recorded rows: per game, rows while active; active &= ~done."""
+    n = dones.shape[1]
+    lists = [dict(obs=[], act=[], rew=[]) for _ in range(n)]
+    active = np.ones(n, dtype=bool)
+    for t in range(max_steps):
+        if not active.any():
+            break
+        for i in range(n):
+            if active[i]:
+                lists[i]['obs'].append(obs[t, i])
+                lists[i]['act'].append(int(actions[t, i]))
+                lists[i]['rew'].append(float(rewards[t, i]))
+        active = active & ~dones[t].astype(bool)
+    return lists, active
+
+
+def test_frozen_episodes_equal_the_reference_cut(make_env):
+    """No auto-reset (the reference's loop): one episode per game, rows after the first done excluded, Trajectory fields."""
+    n, T, seed = 96, 700, 77
+    env = make_env(n, seed, with_legal=True, with_obs=True)
+    env.reset()
+    traj = TrajectoryBuffer(env, T, record_boards=True)
+    traj.begin()
+    rng = np.random.default_rng(2)
+    for t in range(T):
+        legal = host(traj.legal[t])
+        acts = np.array([rng.choice([a for a in range(4) if (m >> a) & 1]) if m else 0 for m in legal], dtype=np.uint8)
+        traj.step(torch.from_numpy(acts).to(env.device))
+    ep = traj.episodes(want_episode_of=True)
+    lists, still_active = reference_style_cut(host(traj.obs), host(traj.actions), host(traj.reward), host(traj.done), T)
+    assert not still_active.any()  # random-legal play ends within 700 moves
+    assert len(ep['env']) == n and host(ep['env']).tolist() == list(range(n)) and bool(ep['terminated'].all())
+    final_boards = host(traj.boards[T])
+    for i in (0, 1, 17, n - 1):
+        tr = traj.trajectory(ep, i)
+        assert len(lists[i]['act']) == int(ep['length'][i]) == tr['actions'].shape[0]
+        assert np.array_equal(host(tr['observations']), np.stack(lists[i]['obs']))
+        assert host(tr['actions']).tolist() == lists[i]['act'] and host(tr['rewards']).astype(float).tolist() == lists[i]['rew']
+        assert tr['done'] is True and tr['total_reward'] == float(sum(lists[i]['rew']))
+        assert tr['max_tile'] == 1 << int(final_boards[i].max())  # frozen games keep their last board
+    lengths = host(ep['length'])
+    eo = host(ep['episode_of'])
+    for i in (0, 5, n - 1):
+        assert (eo[: lengths[i], i] == i).all() and (eo[lengths[i]:, i] == -1).all()
+    # the same through the oracle's restatement
+    want = oracle.segment_episodes(host(traj.done), host(traj.reward), host(traj.max_exp), flags=1)
+    assert np.array_equal(host(ep['length']), want['length']) and np.array_equal(host(ep['total_reward']), want['total_reward'])
+    assert np.array_equal(host(ep['max_tile']), np.where(want['max_exp'] > 0, 1 << want['max_exp'].astype(np.int64), 0))
+
+
+def test_auto_reset_episodes_and_ring_mode(make_env):
+    n, T, C, seed = 300, 260, 64, 9
+    plain_env = make_env(n, seed, auto_reset=True)
+    ring_env = make_env(n, seed, auto_reset=True)
+    for e in (plain_env, ring_env):
+        e.reset()
+    plain = TrajectoryBuffer(plain_env, T, record_obs=False, record_legal=False)
+    ring = TrajectoryBuffer(ring_env, C, record_obs=False, record_legal=False, ring=True)
+    plain.begin()
+    ring.begin()
+    for t in range(T):
+        plain.step(None)
+        ring.step(None)
+    ep = plain.episodes(want_episode_of=True)
+    want, want_of = oracle.segment_episodes(host(plain.done), host(plain.reward), host(plain.max_exp), want_episode_of=True)
+    for key in ('env', 'length', 'terminated', 'total_reward'):
+        assert np.array_equal(host(ep[key]).astype(want[key].dtype), want[key]), key
+    assert np.array_equal(host(ep['start']), want['start']) and np.array_equal(host(ep['episode_of']), want_of)
+    assert np.array_equal(host(ep['max_tile']), 1 << want['max_exp'].astype(np.int64))
+    # every environment's episodes tile its column exactly
+    lengths = np.bincount(want['env'], weights=want['length'], minlength=n)
+    assert (lengths == T).all() and len(want) > n and int(want['terminated'].sum()) == int(host(plain.done).sum())
+    # ring: rows wrapped 4 times; the window is the last C steps (no obs/legal rows recorded -> all C are valid)
+    assert ring.generation == T // C and ring.window() == (T - C, C)
+    order = [(T - C + r) % C for r in range(C)]
+    assert np.array_equal(host(ring.done)[order], host(plain.done)[T - C:]) and np.array_equal(host(ring.reward)[order], host(plain.reward)[T - C:])
+    rep = ring.episodes()
+    rwant = oracle.segment_episodes(host(plain.done)[T - C:], host(plain.reward)[T - C:], host(plain.max_exp)[T - C:])
+    assert np.array_equal(host(rep['length']), rwant['length']) and np.array_equal(host(rep['start']), rwant['start'].astype(np.int64) + T - C)
+    assert np.array_equal(host(rep['total_reward']), rwant['total_reward'])
+    with pytest.raises(IndexError):
+        plain.step(None)  # a plain buffer is full after `horizon` steps
+    # ring with observation rows: the oldest step's "before" row has been reused -> window of C - 1 steps
+    ring2 = TrajectoryBuffer(ring_env, 8, ring=True)
+    ring2.begin()
+    for _ in range(20):
+        ring2.step(None)
+    assert ring2.window() == (13, 7) and len(ring2.episodes()['env']) >= n
+
+
+def test_rollout_episode_statistics(make_env):
+    """env2048_rollout_episodes: per-episode statistics accumulated on device == the oracle's, games spanning calls are
+    counted whole, and the derived report has the keys of evaluate_games (self_play.py:503-521)."""
+    n, seed = 900, 31
+    env = make_env(n, seed, env_base=10, auto_reset=True)
+    env.reset()
+    start = host(env.boards).copy()
+    stats = env.rollout_episodes(170)
+    stats = env.rollout_episodes(230, stats)  # second call continues the games in progress
+    ref = oracle.rollout_episodes(start, seed, 0, 400, env_base=10, flags=3)
+    assert np.array_equal(host(stats).view(np.uint64), ref['stats'])
+    assert np.array_equal(host(env.boards), ref['boards'])
+    assert np.array_equal(host(env._ep_length).astype(np.uint32), ref['ep_length']) and np.array_equal(host(env._ep_return), ref['ep_return'])
+    rep = BatchedEnv2048.episode_statistics(stats)
+    w = ref['stats']
+    games = int(w[0])
+    assert rep['games'] == games > n and rep['mean_length'] == int(w[1]) / games and rep['mean_reward'] == int(w[2]) / games
+    assert 100 < rep['mean_length'] < 200 and rep['min_reward'] <= rep['mean_reward'] <= rep['max_reward']
+    assert sum(rep['max_tile_histogram'].values()) == games and rep['max_tile'] in (128, 256, 512)
+    assert set(rep) >= {'mean_reward', 'std_reward', 'max_reward', 'min_reward', 'mean_max_tile', 'max_tile', 'mean_length',
+                        'reached_2048', 'reached_4096', 'reached_8192', 'reached_16384', 'reached_32768'}
+    # the plain rollout is untouched by the statistics variant: same boards from the same start
+    plain = make_env(n, seed, env_base=10, auto_reset=True)
+    plain.reset()
+    plain.rollout(400)
+    assert torch.equal(plain.boards, env.boards)
+
+
+def test_episode_entry_points_reject_bad_arguments(make_env):
+    env = make_env(8, 1)
+    if isinstance(env.lib, OracleLibrary):
+        pytest.skip('argument validation lives in the C-ABI')
+    done = torch.zeros((4, 8), dtype=torch.uint8, device=env.device)
+    counts = torch.zeros((8,), dtype=torch.int32, device=env.device)
+    s = torch.cuda.current_stream().cuda_stream
+    with pytest.raises(capi.Env2048Error) as e:
+        env.lib.count_episodes(0, s, 8, 7, 4, 0, 4, done.data_ptr(), 0, counts.data_ptr())  # stride < n
+    assert e.value.code == capi.ERR_INVALID_ARG
+    with pytest.raises(capi.Env2048Error) as e:
+        env.lib.count_episodes(0, s, 8, 8, 5, 0, 4, done.data_ptr(), 0, counts.data_ptr())  # more rows than the ring holds
+    assert e.value.code == capi.ERR_INVALID_ARG
+    with pytest.raises(capi.Env2048Error) as e:
+        env.lib.count_episodes(0, s, 8, 8, 4, 0, 4, done.data_ptr(), 8, counts.data_ptr())  # unknown flag
+    assert e.value.code == capi.ERR_INVALID_ARG
+    with pytest.raises(ValueError):
+        env.step(None, out_reward=torch.zeros(8, dtype=torch.int32, device=env.device), normalized_reward=True)
