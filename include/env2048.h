@@ -342,6 +342,25 @@ ENV2048_EXPORT int env2048_chance_outcomes(int device, void *stream, uint64_t n,
                                            float *out_prob, uint8_t *out_count);
 
 /*
+ * One full expectimax ply of the true environment, fused: for every board i and action a, the afterstate's merge score
+ * after_reward[4*i + a] and -- if a is legal -- ALL chance outcomes of that afterstate in the 32 slots s = 2*k + v of
+ * env2048_chance_outcomes (k = rank of the empty cell in row-major order, v = 0 tile 2 / 1 tile 4):
+ *     succ_boards[((4*i + a)*32 + s) * 16 ..]  the successor board (zero board for an unused slot)
+ *     succ_prob  [ (4*i + a)*32 + s ]          P(tile) / n_empty (0 for an unused slot)
+ *     succ_status[ (4*i + a)*32 + s ]          bits 0-3: legal-action mask of the successor, bit 4: successor is terminal
+ *     succ_count [ 4*i + a ]                   used slots = 2 * n_empty(afterstate); 0 for an ILLEGAL action (the board
+ *                                              does not change, so there is nothing to enumerate: all 32 slots are zero)
+ *     legal[i]                                 bit a set <=> action a legal on board i
+ * = env2048_afterstates4 -> env2048_chance_outcomes (on the legal afterstates) -> env2048_status of every successor in one
+ * launch, without the 4n afterstates ever being written to memory.  succ_status, succ_count, after_reward, legal may be NULL.
+ * [replaces: per node of a search over the true environment, twentyfortyeight/core/gameboard.py:105-129 latent_state x 4,
+ *            :132-171 after_state, :328-348 is_done and gamemove.py:45-83 legal_actions_mask on every outcome]
+ */
+ENV2048_EXPORT int env2048_expectimax_ply(int device, void *stream, uint64_t n, const uint8_t *boards, uint8_t *succ_boards,
+                                          float *succ_prob, uint8_t *succ_status, uint8_t *succ_count, int32_t *after_reward,
+                                          uint8_t *legal);
+
+/*
  * Read-only board status; every output may be NULL.
  *     done / legal / obs as in env2048_step;  max_exp[i] = log2(max tile);  n_empty[i] = #zeros
  * [replaces: twentyfortyeight/core/gameboard.py:328-348 is_done;

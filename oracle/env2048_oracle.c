@@ -644,6 +644,46 @@ ORACLE_API int oracle_chance_outcomes(uint64_t n, const uint8_t *boards, uint8_t
     return 0;
 }
 
+/* One expectimax ply [ref: gameboard.py:105-129 latent_state for each action; :132-171 after_state on every LEGAL
+ * afterstate (legality: the move changes the board, gamemove.py:132-164 / gameboard.py:317); per outcome
+ * gamemove.py:45-83 legal_actions_mask and gameboard.py:328-348 is_done].  Same slot layout as oracle_chance_outcomes;
+ * an illegal action has count 0 and all-zero slots. */
+ORACLE_API int oracle_expectimax_ply(uint64_t n, const uint8_t *boards, uint8_t *succ_boards, float *succ_prob,
+                                     uint8_t *succ_status, uint8_t *succ_count, int32_t *after_reward, uint8_t *legal)
+{
+    memset(succ_boards, 0, (size_t)n * 128 * 16);
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint8_t *b = boards + 16 * i;
+        uint8_t mask = 0;
+        for (int a = 0; a < 4; ++a) {
+            uint8_t after[16];
+            int64_t r = oracle_latent_state(b, a, after);
+            int changed = memcmp(after, b, 16) != 0;
+            int n_empty = oracle_count_empty(after);
+            uint64_t base = (4 * i + (uint64_t)a) * 32;
+            if (after_reward) after_reward[4 * i + a] = (int32_t)r;
+            if (succ_count) succ_count[4 * i + a] = (uint8_t)(changed ? 2 * n_empty : 0);
+            for (int s = 0; s < 32; ++s) {
+                succ_prob[base + s] = 0.0f;
+                if (succ_status) succ_status[base + s] = 0;
+            }
+            if (!changed) continue;
+            mask |= (uint8_t)(1u << a);
+            for (int k = 0; k < n_empty; ++k)
+                for (int v = 0; v < 2; ++v) {
+                    uint8_t *o = succ_boards + (base + 2 * k + v) * 16;
+                    memcpy(o, after, 16);
+                    oracle_fill_cell_kv(o, k, (uint8_t)(v + 1));
+                    succ_prob[base + 2 * k + v] = (v ? 0.1f : 0.9f) / (float)n_empty;
+                    if (succ_status)
+                        succ_status[base + 2 * k + v] = (uint8_t)(oracle_legal_actions_mask(o) | (oracle_is_done(o) ? 16 : 0));
+                }
+        }
+        if (legal) legal[i] = mask;
+    }
+    return 0;
+}
+
 /* [ref: twentyfortyeight/utils/binary.py:11-86 encode_flatten]  eye(width)[log2(cell)], empty -> index 0. */
 ORACLE_API int oracle_encode_onehot(uint64_t n, const uint8_t *boards, uint32_t width, uint8_t *out)
 {

@@ -83,6 +83,7 @@ PROTOTYPES = {
     'env2048_spawn': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr]),
     'env2048_spawn_random': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _u64, _u64, _u32]),
     'env2048_chance_outcomes': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr]),
+    'env2048_expectimax_ply': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
     'env2048_status': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
     'env2048_encode_onehot': (_c_int, [_c_int, _ptr, _u64, _ptr, _u32, _ptr]),
     'env2048_pack_i32': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr]),
@@ -210,6 +211,10 @@ class Library:
 
     def chance_outcomes(self, device, stream, n, boards, out_boards, out_prob, out_count) -> None:
         self._check(self._dll.env2048_chance_outcomes(device, stream, n, boards, out_boards, out_prob, out_count))
+
+    def expectimax_ply(self, device, stream, n, boards, succ_boards, succ_prob, succ_status, succ_count, after_reward, legal) -> None:
+        self._check(self._dll.env2048_expectimax_ply(device, stream, n, boards, succ_boards, succ_prob, succ_status, succ_count,
+                                                     after_reward, legal))
 
     def encode_onehot(self, device, stream, n, boards, width, out) -> None:
         self._check(self._dll.env2048_encode_onehot(device, stream, n, boards, width, out))

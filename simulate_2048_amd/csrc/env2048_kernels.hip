@@ -939,6 +939,113 @@ __global__ __launch_bounds__(BLOCK) void afterstates4_kernel(uint64_t n, const u
     if (out_legal) out_legal[i] = (uint8_t)legal;
 }
 
+// One full expectimax ply of the TRUE environment in one launch: for every board the afterstates of all four actions
+// [ref: twentyfortyeight/core/gameboard.py:105-129 latent_state] and, for every legal action, all (empty cell, tile)
+// chance outcomes of its afterstate with their probabilities, in the reference's enumeration order
+// [ref: gameboard.py:132-171 after_state] -- 4 x 32 = 128 successor slots per board -- plus, optionally, the status byte of
+// every successor (legal-action mask, terminal flag: gamemove.py:45-83, gameboard.py:328-348).  The 4n afterstates never
+// go to HBM.  Work split: a wave owns 64 boards; first each lane computes the four afterstates of ONE board (one byte
+// transpose shared by the four slides) and parks them, their empty-cell masks and spawn probabilities in the wave's LDS
+// strip; then the wave walks its 64 boards in 128 iterations, lane l producing successor (action 2h + l/32, slot l%32) of
+// board it/2 (h = it%2), so that every store instruction of the wave writes 1 KiB (boards), 256 B (probabilities) or 64 B
+// (status) of CONTIGUOUS output.  HBM-bound: 16 B in, 128 x (16 + 4 [+ 1]) B out per board.
+struct PlyAfter {  // one (board, action) entry of the LDS strip: 32 bytes
+    uint32_t r0, r1, r2, r3;
+    uint32_t empties;  // cell mask of the afterstate's empty cells; 0 = action illegal (nothing to enumerate)
+    uint32_t n_empty;
+    float p2, p4;  // P(tile 2) / n_empty, P(tile 4) / n_empty
+};
+
+constexpr int PLY_BLOCK = 256;
+
+__global__ __launch_bounds__(PLY_BLOCK) void expectimax_ply_kernel(uint64_t n, const uint8_t *boards, uint8_t *succ_boards,
+                                                                   float *succ_prob, uint8_t *succ_status, uint8_t *succ_count,
+                                                                   int32_t *after_reward, uint8_t *legal_out)
+{
+    __shared__ __attribute__((aligned(16))) PlyAfter strip_lds[PLY_BLOCK / 64][64 * 4];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t board0 = ((uint64_t)blockIdx.x * (PLY_BLOCK / 64) + wave) * 64u;  // first board of this wave
+    if (board0 >= n) return;  // wave-uniform
+    PlyAfter *strip = strip_lds[wave];
+
+    // phase 1: one board per lane -> four afterstates into LDS
+    const uint64_t mine = board0 + lane;
+    if (mine < n) {
+        const Board bd = load_board(boards, mine);
+        uint32_t c0, c1, c2, c3;
+        transpose4x4(bd.r0, bd.r1, bd.r2, bd.r3, c0, c1, c2, c3);
+        Board after[4];
+        int4 rewards;
+        uint32_t legal = 0u, changed;
+        {  // 0 = left: planes are the columns, wall side first
+            uint32_t a = c0, b = c1, c = c2, d = c3;
+            rewards.x = (int32_t)slide_merge_planes(a, b, c, d, changed);
+            transpose4x4(a, b, c, d, after[0].r0, after[0].r1, after[0].r2, after[0].r3);
+            legal |= changed != 0u ? 1u : 0u;
+        }
+        {  // 1 = up: planes are the rows
+            uint32_t a = bd.r0, b = bd.r1, c = bd.r2, d = bd.r3;
+            rewards.y = (int32_t)slide_merge_planes(a, b, c, d, changed);
+            after[1] = Board{a, b, c, d};
+            legal |= changed != 0u ? 2u : 0u;
+        }
+        {  // 2 = right: columns, last column is the wall
+            uint32_t a = c3, b = c2, c = c1, d = c0;
+            rewards.z = (int32_t)slide_merge_planes(a, b, c, d, changed);
+            transpose4x4(d, c, b, a, after[2].r0, after[2].r1, after[2].r2, after[2].r3);
+            legal |= changed != 0u ? 4u : 0u;
+        }
+        {  // 3 = down: rows, last row is the wall
+            uint32_t a = bd.r3, b = bd.r2, c = bd.r1, d = bd.r0;
+            rewards.w = (int32_t)slide_merge_planes(a, b, c, d, changed);
+            after[3] = Board{d, c, b, a};
+            legal |= changed != 0u ? 8u : 0u;
+        }
+        uint32_t counts = 0u;
+#pragma unroll
+        for (uint32_t act = 0; act < 4u; ++act) {
+            const bool is_legal = ((legal >> act) & 1u) != 0u;
+            const uint32_t empt = is_legal ? empty_mask(after[act]) : 0u;  // a legal move always leaves an empty cell
+            const uint32_t n_empty = ENV2048_POPC(empt);
+            const float cells = (float)(n_empty ? n_empty : 1u);
+            strip[4u * lane + act] = PlyAfter{after[act].r0, after[act].r1, after[act].r2, after[act].r3, empt, n_empty, 0.9f / cells, 0.1f / cells};
+            counts |= (2u * n_empty) << (8u * act);
+        }
+        if (after_reward) reinterpret_cast<int4 *>(after_reward)[mine] = rewards;
+        if (legal_out) legal_out[mine] = (uint8_t)legal;
+        if (succ_count) reinterpret_cast<uint32_t *>(succ_count)[mine] = counts;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the strip is wave-private: LDS ops of a wave are ordered
+    __builtin_amdgcn_wave_barrier();
+
+    // phase 2: 128 successor slots per board, 64 per iteration
+    const uint32_t boards_here = (uint32_t)min((uint64_t)64, n - board0);
+    const uint32_t slot = lane & 31u, k = slot >> 1;
+    const bool four = (slot & 1u) != 0u;
+    uint4 *out_b = reinterpret_cast<uint4 *>(succ_boards) + board0 * 128u + lane;
+    float *out_p = succ_prob + board0 * 128u + lane;
+    uint8_t *out_s = succ_status ? succ_status + board0 * 128u + lane : nullptr;
+    for (uint32_t it = 0; it < 2u * boards_here; ++it) {
+        const PlyAfter a = strip[4u * (it >> 1) + 2u * (it & 1u) + (lane >> 5)];
+        Board bd{0u, 0u, 0u, 0u};
+        float prob = 0.0f;
+        uint32_t status = 0u;
+        if (k < a.n_empty) {
+            bd = Board{a.r0, a.r1, a.r2, a.r3};
+            place_tile(bd, kth_empty(a.empties, k), four);
+            prob = four ? a.p4 : a.p2;
+            if (out_s) {
+                const uint32_t legal = legal_mask(bd);
+                status = legal | (legal == 0u ? 16u : 0u);  // a non-empty board is terminal iff no action is legal
+            }
+        }
+        out_b[64u * it] = make_uint4(bd.r0, bd.r1, bd.r2, bd.r3);
+        out_p[64u * it] = prob;
+        if (out_s) out_s[64u * it] = (uint8_t)status;
+    }
+}
+
 __global__ __launch_bounds__(BLOCK) void spawn_kernel(uint64_t n, uint8_t *boards, const uint8_t *spawn_k,
                                                       const uint8_t *spawn_e, uint8_t *placed)
 {
@@ -1634,6 +1741,23 @@ int env2048_chance_outcomes(int device, void *stream, uint64_t n, const uint8_t 
     hipLaunchKernelGGL(chance_outcomes_kernel, grid_for(32 * n), dim3(BLOCK), 0, (hipStream_t)stream, n, boards, out_boards,
                        out_prob, out_count);
     return launched("env2048_chance_outcomes launch");
+}
+
+int env2048_expectimax_ply(int device, void *stream, uint64_t n, const uint8_t *boards, uint8_t *succ_boards, float *succ_prob,
+                           uint8_t *succ_status, uint8_t *succ_count, int32_t *after_reward, uint8_t *legal)
+{
+    if (n == 0) return ENV2048_OK;
+    if (!boards || !succ_boards || !succ_prob)
+        return fail(ENV2048_ERR_INVALID_ARG, "env2048_expectimax_ply: boards, succ_boards and succ_prob are required");
+    if (misaligned(boards, 16) || misaligned(succ_boards, 16) || misaligned(succ_prob, 4) || misaligned(after_reward, 16) ||
+        misaligned(succ_count, 4))
+        return fail(ENV2048_ERR_ALIGNMENT, "env2048_expectimax_ply: boards / succ_boards / after_reward must be 16-byte, succ_prob / succ_count 4-byte aligned");
+    if (int rc = check_count(128 * n)) return rc;
+    DeviceScope scope(device);
+    if (scope.rc) return scope.rc;
+    hipLaunchKernelGGL(expectimax_ply_kernel, dim3((unsigned)((n + PLY_BLOCK - 1) / PLY_BLOCK)), dim3(PLY_BLOCK), 0, (hipStream_t)stream, n,
+                       boards, succ_boards, succ_prob, succ_status, succ_count, after_reward, legal);
+    return launched("env2048_expectimax_ply launch");
 }
 
 int env2048_encode_onehot(int device, void *stream, uint64_t n, const uint8_t *boards, uint32_t width, uint8_t *out)

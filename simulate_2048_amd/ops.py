@@ -122,6 +122,26 @@ def chance_outcomes(boards: torch.Tensor, rt=None):
     return out, prob, count
 
 
+def expectimax_ply(boards: torch.Tensor, *, want_status: bool = True, rt=None) -> dict:
+    """One fused expectimax ply: every board's 4 x 32 successor slots (env2048_expectimax_ply).
+    -> dict(boards (n,4,32,16) u8, prob (n,4,32) f32, count (n,4) u8, reward (n,4) i32, legal (n,) u8[, status (n,4,32) u8])."""
+    rt = rt or runtime.current()
+    n = boards.shape[0]
+    out = {
+        'boards': torch.empty((n, 4, 32, 16), dtype=torch.uint8, device=rt.device),
+        'prob': torch.empty((n, 4, 32), dtype=torch.float32, device=rt.device),
+        'count': torch.empty((n, 4), dtype=torch.uint8, device=rt.device),
+        'reward': torch.empty((n, 4), dtype=torch.int32, device=rt.device),
+        'legal': torch.empty((n,), dtype=torch.uint8, device=rt.device),
+    }
+    if want_status:
+        out['status'] = torch.empty((n, 4, 32), dtype=torch.uint8, device=rt.device)
+    dev, stream = rt.handles()
+    rt.lib.expectimax_ply(dev, stream, n, _p(boards), _p(out['boards']), _p(out['prob']), _p(out.get('status')), _p(out['count']),
+                          _p(out['reward']), _p(out['legal']))
+    return out
+
+
 def onehot(boards: torch.Tensor, width: int = 31, rt=None) -> torch.Tensor:
     rt = rt or runtime.current()
     n = boards.shape[0]

@@ -253,6 +253,16 @@ class OracleLibrary:
         if out_count is not None:
             _view(out_count, n, np.uint8)[:] = res['count']
 
+    def expectimax_ply(self, device, stream, n, boards, succ_boards, succ_prob, succ_status, succ_count, after_reward, legal):
+        self.calls.append(('expectimax_ply', n))
+        res = oracle.expectimax_ply(_view(boards, n * 16, np.uint8).reshape(n, 16).copy())
+        _view(succ_boards, n * 128 * 16, np.uint8)[:] = res['boards'].reshape(-1)
+        _view(succ_prob, n * 128, np.float32)[:] = res['prob'].reshape(-1)
+        for ptr, key, count, dtype in ((succ_status, 'status', 128, np.uint8), (succ_count, 'count', 4, np.uint8),
+                                       (after_reward, 'reward', 4, np.int32), (legal, 'legal', 1, np.uint8)):
+            if ptr is not None:
+                _view(ptr, n * count, dtype)[:] = res[key].reshape(-1)
+
     def encode_onehot(self, device, stream, n, boards, width, out):
         self.calls.append(('encode_onehot', n))
         res = oracle.encode_onehot(_view(boards, n * 16, np.uint8).reshape(n, 16).copy(), width)

@@ -509,6 +509,58 @@ def test_chance_outcomes_vs_reference_after_state(lib, golden):
     np.testing.assert_allclose(prob.cpu().numpy().astype(np.float64), g['prob'], rtol=2.4e-7, atol=0.0)
 
 
+def test_expectimax_ply_matches_oracle_and_the_unfused_chain(lib, golden):
+    """env2048_expectimax_ply == oracle, == env2048_afterstates4 -> env2048_chance_outcomes -> env2048_status composed by hand,
+    and its afterstate scores == the reference's latent_state scores (golden); ragged sizes around the 64-board wave tile."""
+    all_boards = np.concatenate([golden['afterstates']['boards'], golden['chance_outcomes']['boards']])
+    for n in (1, 63, 64, 65, 257, all_boards.shape[0]):
+        boards = all_boards[:n]
+        b = cu(boards)
+        sb = torch.full((n, 4, 32, 16), 99, dtype=torch.uint8, device='cuda')
+        sp = torch.full((n, 4, 32), -1.0, dtype=torch.float32, device='cuda')
+        ss = torch.full((n, 4, 32), 99, dtype=torch.uint8, device='cuda')
+        sc = torch.full((n, 4), 99, dtype=torch.uint8, device='cuda')
+        ar = torch.full((n, 4), -1, dtype=torch.int32, device='cuda')
+        lg = torch.full((n,), 99, dtype=torch.uint8, device='cuda')
+        lib.expectimax_ply(DEV, stream(), n, p(b), p(sb), p(sp), p(ss), p(sc), p(ar), p(lg))
+        torch.cuda.synchronize()
+        ref = oracle.expectimax_ply(boards)
+        for got, key in ((sb, 'boards'), (sp, 'prob'), (ss, 'status'), (sc, 'count'), (ar, 'reward'), (lg, 'legal')):
+            np.testing.assert_array_equal(got.cpu().numpy(), ref[key], err_msg=f'{key} n={n}')
+        np.testing.assert_array_equal(b.cpu().numpy(), boards)  # input untouched
+        # optional outputs left out
+        sb2 = torch.zeros_like(sb)
+        sp2 = torch.zeros_like(sp)
+        lib.expectimax_ply(DEV, stream(), n, p(b), p(sb2), p(sp2), None, None, None, None)
+        torch.cuda.synchronize()
+        assert torch.equal(sb2, sb) and torch.equal(sp2, sp)
+    # the unfused chain on the GPU
+    n = all_boards.shape[0]
+    a4 = torch.zeros((n, 4, 16), dtype=torch.uint8, device='cuda')
+    r4 = torch.zeros((n, 4), dtype=torch.int32, device='cuda')
+    l4 = torch.zeros((n,), dtype=torch.uint8, device='cuda')
+    lib.afterstates4(DEV, stream(), n, p(b), p(a4), p(r4), p(l4))
+    ob = torch.zeros((4 * n, 32, 16), dtype=torch.uint8, device='cuda')
+    op = torch.zeros((4 * n, 32), dtype=torch.float32, device='cuda')
+    lib.chance_outcomes(DEV, stream(), 4 * n, p(a4), p(ob), p(op), None)
+    st_legal = torch.zeros((4 * n * 32,), dtype=torch.uint8, device='cuda')
+    st_done = torch.zeros((4 * n * 32,), dtype=torch.uint8, device='cuda')
+    lib.status(DEV, stream(), 4 * n * 32, p(ob), p(st_done), p(st_legal), None, None, None)
+    torch.cuda.synchronize()
+    is_legal = ((l4[:, None] >> torch.arange(4, device='cuda', dtype=torch.uint8)) & 1).bool()  # (n, 4)
+    mask = is_legal[:, :, None]
+    assert torch.equal(torch.where(mask[..., None], ob.reshape(n, 4, 32, 16), torch.zeros_like(sb)), sb)
+    assert torch.equal(torch.where(mask, op.reshape(n, 4, 32), torch.zeros_like(sp)), sp)
+    used = sp > 0
+    chain_status = (st_legal | (st_done << 4)).reshape(n, 4, 32)
+    assert torch.equal(torch.where(used, chain_status, torch.zeros_like(ss)), ss)
+    assert torch.equal(r4, ar) and torch.equal(l4, lg)
+    m = golden['afterstates']['boards'].shape[0]
+    np.testing.assert_array_equal(ar.cpu().numpy()[:m], golden['afterstates']['reward'])  # the reference's own scores
+    sums = sp.sum(dim=2)
+    assert torch.allclose(sums[is_legal], torch.ones_like(sums[is_legal]), atol=1e-6) and bool((sums[~is_legal] == 0).all())
+
+
 def test_spawn_random_and_onehot_match_oracle(lib, golden):
     boards = golden['afterstates']['boards']
     n = boards.shape[0]

@@ -305,3 +305,19 @@ def test_unseeded_reset_then_step_draw_independent_words():
             idx = np.flatnonzero(flat)
             same += int(rank in (idx[1] - 1, idx[0]) and b[tuple(new_cell)] in a)
         assert same < trials * 0.5  # before the fix: 100 %
+
+
+def test_expectimax_ply_wrapper(golden):
+    """ops.expectimax_ply through the stand-in: shapes, optional status, agreement with the separate wrappers."""
+    from simulate_2048_amd import ops, runtime
+
+    boards = torch.from_numpy(golden['afterstates']['boards'][:200].copy())
+    with runtime.use(OracleLibrary(), 'cpu'):
+        ply = ops.expectimax_ply(boards)
+        lean = ops.expectimax_ply(boards, want_status=False)
+        after, reward, legal = ops.afterstates4(boards)
+    assert tuple(ply['boards'].shape) == (200, 4, 32, 16) and tuple(ply['prob'].shape) == (200, 4, 32) and 'status' not in lean
+    assert torch.equal(ply['reward'], reward) and torch.equal(ply['legal'], legal) and torch.equal(lean['boards'], ply['boards'])
+    np.testing.assert_array_equal(ply['reward'].numpy(), golden['afterstates']['reward'][:200])
+    legal_bits = ((legal[:, None] >> torch.arange(4)) & 1).bool()
+    assert bool(((ply['count'] > 0) == legal_bits).all())
