@@ -234,6 +234,16 @@ def workload_text(n: int) -> str:
 # one rank
 # ------------------------------------------------------------------------------------------------
 def run_rank(args) -> None:
+    # Only the JSON line may reach stdout: libraries print there too (RCCL's version banner on its first collective,
+    # gloo's connection notes), so file descriptor 1 is pointed at stderr for the whole run and the result line is
+    # written to the saved original at the end.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line: str) -> None:
+        os.write(result_fd, (line + '\n').encode())
+
     import torch
 
     from simulate_2048_amd import capi
@@ -254,7 +264,9 @@ def run_rank(args) -> None:
     torch.cuda.set_device(device_index)
     device = torch.device('cuda', device_index)
     dist = None
-    if world > 1:
+    # ENV2048_BENCH_FORCE_DIST=1: initialise the process group even for one rank (started with RANK=0 WORLD_SIZE=1
+    # MASTER_ADDR/PORT set) -- a one-GPU rehearsal of the RCCL barrier / all_reduce / all_gather calls of the N > 1 path
+    if world > 1 or os.environ.get('ENV2048_BENCH_FORCE_DIST') == '1':
         import torch.distributed as dist
 
         if args.dist_backend == 'nccl':
@@ -335,7 +347,7 @@ def run_rank(args) -> None:
         launch_s = 8e-6
         cold = cold_leg(args, torch, lib, capi, device, device_index, h, stream, n, env_base, world, midgame, pool, flags, launch_s)
         if rank == 0:
-            print(json.dumps({'hbm_cold': cold}), flush=True)
+            emit(json.dumps({'hbm_cold': cold}))
         return
     run_steps(W)
     torch.cuda.synchronize()
@@ -441,7 +453,7 @@ def run_rank(args) -> None:
             out['other_configs'] = other
         if boards_midgame is not None:
             out['cpu_baseline'] = cpu_baseline(boards_midgame, args.cpu_seconds)
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -483,6 +495,35 @@ def cold_leg(args, torch, lib, capi, device, device_index, h, stream, n, env_bas
         torch.cuda.synchronize()
         cold_times.append(ev0.elapsed_time(ev1) * 1e-3 / (passes * sets))
     cold_s = statistics.median(cold_times)
+    # the same sets, but even / odd sets on two streams: consecutive launches are independent batches, so the tail of one
+    # launch may overlap the head of the next (what a caller with several independent cold batches would do)
+    side = torch.cuda.Stream(device)
+    even = (capi.StepArgs * ((sets + 1) // 2))()
+    odd = (capi.StepArgs * (sets // 2))()
+
+    def cold_pass_two_streams() -> None:
+        nonlocal cold_step
+        for s in range(sets):
+            rec = capi.StepArgs(n, (world + s) * n + env_base, cb[s].data_ptr(), ca[s].data_ptr(), cr[s].data_ptr(), cd[s].data_ptr(),
+                                None, None, SEED, cold_step, flags | hint, 0)
+            (odd if s & 1 else even)[s >> 1] = rec
+        lib.step_many(device_index, h, even)
+        lib.step_many(device_index, side.cuda_stream, odd)
+        cold_step += 1
+
+    two_times = []
+    for _ in range(3):
+        ev0, ev1, evb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event()
+        ev0.record(stream)
+        side.wait_event(ev0)
+        for _ in range(passes):
+            cold_pass_two_streams()
+        evb.record(side)
+        stream.wait_event(evb)
+        ev1.record(stream)
+        torch.cuda.synchronize()
+        two_times.append(ev0.elapsed_time(ev1) * 1e-3 / (passes * sets))
+    two_s = statistics.median(two_times)
     prof = load_step_profile(n, 'cold')
     return {
         'bound': 'hbm',
@@ -495,6 +536,10 @@ def cold_leg(args, torch, lib, capi, device, device_index, h, stream, n, env_bas
         'footprint_bytes': sets * set_bytes,
         'launches_timed': passes * sets,
         'stores': args.cold_stores,
+        'two_streams': {'achieved': ALGO_BYTES_PER_STEP * n / two_s / 1e9, 'frac': ALGO_BYTES_PER_STEP * n / two_s / 1e9 / HBM_PEAK_GBS,
+                        'us_per_launch': two_s * 1e6,
+                        'note': 'even / odd sets on two streams (independent batches may overlap): aggregate bytes / time, not a '
+                                'single-launch duration'},
         'traffic': None if prof is None else prof.get('fabric_bytes_per_launch'),
         'traffic_source': None if prof is None else dict(source=prof.get('source'), stale=prof['stale']),
         'how': f'{sets} disjoint sets of (boards, actions, reward, done) = {sets * set_bytes / 2**20:.0f} MiB > 2 x Infinity Cache, '

@@ -1040,9 +1040,27 @@ __global__ __launch_bounds__(PLY_BLOCK) void expectimax_ply_kernel(uint64_t n, c
                 status = legal | (legal == 0u ? 16u : 0u);  // a non-empty board is terminal iff no action is legal
             }
         }
+        // write-once output streams: write-through (sc1) stores leave nothing dirty in the XCD L2s -- measured 121 vs 151 us
+        // per 2^18 boards (ordinary stores) and 130 us (non-temporal); ENV2048_PLY_STORE=0/1 rebuilds those variants
+#ifndef ENV2048_PLY_STORE
+#define ENV2048_PLY_STORE 2
+#endif
+#if ENV2048_PLY_STORE == 1
+        __builtin_nontemporal_store(bd.r0, &reinterpret_cast<uint32_t *>(out_b + 64u * it)[0]);
+        __builtin_nontemporal_store(bd.r1, &reinterpret_cast<uint32_t *>(out_b + 64u * it)[1]);
+        __builtin_nontemporal_store(bd.r2, &reinterpret_cast<uint32_t *>(out_b + 64u * it)[2]);
+        __builtin_nontemporal_store(bd.r3, &reinterpret_cast<uint32_t *>(out_b + 64u * it)[3]);
+        __builtin_nontemporal_store(prob, out_p + 64u * it);
+        if (out_s) __builtin_nontemporal_store((uint8_t)status, out_s + 64u * it);
+#elif ENV2048_PLY_STORE == 2
+        store_x4_through(out_b + 64u * it, u32x4{bd.r0, bd.r1, bd.r2, bd.r3});
+        store_x1_through(out_p + 64u * it, __float_as_uint(prob));
+        if (out_s) out_s[64u * it] = (uint8_t)status;
+#else
         out_b[64u * it] = make_uint4(bd.r0, bd.r1, bd.r2, bd.r3);
         out_p[64u * it] = prob;
         if (out_s) out_s[64u * it] = (uint8_t)status;
+#endif
     }
 }
 

@@ -36,12 +36,13 @@ def timed(fn, reps=30, warm=5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--boards', type=int, default=1 << 18)
+    ap.add_argument('--lib', default=None, help='experiment build of libenv2048.so to time instead of the product library')
     args = ap.parse_args()
     n = args.boards
     env = BatchedEnv2048(n, 0x2048, device='cuda:0', auto_reset=True)
     env.reset()
     env.rollout(64)
-    lib = capi.library()
+    lib = capi.Library(args.lib) if args.lib else capi.library()
     dev, s = 0, torch.cuda.current_stream().cuda_stream
     p = lambda t: None if t is None else t.data_ptr()
     b = env.boards

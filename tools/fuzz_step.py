@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Randomised differential run of env2048_step against the CPU oracle (GPU box): random batch sizes, global
-index offsets, seeds, flag combinations, output subsets and observation formats.  Not part of the test-suite
+"""Randomised differential run of env2048_step / env2048_step_many against the CPU oracle (GPU box): random batch sizes,
+global index offsets, seeds, flag combinations (auto-reset, on-device actions, store-policy hints, log-normalised
+reward), output subsets (reward, legal, obs, max_exp) and observation formats.  Not part of the test-suite
 (the deterministic cases live in tests/test_hip_parity.py); run it after kernel changes:
     python tools/fuzz_step.py [seconds]"""
 import sys
@@ -36,22 +37,36 @@ while time.time() - t0 < budget:
     want_legal, want_obs, want_reward = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
     obs_flag, obs_dtype = OBS[int(rng.integers(0, 3))] if want_obs else OBS[0]
     acts = None if flags & capi.FLAG_RANDOM_ACTIONS else actions
-    ref = oracle.step_batch(boards, acts, seed, step, env_base=env_base, flags=flags, want_legal=True, want_obs=True, threads=8)
+    want_max, norm = bool(rng.integers(0, 2)), bool(rng.integers(0, 4) == 0) and want_reward
+    hint = int(rng.choice([0, 0, capi.FLAG_STORES_WRITE_THROUGH, capi.FLAG_STORES_WRITE_BACK]))
+    ref = oracle.step_batch_ex(boards, acts, seed, step, env_base=env_base, flags=flags)
     b = torch.as_tensor(boards).cuda()
     a = None if acts is None else torch.as_tensor(acts).cuda()
-    reward = torch.full((n,), -7, dtype=torch.int32, device='cuda') if want_reward else None
+    reward = torch.full((n,), -7, dtype=torch.float32 if norm else torch.int32, device='cuda') if want_reward else None
+    max_exp = torch.full((n,), 99, dtype=torch.uint8, device='cuda') if want_max else None
     done = torch.full((n,), 9, dtype=torch.uint8, device='cuda')
     legal = torch.full((n,), 99, dtype=torch.uint8, device='cuda') if want_legal else None
     obs = torch.full((n, 16), -1.0, dtype=obs_dtype, device='cuda') if want_obs else None
     p = lambda t: None if t is None else t.data_ptr()
-    lib.step(0, torch.cuda.current_stream().cuda_stream, n, env_base, p(b), p(a), p(reward), p(done), p(legal), p(obs), seed, step,
-             flags | obs_flag)
+    all_flags = flags | obs_flag | hint | (capi.FLAG_REWARD_LOG2_F32 if norm else 0)
+    if want_max or rng.integers(0, 2):
+        rec = (capi.StepArgs * 1)(capi.StepArgs(n, env_base, p(b), p(a), p(reward), p(done), p(legal), p(obs), seed, step, all_flags, 0, p(max_exp)))
+        lib.step_many(0, torch.cuda.current_stream().cuda_stream, rec)
+    else:
+        lib.step(0, torch.cuda.current_stream().cuda_stream, n, env_base, p(b), p(a), p(reward), p(done), p(legal), p(obs), seed, step,
+                 all_flags)
     torch.cuda.synchronize()
     tag = f'n={n} env_base={env_base} seed={seed} step={step} flags={flags} obs={obs_dtype} legal={want_legal} reward={want_reward}'
     np.testing.assert_array_equal(b.cpu().numpy(), ref['boards'], err_msg=tag)
     np.testing.assert_array_equal(done.cpu().numpy(), ref['done'], err_msg=tag)
-    if want_reward:
+    tag += f' max_exp={want_max} norm={norm} hint={hint}'
+    if want_reward and norm:
+        got, want = reward.cpu().numpy(), ref['reward_norm']
+        assert np.all(np.abs(got - want) <= np.spacing(np.maximum(want, np.float32(1e-30)))), tag
+    elif want_reward:
         np.testing.assert_array_equal(reward.cpu().numpy(), ref['reward'], err_msg=tag)
+    if want_max:
+        np.testing.assert_array_equal(max_exp.cpu().numpy(), ref['max_exp'], err_msg=tag)
     if want_legal:
         np.testing.assert_array_equal(legal.cpu().numpy(), ref['legal'], err_msg=tag)
     if want_obs:
