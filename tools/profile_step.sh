@@ -33,3 +33,5 @@ python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
 echo "bench default rc=$?"
 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_driver_shape.json 2> $O/bench_driver_shape.err
 echo "bench driver-shape rc=$?"
+python3 tools/summarize_profiles.py $TAG ${2:-$(basename $TAG)} $O/summary > $O/summary.log 2>&1 && rm -rf $O/pmc_*/ $O/stats_*/
+echo "summary rc=$?"

@@ -4,7 +4,9 @@
     profiles/<label>_pmc_summary.json                   counter means per launch of step_kernel<false, false>, both legs
     profiles/<label>_bench.json, _bench_driver_shape.json
     profiles/step_pmc.json                              what bench.py reads (keyed by leg:boards, stamped with the kernel-source hash)
-usage: tools/summarize_profiles.py <gpurun_out tag> <label>"""
+usage: tools/summarize_profiles.py <gpurun_out tag> <label> [<destination dir, default profiles/>]
+tools/profile_step.sh runs this ON the GPU box with destination gpurun_out/<tag>/summary and then deletes the raw
+per-dispatch CSVs (tens of MB), so only the summaries travel back; copy them into profiles/ to commit them."""
 import csv
 import glob
 import json
@@ -42,10 +44,10 @@ def kernel_avg_us(stats_csv: Path):
     return None
 
 
-def main(tag, label):
+def main(tag, label, dest=None):
     src = REPO / 'gpurun_out' / tag
-    dst = REPO / 'profiles'
-    dst.mkdir(exist_ok=True)
+    dst = Path(dest) if dest else REPO / 'profiles'
+    dst.mkdir(parents=True, exist_ok=True)
     summary = {'kernel': KERNEL, 'boards_per_launch': BOARDS, 'kernel_source_sha': bench.kernel_source_sha(),
                'algorithmic_bytes_per_launch': 38 * BOARDS, 'legs': {}}
     table_path = dst / 'step_pmc.json'
@@ -84,4 +86,4 @@ def main(tag, label):
 
 
 if __name__ == '__main__':
-    main(sys.argv[1], sys.argv[2])
+    main(*sys.argv[1:4])
