@@ -622,6 +622,24 @@ def other_configs(torch, lib, device, device_index, h) -> dict:
         torch.cuda.synchronize()
         roll_times.append((time.perf_counter() - t0, ev0.elapsed_time(ev1) * 1e-3))
     wall_roll, ev_roll = sorted(roll_times)[1]
+    # the same 512 moves with PRE-STAGED host actions in one launch (env2048_replay): uniform random action rows
+    gen = torch.Generator(device='cpu').manual_seed(11)
+    rows = torch.randint(0, 4, (T, n4), generator=gen, dtype=torch.uint8).to(device)
+    rr = torch.zeros((T, n4), dtype=torch.int32, device=device)
+    dd = torch.zeros((T, n4), dtype=torch.uint8, device=device)
+    replay_times = []
+    for rep in range(3):
+        b.boards.copy_(start)
+        b.step_index = 0
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        ev0.record(stream)
+        b.replay(rows, out_reward=rr, out_done=dd)
+        ev1.record(stream)
+        torch.cuda.synchronize()
+        replay_times.append(ev0.elapsed_time(ev1) * 1e-3)
+    ev_replay = sorted(replay_times)[1]
+    del rows, rr, dd
     sum_roll = int(stats['return_sum'].sum())
     eps_roll = int(stats['episodes'].sum(dtype=torch.int64))
     valid_roll = int(stats['valid_moves'].sum(dtype=torch.int64))
@@ -632,6 +650,9 @@ def other_configs(torch, lib, device, device_index, h) -> dict:
                                  'us_per_step_event': ev_steps / T * 1e6, 'records': 'reward and done rows [512, 2^20] written in HBM'},
         'as_one_rollout_kernel': {'value': n4 * T / wall_roll, 'unit': 'board-steps/s', 'ms_total_wall': wall_roll * 1e3,
                                   'ms_total_event': ev_roll * 1e3, 'bound': 'VALU issue (boards stay in registers: 44 B per env per 512 steps)'},
+        'as_one_replay_kernel_host_actions': {'value': n4 * T / ev_replay, 'unit': 'board-steps/s', 'ms_total_event': ev_replay * 1e3,
+                                              'note': 'env2048_replay: staged uint8 action rows in, reward + done rows [512, 2^20] out, '
+                                                      '6 B per board-step (different actions than the two legs above)'},
         'cross_check': {'boards_identical': same_boards, 'reward_sum': [sum_steps, sum_roll], 'episodes': [eps_steps, eps_roll],
                         'ok': same_boards and sum_steps == sum_roll and eps_steps == eps_roll},
         'statistics': {'mean_episode_length': n4 * T / max(eps_roll, 1), 'invalid_move_fraction': 1.0 - valid_roll / (n4 * T),

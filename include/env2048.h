@@ -234,6 +234,21 @@ ENV2048_EXPORT int env2048_rollout(int device, void *stream, uint64_t n, uint64_
                     uint32_t flags);
 
 /*
+ * T consecutive transitions with PRE-STAGED actions in one launch, boards held in registers: actions, reward and done
+ * are [T, row_stride] row arrays and the result is identical to
+ *     env2048_step_sequence(device, stream, n, env_base, boards, {actions + t*row_stride}, reward, done, NULL, NULL,
+ *                           row_stride, seed, step0, T, flags)
+ * (reward / done may be NULL; flags: AUTO_RESET only).  Per board-step it moves 6 bytes (action in, reward + done out)
+ * instead of the 38 of a step launch and pays no launch: for replaying recorded games, verifying stored trajectories and
+ * scoring open-loop action sequences against the true environment.  return_sum / episodes / valid_moves as in
+ * env2048_rollout (each may be NULL).
+ * [replaces: the env.step calls of the move loop, reinforce/training/self_play.py:314-368, when the actions are known]
+ */
+ENV2048_EXPORT int env2048_replay(int device, void *stream, uint64_t n, uint64_t env_base, uint8_t *boards, const uint8_t *actions,
+                                  int32_t *reward, uint8_t *done, uint64_t row_stride, uint64_t seed, uint64_t step0, uint32_t T,
+                                  uint32_t flags, int64_t *return_sum, uint32_t *episodes, uint32_t *valid_moves);
+
+/*
  * The same rollout reporting per-EPISODE statistics, accumulated on device -- what evaluate_games computes from a list
  * of trajectories (reinforce/training/self_play.py:503-521: mean/std/min/max of the total reward, mean and max of the
  * max tile, mean length, "reached 2048/4096/..." counts) for millions of games without moving a trajectory.

@@ -193,6 +193,27 @@ class BatchedEnv2048:
         self.step_index += int(num_steps)
         return {'return_sum': ret, 'episodes': eps, 'valid_moves': moves}
 
+    def replay(self, actions: torch.Tensor, *, out_reward: torch.Tensor | None = None, out_done: torch.Tensor | None = None):
+        """``actions`` (T, N) uint8 pre-staged moves played in ONE kernel (env2048_replay), boards held in registers:
+        the same boards, rewards and done flags as T ``step(actions[t])`` calls.  ``out_reward`` (T, N) int32 /
+        ``out_done`` (T, N) uint8 receive the per-step rows.  Returns dict(return_sum, episodes, valid_moves)."""
+        if actions.dtype != torch.uint8 or actions.dim() != 2 or actions.shape[1] != self.num_envs or not actions.is_contiguous() \
+                or actions.device != self.boards.device:
+            raise ValueError(f'actions must be a contiguous uint8 (T, {self.num_envs}) tensor on {self.boards.device}')
+        T, n = int(actions.shape[0]), self.num_envs
+        if out_reward is not None:
+            self._check_out(out_reward, torch.int32, (T, n))
+        if out_done is not None:
+            self._check_out(out_done, torch.uint8, (T, n))
+        ret = torch.zeros((n,), dtype=torch.int64, device=self.device)
+        eps = torch.zeros((n,), dtype=torch.int32, device=self.device)
+        moves = torch.zeros((n,), dtype=torch.int32, device=self.device)
+        dev, stream = _stream_handle(self.device)
+        self.lib.replay(dev, stream, n, self.env_base, _p(self.boards), _p(actions), _p(out_reward), _p(out_done), n, self.seed,
+                        self.step_index, T, capi.FLAG_AUTO_RESET if self.auto_reset else 0, _p(ret), _p(eps), _p(moves))
+        self.step_index += T
+        return {'return_sum': ret, 'episodes': eps, 'valid_moves': moves}
+
     def rollout_episodes(self, num_steps: int, stats: torch.Tensor | None = None) -> torch.Tensor:
         """``num_steps`` random-action transitions in one kernel, with per-EPISODE statistics accumulated on device
         (env2048_rollout_episodes): returns the 40-word uint64 block as an int64 tensor (see ``episode_statistics``).

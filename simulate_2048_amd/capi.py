@@ -75,6 +75,7 @@ PROTOTYPES = {
     'env2048_reset_keyed_i32': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr]),
     'env2048_status_i32': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr]),
     'env2048_rollout': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _u64, _u64, _u32, _ptr, _ptr, _ptr, _u32]),
+    'env2048_replay': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _ptr, _ptr, _ptr, _u64, _u64, _u64, _u32, _u32, _ptr, _ptr, _ptr]),
     'env2048_rollout_episodes': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _u64, _u64, _u32, _u32, _ptr, _ptr, _ptr]),
     'env2048_count_episodes': (_c_int, [_c_int, _ptr, _u64, _u64, _u32, _u32, _u32, _ptr, _u32, _ptr]),
     'env2048_segment_episodes': (_c_int, [_c_int, _ptr, _u64, _u64, _u32, _u32, _u32, _ptr, _ptr, _ptr, _u32, _ptr, _ptr, _ptr]),
@@ -184,6 +185,11 @@ class Library:
                 flags) -> None:
         self._check(self._dll.env2048_rollout(device, stream, n, env_base, boards, seed, step0, T, return_sum,
                                               episodes, valid_moves, flags))
+
+    def replay(self, device, stream, n, env_base, boards, actions, reward, done, row_stride, seed, step0, T, flags, return_sum,
+               episodes, valid_moves) -> None:
+        self._check(self._dll.env2048_replay(device, stream, n, env_base, boards, actions, reward, done, row_stride, seed, step0, T,
+                                             flags, return_sum, episodes, valid_moves))
 
     def rollout_episodes(self, device, stream, n, env_base, boards, seed, step0, T, flags, ep_length, ep_return, stats) -> None:
         self._check(self._dll.env2048_rollout_episodes(device, stream, n, env_base, boards, seed, step0, T, flags, ep_length,

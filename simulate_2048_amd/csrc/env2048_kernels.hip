@@ -556,6 +556,11 @@ struct RolloutArgs {
     uint32_t *ep_length;
     int64_t *ep_return;
     unsigned long long *stats;
+    // REPLAY only: pre-staged action rows (read) and per-step reward / done rows (written), all [T, row_stride]
+    const uint8_t *action_rows;
+    int32_t *reward_rows;
+    uint8_t *done_rows;
+    uint64_t row_stride;
 };
 
 // T steps with the boards resident in registers; same tile layout and RNG words as step_kernel.
@@ -563,7 +568,11 @@ struct RolloutArgs {
 // the running length/return of its four games; a finished game (rare: 0.7 % of steps) updates block-wide accumulators in
 // LDS (count, sums, sums of squares, min/max return, histogram of the final max tile), which the block adds to the
 // caller's 40-word block with one global atomic per word when it retires.
-template <bool STATS>
+// REPLAY: the action of step t comes from row t of a pre-staged [T, row_stride] byte array instead of the step word, and
+// reward / done of every step are written as rows (6 B per board-step instead of the 38 B of a step launch): T
+// env2048_step calls with staged actions in ONE launch, boards in registers.  Row t+1's action bytes are requested
+// before step t is computed, so their latency hides behind a whole step of arithmetic.
+template <bool STATS, bool REPLAY = false>
 __global__ __launch_bounds__(BLOCK) void rollout_kernel(RolloutArgs a)
 {
     __shared__ uint4 dir_lds[8];
@@ -602,8 +611,22 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(RolloutArgs a)
         cur_len[j] = (STATS && valid[j] && a.ep_length) ? a.ep_length[i] : 0u;
         cur_ret[j] = (STATS && valid[j] && a.ep_return) ? (unsigned long long)a.ep_return[i] : 0ull;
     }
+    uint32_t next_act[BOARDS_PER_LANE];
+    if (REPLAY) {
+#pragma unroll
+        for (int j = 0; j < BOARDS_PER_LANE; ++j) next_act[j] = (valid[j] && a.T) ? a.action_rows[tile0 + 64u * j + lane] : 0u;
+    }
 
     for (uint32_t t = 0; t < a.T; ++t) {
+        uint32_t act[BOARDS_PER_LANE];
+        if (REPLAY) {
+            const bool more = t + 1u < a.T;  // uniform
+#pragma unroll
+            for (int j = 0; j < BOARDS_PER_LANE; ++j) {
+                act[j] = next_act[j];
+                if (more && valid[j]) next_act[j] = a.action_rows[(uint64_t)(t + 1u) * a.row_stride + tile0 + 64u * j + lane];
+            }
+        }
         const uint64_t step = a.step0 + t;
         const RngKey key{a.seed_lo, a.seed_hi, (uint32_t)step, (uint32_t)(step >> 32)};
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // last step's strip reads precede this rewrite
@@ -615,11 +638,16 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(RolloutArgs a)
             const uint32_t word = strip[strip_off + 64u * j + lane];
             uint32_t reward;
             bool changed, done;
-            transition(bd[j], load_selectors(dir_lds, word & 3u), word, reward, changed, done);
+            transition(bd[j], load_selectors(dir_lds, (REPLAY ? act[j] : word) & 3u), word, reward, changed, done);
             ret[j] += reward;
             eps[j] += done ? 1u : 0u;
             moves[j] += changed ? 1u : 0u;
             pending |= (done ? 1u : 0u) << j;
+            if (REPLAY && valid[j]) {
+                const uint64_t at = (uint64_t)t * a.row_stride + tile0 + 64u * j + lane;
+                if (a.reward_rows) __builtin_nontemporal_store((int32_t)reward, &a.reward_rows[at]);
+                if (a.done_rows) __builtin_nontemporal_store((uint8_t)(done ? 1 : 0), &a.done_rows[at]);
+            }
             if (STATS) {
                 cur_len[j] += 1u;
                 cur_ret[j] += reward;
@@ -1656,9 +1684,33 @@ int env2048_rollout(int device, void *stream, uint64_t n, uint64_t env_base, uin
     DeviceScope scope(device);
     if (scope.rc) return scope.rc;
     RolloutArgs a{n, env_base, boards, return_sum, episodes, valid_moves, (uint32_t)seed, (uint32_t)(seed >> 32),
-                  step0, T, flags, nullptr, nullptr, nullptr};
+                  step0, T, flags, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     hipLaunchKernelGGL(rollout_kernel<false>, tile_grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, a);
     return launched("env2048_rollout launch");
+}
+
+int env2048_replay(int device, void *stream, uint64_t n, uint64_t env_base, uint8_t *boards, const uint8_t *actions, int32_t *reward,
+                   uint8_t *done, uint64_t row_stride, uint64_t seed, uint64_t step0, uint32_t T, uint32_t flags,
+                   int64_t *return_sum, uint32_t *episodes, uint32_t *valid_moves)
+{
+    if (n == 0 || T == 0) return ENV2048_OK;
+    if (flags & ~ENV2048_FLAG_AUTO_RESET) return fail(ENV2048_ERR_INVALID_ARG, "env2048_replay: unknown flag bits 0x%x", flags);
+    if (!boards || !actions) return fail(ENV2048_ERR_INVALID_ARG, "env2048_replay: boards and actions are required");
+    if (row_stride < n)
+        return fail(ENV2048_ERR_INVALID_ARG, "env2048_replay: row_stride %llu is smaller than n = %llu", (unsigned long long)row_stride,
+                    (unsigned long long)n);
+    if (misaligned(boards, 16)) return fail(ENV2048_ERR_ALIGNMENT, "env2048_replay: boards must be 16-byte aligned");
+    if (misaligned(reward, 4) || misaligned(return_sum, 8) || misaligned(episodes, 4) || misaligned(valid_moves, 4))
+        return fail(ENV2048_ERR_ALIGNMENT, "env2048_replay: misaligned output array");
+    if (step0 + T < step0) return fail(ENV2048_ERR_RANGE, "env2048_replay: step0 + T overflows");
+    if (int rc = check_range(n, env_base)) return rc;
+    if (int rc = check_count(n)) return rc;
+    DeviceScope scope(device);
+    if (scope.rc) return scope.rc;
+    RolloutArgs a{n, env_base, boards, return_sum, episodes, valid_moves, (uint32_t)seed, (uint32_t)(seed >> 32), step0, T, flags,
+                  nullptr, nullptr, nullptr, actions, reward, done, row_stride};
+    hipLaunchKernelGGL((rollout_kernel<false, true>), tile_grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, a);
+    return launched("env2048_replay launch");
 }
 
 int env2048_rollout_episodes(int device, void *stream, uint64_t n, uint64_t env_base, uint8_t *boards, uint64_t seed, uint64_t step0,
@@ -1677,7 +1729,7 @@ int env2048_rollout_episodes(int device, void *stream, uint64_t n, uint64_t env_
     DeviceScope scope(device);
     if (scope.rc) return scope.rc;
     RolloutArgs a{n, env_base, boards, nullptr, nullptr, nullptr, (uint32_t)seed, (uint32_t)(seed >> 32), step0, T, flags,
-                  ep_length, ep_return, reinterpret_cast<unsigned long long *>(stats)};
+                  ep_length, ep_return, reinterpret_cast<unsigned long long *>(stats), nullptr, nullptr, nullptr, 0};
     hipLaunchKernelGGL(rollout_kernel<true>, tile_grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, a);
     return launched("env2048_rollout_episodes launch");
 }

@@ -151,6 +151,33 @@ class OracleLibrary:
         if valid_moves is not None:
             _view(valid_moves, n, np.uint32)[:] = res['valid_moves']
 
+    def replay(self, device, stream, n, env_base, boards, actions, reward, done, row_stride, seed, step0, T, flags, return_sum, episodes,
+               valid_moves):
+        """By definition the sequence of single steps (include/env2048.h): composed from the oracle's step."""
+        self.calls.append(('replay', n))
+        b = _view(boards, n * 16, np.uint8)
+        cur = b.reshape(n, 16).copy()
+        acts = _view(actions, T * row_stride, np.uint8).reshape(T, row_stride)
+        rew = None if reward is None else _view(reward, T * row_stride, np.int32).reshape(T, row_stride)
+        dn = None if done is None else _view(done, T * row_stride, np.uint8).reshape(T, row_stride)
+        ret, eps, moves = np.zeros(n, np.int64), np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+        for t in range(T):
+            before = cur
+            res = oracle.step_batch(cur, acts[t, :n].copy(), seed, step0 + t, env_base=env_base, flags=flags & 1)
+            cur = res['boards']
+            ret += res['reward']
+            eps += res['done']
+            # a move was valid iff a tile was spawned: the afterstate differs from the board
+            moves += oracle.afterstate_batch(before, acts[t, :n].copy())['changed']
+            if rew is not None:
+                rew[t, :n] = res['reward']
+            if dn is not None:
+                dn[t, :n] = res['done']
+        b[:] = cur.reshape(-1)
+        for ptr, val, dtype in ((return_sum, ret, np.int64), (episodes, eps, np.uint32), (valid_moves, moves, np.uint32)):
+            if ptr is not None:
+                _view(ptr, n, dtype)[:] = val
+
     def rollout_episodes(self, device, stream, n, env_base, boards, seed, step0, T, flags, ep_length, ep_return, stats):
         self.calls.append(('rollout_episodes', n))
         b = _view(boards, n * 16, np.uint8)

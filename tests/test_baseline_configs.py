@@ -127,6 +127,32 @@ def test_config_4_rollout_512_equals_512_steps_and_oracle(lib):
     assert 0.13 < invalid < 0.20, invalid
 
 
+def test_replay_at_full_size_equals_step_sequence(lib):
+    """2^20 boards x 64 staged moves: one env2048_replay launch == 64 env2048_step launches (boards and every row)."""
+    n, T = 1 << 20, 64
+    start = midgame(lib, n)
+    gen = torch.Generator(device='cpu').manual_seed(5)
+    actions = torch.randint(0, 4, (T, n), generator=gen, dtype=torch.uint8).cuda()
+    table = (ctypes.c_void_p * T)(*[actions[t].data_ptr() for t in range(T)])
+    b1, b2 = start.clone(), start.clone()
+    r1 = torch.zeros((T, n), dtype=torch.int32, device='cuda')
+    d1 = torch.zeros((T, n), dtype=torch.uint8, device='cuda')
+    r2, d2 = torch.full_like(r1, -1), torch.full_like(d1, 9)
+    lib.step_sequence(DEV, stream(), n, 0, p(b1), table, p(r1), p(d1), None, None, n, SEED, 64, T, AUTO)
+    ret = torch.zeros((n,), dtype=torch.int64, device='cuda')
+    eps = torch.zeros((n,), dtype=torch.int32, device='cuda')
+    lib.replay(DEV, stream(), n, 0, p(b2), p(actions), p(r2), p(d2), n, SEED, 64, T, AUTO, p(ret), p(eps), None)
+    torch.cuda.synchronize()
+    assert torch.equal(b1, b2) and torch.equal(r1, r2) and torch.equal(d1, d2)
+    assert torch.equal(ret, r1.sum(dim=0, dtype=torch.int64)) and torch.equal(eps.long(), d1.long().sum(dim=0))
+    with pytest.raises(capi.Env2048Error) as e:
+        lib.replay(DEV, stream(), n, 0, p(b2), p(actions), None, None, n - 1, SEED, 0, T, AUTO, None, None, None)
+    assert e.value.code == capi.ERR_INVALID_ARG
+    with pytest.raises(capi.Env2048Error) as e:
+        lib.replay(DEV, stream(), n, 0, p(b2), p(actions), None, None, n, SEED, 0, T, RANDOM, None, None, None)  # actions are given
+    assert e.value.code == capi.ERR_INVALID_ARG
+
+
 def test_step_sequence_rows_equal_single_steps(lib):
     """env2048_step_sequence == the same env2048_step calls one by one: every output row, with host action
     tables, row_stride 0 (overwrite) and > n (padded rows), f32 and bf16 observations, a ragged batch."""

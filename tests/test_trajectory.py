@@ -184,6 +184,38 @@ def test_rollout_episode_statistics(make_env):
     assert torch.equal(plain.boards, env.boards)
 
 
+def test_replay_equals_the_same_steps_one_by_one(make_env):
+    """env2048_replay: T pre-staged moves in one launch == T step calls -- boards, reward rows, done rows, per-env sums;
+    ragged batch, odd env_base, with and without auto-reset, optional outputs left out."""
+    n, T, seed = 1500, 37, 13
+    rng = np.random.default_rng(3)
+    for auto_reset in (True, False):
+        a = make_env(n, seed, env_base=5, auto_reset=auto_reset)
+        b = make_env(n, seed, env_base=5, auto_reset=auto_reset)
+        for e in (a, b):
+            e.reset()
+            e.rollout(120)  # late game: games end during the replay
+        actions = torch.from_numpy(rng.integers(0, 4, size=(T, n)).astype(np.uint8)).to(a.device)
+        rew = torch.zeros((T, n), dtype=torch.int32, device=a.device)
+        don = torch.zeros((T, n), dtype=torch.uint8, device=a.device)
+        for t in range(T):
+            a.step(actions[t], out_reward=rew[t], out_done=don[t])
+        rew2 = torch.full((T, n), -1, dtype=torch.int32, device=a.device)
+        don2 = torch.full((T, n), 9, dtype=torch.uint8, device=a.device)
+        out = b.replay(actions, out_reward=rew2, out_done=don2)
+        assert torch.equal(a.boards, b.boards) and torch.equal(rew, rew2) and torch.equal(don, don2)
+        assert a.step_index == b.step_index
+        assert torch.equal(out['return_sum'], rew.sum(dim=0, dtype=torch.int64)) and torch.equal(out['episodes'].long(), don.long().sum(dim=0))
+        assert int(out['valid_moves'].sum()) > 0 and int(don.sum()) > (20 if auto_reset else 5)
+        c = make_env(n, seed, env_base=5, auto_reset=auto_reset)
+        c.reset()
+        c.rollout(120)
+        c.replay(actions)  # no row outputs
+        assert torch.equal(c.boards, a.boards)
+    with pytest.raises(ValueError):
+        b.replay(actions[:, :10].contiguous())
+
+
 def test_episode_entry_points_reject_bad_arguments(make_env):
     env = make_env(8, 1)
     if isinstance(env.lib, OracleLibrary):
