@@ -442,6 +442,7 @@ def run_rank(args) -> None:
                 'wall_us_per_step': {'median': wall / K * 1e6, 'min': min(walls_max) / K * 1e6, 'max': max(walls_max) / K * 1e6},
                 'event_us_per_step': {'median': launch_s * 1e6, 'min': min(events_max) / K * 1e6, 'max': max(events_max) / K * 1e6},
                 'per_rank_us_per_step': [{'rank': r, 'event': v[0], 'wall': v[1]} for r, v in enumerate(per_rank)],
+                'host_enqueue_us_per_launch': statistics.median(enqueue_times) * 1e6,  # rank 0; meaningful while the launch queue has room (small K)
                 'note': 'value = boards x K x ranks / median over blocks of (max over ranks of the block wall time)',
             },
             'roofline': roofline,
@@ -622,6 +623,7 @@ def other_configs(torch, lib, device, device_index, h) -> dict:
         torch.cuda.synchronize()
         roll_times.append((time.perf_counter() - t0, ev0.elapsed_time(ev1) * 1e-3))
     wall_roll, ev_roll = sorted(roll_times)[1]
+    same_boards = bool(torch.equal(a.boards, b.boards))
     # the same 512 moves with PRE-STAGED host actions in one launch (env2048_replay): uniform random action rows
     gen = torch.Generator(device='cpu').manual_seed(11)
     rows = torch.randint(0, 4, (T, n4), generator=gen, dtype=torch.uint8).to(device)
@@ -643,7 +645,6 @@ def other_configs(torch, lib, device, device_index, h) -> dict:
     sum_roll = int(stats['return_sum'].sum())
     eps_roll = int(stats['episodes'].sum(dtype=torch.int64))
     valid_roll = int(stats['valid_moves'].sum(dtype=torch.int64))
-    same_boards = bool(torch.equal(a.boards, b.boards))
     out['configs[4]'] = {
         'workload': '1 048 576 boards x 512-step rollout, Philox tile spawn, on-device uniform random actions, auto-reset on terminal',
         'as_512_step_launches': {'value': n4 * T / wall_steps, 'unit': 'board-steps/s', 'ms_total_wall': wall_steps * 1e3,

@@ -29,9 +29,13 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_WAV
   echo "pmc cold $name done"
 done
 cd $R
-python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
-echo "bench default rc=$?"
-python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_driver_shape.json 2> $O/bench_driver_shape.err
-echo "bench driver-shape rc=$?"
-python3 tools/summarize_profiles.py $TAG ${2:-$(basename $TAG)} $O/summary > $O/summary.log 2>&1 && rm -rf $O/pmc_*/ $O/stats_*/
+LABEL=${2:-$(basename $TAG)}
+# summaries first (then the raw per-dispatch CSVs, tens of MB, are dropped), and the fresh counter table goes where bench.py
+# reads it, so that the bench lines below carry the traffic / VALU counts of THIS kernel build
+python3 tools/summarize_profiles.py $TAG $LABEL $O/summary > $O/summary.log 2>&1 && rm -rf $O/pmc_*/ $O/stats_*/
 echo "summary rc=$?"
+cp $O/summary/step_pmc.json $R/profiles/step_pmc.json
+python3 bench.py > $O/summary/${LABEL}_bench_default.json 2> $O/bench_default.err
+echo "bench default rc=$?"
+python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/summary/${LABEL}_bench_driver_shape.json 2> $O/bench_driver_shape.err
+echo "bench driver-shape rc=$?"

@@ -2,7 +2,7 @@
 """Turn gpurun_out/<tag>/ (written by tools/profile_step.sh) into the committed profiles/ files:
     profiles/<label>_{resident,cold}_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the bench command
     profiles/<label>_pmc_summary.json                   counter means per launch of step_kernel<false, false>, both legs
-    profiles/<label>_bench.json, _bench_driver_shape.json
+    (tools/profile_step.sh adds <label>_bench_default.json / _bench_driver_shape.json next to them)
     profiles/step_pmc.json                              what bench.py reads (keyed by leg:boards, stamped with the kernel-source hash)
 usage: tools/summarize_profiles.py <gpurun_out tag> <label> [<destination dir, default profiles/>]
 tools/profile_step.sh runs this ON the GPU box with destination gpurun_out/<tag>/summary and then deletes the raw
@@ -77,10 +77,6 @@ def main(tag, label, dest=None):
     (dst / f'{label}_pmc_summary.json').write_text(json.dumps(summary, indent=1) + '\n')
     if table['entries']:
         table_path.write_text(json.dumps(table, indent=1) + '\n')
-    for name in ('bench_default', 'bench_driver_shape'):
-        f = src / f'{name}.json'
-        if f.exists() and f.stat().st_size:
-            shutil.copy(f, dst / f'{label}_{name}.json')
     brief = {leg: {k: v for k, v in e.items() if k != 'counters'} for leg, e in summary['legs'].items()}
     print(json.dumps(brief, indent=1))
 
