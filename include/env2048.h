@@ -76,6 +76,12 @@ extern "C" {
  * bits override the size rule (they exclude each other). */
 #define ENV2048_FLAG_STORES_WRITE_THROUGH 16u
 #define ENV2048_FLAG_STORES_WRITE_BACK 32u
+/* env2048_step* only, tuning hints that change no result: the step kernel exists in two tilings -- one board per lane
+ * (short dependent chain, eight times as many workgroups: faster up to 2^18 boards per launch, where latency is the
+ * limit) and four boards per lane (shared Philox blocks, amortised constants: faster above, where instruction issue is
+ * the limit).  By default the launch size decides; these two bits override it (they exclude each other). */
+#define ENV2048_FLAG_TILE_SMALL 128u
+#define ENV2048_FLAG_TILE_LARGE 256u
 /* env2048_step* only: `reward` is an n-float32 array receiving the LOG-NORMALISED reward log2(score) / 16 (0 for a
  * score of 0) -- normalize_reward of the reference (twentyfortyeight/utils/normalize.py:6-33, the `normalize=True`
  * constructor flag, twentyfortyeight/envs/twentyfortyeight.py:80-81) for a whole batch; within 1 ulp (float32) of the

@@ -28,6 +28,8 @@ FLAG_OBS_BF16 = 8
 FLAG_STORES_WRITE_THROUGH = 16
 FLAG_STORES_WRITE_BACK = 32
 FLAG_REWARD_LOG2_F32 = 64
+FLAG_TILE_SMALL = 128
+FLAG_TILE_LARGE = 256
 
 LIB_PATH = Path(__file__).resolve().parent / 'lib' / 'libenv2048.so'
 

@@ -198,10 +198,22 @@ constexpr int WAVES_PER_BLOCK = BLOCK / 64;
 #ifndef ENV2048_BOARDS_PER_LANE
 #define ENV2048_BOARDS_PER_LANE 4
 #endif
-constexpr int BOARDS_PER_LANE = ENV2048_BOARDS_PER_LANE;
-constexpr int TILE_BOARDS = 64 * BOARDS_PER_LANE;                  // per wave
-constexpr int BLOCK_BOARDS = TILE_BOARDS * WAVES_PER_BLOCK;       // per block
-constexpr int WORD_STRIP = TILE_BOARDS + 4 + 4 + TILE_BOARDS / 4;  // 65 Philox blocks (+ pad to 16 B) + a byte per board
+constexpr int BOARDS_PER_LANE = ENV2048_BOARDS_PER_LANE;  // the large-launch tiling (and the rollout kernels')
+// Tile geometry as a function of the boards each lane handles.  The step kernel exists in two tilings: BPL = 4 (one
+// Philox block feeds four boards of a lane's neighbourhood, constants and selector fetches amortise: best from 2^19
+// boards up, where VALU issue is the limit) and BPL = 1 (a wave's dependent chain is one board long and eight times
+// as many CUs get work: 4.2 vs 5.2 us per step at 4 096 ... 262 144 boards, where latency is the limit).
+constexpr int tile_boards(int bpl) { return 64 * bpl; }                                  // per wave
+constexpr int block_boards(int bpl) { return tile_boards(bpl) * WAVES_PER_BLOCK; }       // per block
+constexpr int word_strip(int bpl)                                                        // uint32 words of a wave's LDS strip:
+{                                                                                        // Philox blocks (+1 straddling, padded to
+    return (tile_boards(bpl) + 4 + 4 + tile_boards(bpl) / 4 + 3) / 4 * 4;                // 16 B) + a byte per board, >= 256 words
+}                                                                                        // where the obs transposition uses it
+constexpr int word_strip_words(int bpl) { return word_strip(bpl) < 256 ? 256 : word_strip(bpl); }
+constexpr int TILE_BOARDS = tile_boards(BOARDS_PER_LANE);
+constexpr int BLOCK_BOARDS = block_boards(BOARDS_PER_LANE);
+constexpr int WORD_STRIP = word_strip_words(BOARDS_PER_LANE);
+constexpr uint64_t SMALL_TILING_MAX_BOARDS = 1ull << 18;  // launches up to this size use the BPL = 1 tiling
 
 __constant__ uint32_t DIR_TABLE[32] = {ENV2048_DIR_SELECTOR_VALUES};
 
@@ -230,10 +242,11 @@ __device__ __forceinline__ DirSelectors load_selectors(const uint4 *dir_lds, uin
 
 // Compute the step words of the wave tile starting at global environment env0 into `strip`
 // (strip[k] = word of environment (env0 & ~3) + k).  Every lane of the wave must call this.
+template <int BPL = BOARDS_PER_LANE>
 __device__ __forceinline__ void fill_word_strip(uint32_t *strip, const RngKey &key, uint64_t env0, uint32_t lane)
 {
     const uint64_t group0 = env0 >> 2;
-    constexpr uint32_t GROUPS = TILE_BOARDS / 4;  // Philox blocks an aligned tile needs
+    constexpr uint32_t GROUPS = tile_boards(BPL) / 4;  // Philox blocks an aligned tile needs
     uint32_t w0, w1, w2, w3;
     env_block(key, group0 + lane, STREAM_STEP, w0, w1, w2, w3);
     if (GROUPS == 64u) {
@@ -296,10 +309,11 @@ __device__ __forceinline__ void reset_queued(const StepArgs &a, uint64_t block0,
 // ENV2048_EXP_ABLATE (bit 0 no game logic, bit 1 no Philox, bit 2 no reward/done stores, bit 3 terminal
 // boards queued but not rebuilt) and ENV2048_EXP_STAMPS (five s_memrealtime stamps + HW_ID per wave into
 // the obs buffer) exist for tools/microbench only.
-template <bool EXTRAS, bool FULL, bool RANDOM>
-__device__ __forceinline__ void step_block(const StepArgs &a, uint4 *dir_lds, uint32_t (*word_lds)[WORD_STRIP],
+template <bool EXTRAS, bool FULL, bool RANDOM, int BOARDS_PER_LANE>
+__device__ __forceinline__ void step_block(const StepArgs &a, uint4 *dir_lds, uint32_t (*word_lds)[word_strip_words(BOARDS_PER_LANE)],
                                            uint32_t *queue_state, uint16_t *reset_slot)
 {
+    constexpr int TILE_BOARDS = tile_boards(BOARDS_PER_LANE), BLOCK_BOARDS = block_boards(BOARDS_PER_LANE);
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -340,7 +354,7 @@ __device__ __forceinline__ void step_block(const StepArgs &a, uint4 *dir_lds, ui
 #pragma unroll
     for (int j = 0; j < BOARDS_PER_LANE; ++j) word[j] = (lane * 2654435761u) ^ (a.key.step_lo * 40503u + j);
 #else
-    fill_word_strip(strip, a.key, env0, lane);
+    fill_word_strip<BOARDS_PER_LANE>(strip, a.key, env0, lane);
 #pragma unroll
     for (int j = 0; j < BOARDS_PER_LANE; ++j) word[j] = strip[strip_off + 64u * j + lane];
 #endif
@@ -504,7 +518,7 @@ __device__ __forceinline__ void step_block(const StepArgs &a, uint4 *dir_lds, ui
 // -mllvm -amdgpu-kernarg-preload-count=16; gfx950 has 14 free user SGPRs), so a wave issues its board
 // loads without first waiting for an s_load of the argument block; the output pointers arrive while the
 // Philox blocks are computed.
-template <bool EXTRAS, bool RANDOM>
+template <bool EXTRAS, bool RANDOM, int BPL>
 __global__ __launch_bounds__(BLOCK) void step_kernel(uint8_t *boards, const uint8_t *actions, uint64_t n, uint64_t env_base,
                                                      uint32_t flags, uint32_t seed_lo, uint32_t seed_hi, uint32_t step_lo,
                                                      uint32_t step_hi, int32_t *reward, uint8_t *done, uint8_t *legal, void *obs,
@@ -512,14 +526,14 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(uint8_t *boards, const uint
 {
     const StepArgs a{n, env_base, boards, actions, reward, done, legal, obs, RngKey{seed_lo, seed_hi, step_lo, step_hi}, flags, max_exp};
     __shared__ uint4 dir_lds[8];
-    __shared__ __attribute__((aligned(16))) uint32_t word_lds[WAVES_PER_BLOCK][WORD_STRIP];
+    __shared__ __attribute__((aligned(16))) uint32_t word_lds[WAVES_PER_BLOCK][word_strip_words(BPL)];
     __shared__ uint32_t queue_state;
-    __shared__ uint16_t reset_slot[BLOCK_BOARDS];
-    const uint64_t block0 = (uint64_t)blockIdx.x * BLOCK_BOARDS;
-    if (block0 + BLOCK_BOARDS <= a.n)  // block-uniform: every block but the last takes the unchecked path
-        step_block<EXTRAS, true, RANDOM>(a, dir_lds, word_lds, &queue_state, reset_slot);
+    __shared__ uint16_t reset_slot[block_boards(BPL)];
+    const uint64_t block0 = (uint64_t)blockIdx.x * block_boards(BPL);
+    if (block0 + block_boards(BPL) <= a.n)  // block-uniform: every block but the last takes the unchecked path
+        step_block<EXTRAS, true, RANDOM, BPL>(a, dir_lds, word_lds, &queue_state, reset_slot);
     else
-        step_block<EXTRAS, false, RANDOM>(a, dir_lds, word_lds, &queue_state, reset_slot);
+        step_block<EXTRAS, false, RANDOM, BPL>(a, dir_lds, word_lds, &queue_state, reset_slot);
 }
 
 struct ResetArgs {
@@ -1387,7 +1401,8 @@ int launched(const char *what)
 }
 
 constexpr uint32_t STEP_FLAGS = ENV2048_FLAG_AUTO_RESET | ENV2048_FLAG_RANDOM_ACTIONS | ENV2048_FLAG_OBS_F16 | ENV2048_FLAG_OBS_BF16 |
-                                ENV2048_FLAG_STORES_WRITE_THROUGH | ENV2048_FLAG_STORES_WRITE_BACK | ENV2048_FLAG_REWARD_LOG2_F32;
+                                ENV2048_FLAG_STORES_WRITE_THROUGH | ENV2048_FLAG_STORES_WRITE_BACK | ENV2048_FLAG_REWARD_LOG2_F32 |
+                                ENV2048_FLAG_TILE_SMALL | ENV2048_FLAG_TILE_LARGE;
 // Launches up to this many boards use write-through stores unless a STORES_* flag says otherwise: they win while
 // boards + outputs of one launch stay within the 256 MiB Infinity Cache (measured 2^20..2^23 boards: -5..-13 %)
 // and lose beyond it (2^24: +7 %).
@@ -1400,6 +1415,8 @@ int validate_step(const env2048_step_args &a, const char *who)
         return fail(ENV2048_ERR_INVALID_ARG, "%s: OBS_F16 and OBS_BF16 exclude each other", who);
     if ((a.flags & ENV2048_FLAG_STORES_WRITE_THROUGH) && (a.flags & ENV2048_FLAG_STORES_WRITE_BACK))
         return fail(ENV2048_ERR_INVALID_ARG, "%s: STORES_WRITE_THROUGH and STORES_WRITE_BACK exclude each other", who);
+    if ((a.flags & ENV2048_FLAG_TILE_SMALL) && (a.flags & ENV2048_FLAG_TILE_LARGE))
+        return fail(ENV2048_ERR_INVALID_ARG, "%s: TILE_SMALL and TILE_LARGE exclude each other", who);
     if (a.reserved) return fail(ENV2048_ERR_INVALID_ARG, "%s: reserved must be 0", who);
     if ((a.flags & ENV2048_FLAG_REWARD_LOG2_F32) && !a.reward)
         return fail(ENV2048_ERR_INVALID_ARG, "%s: REWARD_LOG2_F32 without a reward array", who);
@@ -1417,7 +1434,8 @@ int validate_step(const env2048_step_args &a, const char *who)
 // Enqueue one step launch (arguments already validated, device already selected).
 void launch_step(const env2048_step_args &a, hipStream_t stream)
 {
-    uint32_t kernel_flags = a.flags & ~(ENV2048_FLAG_STORES_WRITE_THROUGH | ENV2048_FLAG_STORES_WRITE_BACK);
+    uint32_t kernel_flags = a.flags & ~(ENV2048_FLAG_STORES_WRITE_THROUGH | ENV2048_FLAG_STORES_WRITE_BACK | ENV2048_FLAG_TILE_SMALL |
+                                        ENV2048_FLAG_TILE_LARGE);
     if (!misaligned(a.reward, 16) && !misaligned(a.done, 4)) kernel_flags |= INTERNAL_FLAG_WIDE_OUTPUTS;
     const bool through = (a.flags & ENV2048_FLAG_STORES_WRITE_THROUGH)  ? true
                          : (a.flags & ENV2048_FLAG_STORES_WRITE_BACK) ? false
@@ -1429,12 +1447,22 @@ void launch_step(const env2048_step_args &a, hipStream_t stream)
     const bool extras = a.legal || a.obs || a.max_exp || (a.flags & ENV2048_FLAG_REWARD_LOG2_F32);
 #endif
     const bool random_actions = (a.flags & ENV2048_FLAG_RANDOM_ACTIONS) != 0u;
-    const dim3 grid = tile_grid_for(a.n), block(BLOCK);
+    const bool small = (a.flags & ENV2048_FLAG_TILE_SMALL)   ? true
+                       : (a.flags & ENV2048_FLAG_TILE_LARGE) ? false
+                                                             : a.n <= SMALL_TILING_MAX_BOARDS;
+    const dim3 grid((unsigned)((a.n + block_boards(small ? 1 : BOARDS_PER_LANE) - 1) / block_boards(small ? 1 : BOARDS_PER_LANE))), block(BLOCK);
     const uint32_t seed_lo = (uint32_t)a.seed, seed_hi = (uint32_t)(a.seed >> 32);
     const uint32_t step_lo = (uint32_t)a.step_index, step_hi = (uint32_t)(a.step_index >> 32);
-#define ENV2048_LAUNCH_STEP(EXTRAS, RANDOM)                                                                                    \
-    hipLaunchKernelGGL((step_kernel<EXTRAS, RANDOM>), grid, block, 0, stream, a.boards, a.actions, a.n, a.env_base, kernel_flags, \
-                       seed_lo, seed_hi, step_lo, step_hi, a.reward, a.done, a.legal, a.obs, a.max_exp)
+#define ENV2048_LAUNCH_STEP(EXTRAS, RANDOM)                                                                                        \
+    do {                                                                                                                           \
+        if (small)                                                                                                                 \
+            hipLaunchKernelGGL((step_kernel<EXTRAS, RANDOM, 1>), grid, block, 0, stream, a.boards, a.actions, a.n, a.env_base,     \
+                               kernel_flags, seed_lo, seed_hi, step_lo, step_hi, a.reward, a.done, a.legal, a.obs, a.max_exp);     \
+        else                                                                                                                       \
+            hipLaunchKernelGGL((step_kernel<EXTRAS, RANDOM, BOARDS_PER_LANE>), grid, block, 0, stream, a.boards, a.actions, a.n,   \
+                               a.env_base, kernel_flags, seed_lo, seed_hi, step_lo, step_hi, a.reward, a.done, a.legal, a.obs,     \
+                               a.max_exp);                                                                                         \
+    } while (0)
     if (extras && random_actions)
         ENV2048_LAUNCH_STEP(true, true);
     else if (extras)

@@ -153,6 +153,44 @@ def test_replay_at_full_size_equals_step_sequence(lib):
     assert e.value.code == capi.ERR_INVALID_ARG
 
 
+def test_both_tilings_agree_at_full_size_and_around_the_switch(lib):
+    """The step kernel's two tilings (1 / 4 boards per lane; the launch size picks one) give identical boards, rewards,
+    done flags, legal masks and observations: at 2^20 + 77 boards (ragged in both), and on either side of the 2^18-board
+    switch with the default policy against the oracle."""
+    n = (1 << 20) + 77
+    start = midgame(lib, n, env_base=2)
+    a = torch.randint(0, 4, (n,), dtype=torch.uint8, device='cuda')
+    outs = []
+    for tile in (capi.FLAG_TILE_SMALL, capi.FLAG_TILE_LARGE):
+        b = start.clone()
+        r = torch.zeros((n,), dtype=torch.int32, device='cuda')
+        d = torch.zeros((n,), dtype=torch.uint8, device='cuda')
+        lg = torch.zeros((n,), dtype=torch.uint8, device='cuda')
+        ob = torch.zeros((n, 16), dtype=torch.float32, device='cuda')
+        for t in range(3):
+            lib.step(DEV, stream(), n, 2, p(b), p(a), p(r), p(d), p(lg), p(ob), SEED, 64 + t, AUTO | tile)
+        lib.step(DEV, stream(), n, 2, p(b), p(a), p(r), p(d), None, None, SEED, 67, AUTO | tile)  # the lean kernel too
+        torch.cuda.synchronize()
+        outs.append((b, r, d, lg, ob))
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+    for n in ((1 << 18) - 3, 1 << 18, (1 << 18) + 1, (1 << 18) + 2049):
+        start = midgame(lib, n)
+        acts = torch.randint(0, 4, (n,), dtype=torch.uint8)
+        b = start.clone()
+        r = torch.zeros((n,), dtype=torch.int32, device='cuda')
+        d = torch.zeros((n,), dtype=torch.uint8, device='cuda')
+        a = acts.cuda()
+        lib.step(DEV, stream(), n, 0, p(b), p(a), p(r), p(d), None, None, SEED, 64, AUTO)
+        ref = oracle.step_batch(start.cpu().numpy(), acts.numpy(), SEED, 64, flags=AUTO, threads=16)
+        torch.cuda.synchronize()
+        assert np.array_equal(b.cpu().numpy(), ref['boards']) and np.array_equal(r.cpu().numpy(), ref['reward'])
+        assert np.array_equal(d.cpu().numpy(), ref['done'])
+    with pytest.raises(capi.Env2048Error) as e:
+        lib.step(DEV, stream(), 8, 0, p(b), p(a), p(r), p(d), None, None, 0, 0, capi.FLAG_TILE_SMALL | capi.FLAG_TILE_LARGE)
+    assert e.value.code == capi.ERR_INVALID_ARG
+
+
 def test_step_sequence_rows_equal_single_steps(lib):
     """env2048_step_sequence == the same env2048_step calls one by one: every output row, with host action
     tables, row_stride 0 (overwrite) and > n (padded rows), f32 and bf16 observations, a ragged batch."""

@@ -45,6 +45,17 @@ def p(t):
 
 
 def hip_step(lib, boards, actions, seed, step_index, *, env_base=0, flags=0, extras=False):
+    """Runs the launch in BOTH tilings of the step kernel (ENV2048_FLAG_TILE_SMALL / _LARGE) and insists on identical
+    outputs, so every oracle comparison in this file covers both; returns the default-policy result."""
+    outs = [_hip_step(lib, boards, actions, seed, step_index, env_base=env_base, flags=flags | tile, extras=extras)
+            for tile in (0, capi.FLAG_TILE_SMALL, capi.FLAG_TILE_LARGE)]
+    for other in outs[1:]:
+        for k in outs[0]:
+            np.testing.assert_array_equal(other[k], outs[0][k], err_msg=f'tilings differ in {k}')
+    return outs[0]
+
+
+def _hip_step(lib, boards, actions, seed, step_index, *, env_base=0, flags=0, extras=False):
     n = boards.shape[0]
     b = cu(boards)
     a = None if actions is None else cu(actions, torch.uint8)
@@ -352,7 +363,7 @@ def test_error_codes(lib):
         lib.step(DEV, stream(), 8, 0, p(b) + 4, p(a), None, p(d), None, None, 0, 0, 0)
     assert e.value.code == capi.ERR_ALIGNMENT
     with pytest.raises(capi.Env2048Error) as e:
-        lib.step(DEV, stream(), 8, 0, p(b), p(a), None, p(d), None, None, 0, 0, 0x100)  # unknown flag bit
+        lib.step(DEV, stream(), 8, 0, p(b), p(a), None, p(d), None, None, 0, 0, 0x8000)  # unknown flag bit
     assert e.value.code == capi.ERR_INVALID_ARG
     with pytest.raises(capi.Env2048Error) as e:
         lib.step(99, stream(), 8, 0, p(b), p(a), None, p(d), None, None, 0, 0, 0)

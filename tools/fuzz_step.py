@@ -39,6 +39,7 @@ while time.time() - t0 < budget:
     acts = None if flags & capi.FLAG_RANDOM_ACTIONS else actions
     want_max, norm = bool(rng.integers(0, 2)), bool(rng.integers(0, 4) == 0) and want_reward
     hint = int(rng.choice([0, 0, capi.FLAG_STORES_WRITE_THROUGH, capi.FLAG_STORES_WRITE_BACK]))
+    hint |= int(rng.choice([0, capi.FLAG_TILE_SMALL, capi.FLAG_TILE_LARGE]))
     ref = oracle.step_batch_ex(boards, acts, seed, step, env_base=env_base, flags=flags)
     b = torch.as_tensor(boards).cuda()
     a = None if acts is None else torch.as_tensor(acts).cuda()
