@@ -331,6 +331,8 @@ def run_rank(args) -> None:
                           p(env.legal), p(env.obs), 0, SEED, step_index, count, flags)
         step_index += count
 
+    enqueue_times = []
+
     def timed_block(count: int):
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         barrier()
@@ -338,9 +340,11 @@ def run_rank(args) -> None:
         t0 = time.perf_counter()
         ev0.record(stream)
         run_steps(count)
+        enqueued = time.perf_counter() - t0
         ev1.record(stream)
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
+        enqueue_times.append(enqueued / max(count, 1))
         return wall, ev0.elapsed_time(ev1) * 1e-3
 
     if args.only_cold:
@@ -582,7 +586,8 @@ def other_configs(torch, lib, device, device_index, h) -> dict:
     out['configs[1]'] = {
         'workload': '65 536 parallel boards, uint8 log2-packed, uniform random host actions, auto-reset, 1 GPU',
         'value': n1 * count / wall, 'unit': 'board-steps/s', 'us_per_step_wall': wall / count * 1e6, 'us_per_step_event': ev / count * 1e6,
-        'bound': 'launch/latency: 1 MiB of boards is L2/Infinity-Cache resident and 32 blocks fill an eighth of the chip',
+        'bound': 'launch rate: 1 MiB of boards is cache-resident and a launch (one-board-per-lane tiling, 128 workgroups) is shorter than '
+                 'the host + command-processor cost of a dependent launch (see timing.host_enqueue_us_per_launch)',
     }
     del env, pool
 
