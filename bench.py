@@ -72,6 +72,7 @@ def parse_args(argv=None):
     ap.add_argument('--only-cold', action='store_true', help='profiling aid: run ONLY the HBM-cold leg (so that rocprofv3 counters of '
                     'step_kernel<false, false> describe cold launches) and print its object')
     ap.add_argument('--cold-stores', choices=['auto', 'through', 'back'], default='auto', help='store-policy hint of the cold leg')
+    ap.add_argument('--cold-tile', choices=['auto', 'small', 'large'], default='auto', help='tiling hint of the cold leg')
     ap.add_argument('--no-other-configs', action='store_true', help='skip the BASELINE configs[1] / configs[4] legs')
     ap.add_argument('--extras', action='store_true', help='also emit legal mask + obs (not the headline)')
     ap.add_argument('--obs-dtype', choices=['f32', 'f16', 'bf16'], default='f32', help='with --extras: element type of obs')
@@ -477,12 +478,14 @@ def cold_leg(args, torch, lib, capi, device, device_index, h, stream, n, env_bas
     records = (capi.StepArgs * sets)()
     cold_step = 1 << 32
     hint = {'auto': 0, 'through': capi.FLAG_STORES_WRITE_THROUGH, 'back': capi.FLAG_STORES_WRITE_BACK}[args.cold_stores]
+    hint |= {'auto': 0, 'small': capi.FLAG_TILE_SMALL, 'large': capi.FLAG_TILE_LARGE}[args.cold_tile]
+    extra_hint = 0
 
     def cold_pass() -> None:
         nonlocal cold_step
         for s in range(sets):
             records[s] = capi.StepArgs(n, (world + s) * n + env_base, cb[s].data_ptr(), ca[s].data_ptr(), cr[s].data_ptr(),
-                                       cd[s].data_ptr(), None, None, SEED, cold_step, flags | hint, 0)
+                                       cd[s].data_ptr(), None, None, SEED, cold_step, flags | hint | extra_hint, 0)
         lib.step_many(device_index, h, records)
         cold_step += 1
 
@@ -500,6 +503,27 @@ def cold_leg(args, torch, lib, capi, device, device_index, h, stream, n, env_bas
         torch.cuda.synchronize()
         cold_times.append(ev0.elapsed_time(ev1) * 1e-3 / (passes * sets))
     cold_s = statistics.median(cold_times)
+    # the same launches with the one-board-per-lane tiling requested (ENV2048_FLAG_TILE_SMALL): four times as many, shorter
+    # workgroups run in two generations, so loads of later workgroups overlap the arithmetic of earlier ones -- slower on
+    # cache-resident data (where the default large tiling is chosen by size), faster on cold data
+    small_hint = None
+    if args.cold_tile == 'auto' and n > (1 << 18):
+        extra_hint = capi.FLAG_TILE_SMALL
+        cold_pass()
+        small_times = []
+        for _ in range(3):
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record(stream)
+            for _ in range(passes):
+                cold_pass()
+            ev1.record(stream)
+            torch.cuda.synchronize()
+            small_times.append(ev0.elapsed_time(ev1) * 1e-3 / (passes * sets))
+        extra_hint = 0
+        sm = statistics.median(small_times)
+        small_hint = {'us_per_launch': sm * 1e6, 'achieved': ALGO_BYTES_PER_STEP * n / sm / 1e9,
+                      'frac': ALGO_BYTES_PER_STEP * n / sm / 1e9 / HBM_PEAK_GBS,
+                      'note': 'same launches with ENV2048_FLAG_TILE_SMALL (caller-side hint for cold batches; not the default at this size)'}
     # the same sets, but even / odd sets on two streams: consecutive launches are independent batches, so the tail of one
     # launch may overlap the head of the next (what a caller with several independent cold batches would do)
     side = torch.cuda.Stream(device)
@@ -510,7 +534,7 @@ def cold_leg(args, torch, lib, capi, device, device_index, h, stream, n, env_bas
         nonlocal cold_step
         for s in range(sets):
             rec = capi.StepArgs(n, (world + s) * n + env_base, cb[s].data_ptr(), ca[s].data_ptr(), cr[s].data_ptr(), cd[s].data_ptr(),
-                                None, None, SEED, cold_step, flags | hint, 0)
+                                None, None, SEED, cold_step, flags | hint | extra_hint, 0)
             (odd if s & 1 else even)[s >> 1] = rec
         lib.step_many(device_index, h, even)
         lib.step_many(device_index, side.cuda_stream, odd)
@@ -541,6 +565,8 @@ def cold_leg(args, torch, lib, capi, device, device_index, h, stream, n, env_bas
         'footprint_bytes': sets * set_bytes,
         'launches_timed': passes * sets,
         'stores': args.cold_stores,
+        'tile': args.cold_tile,
+        'tile_small_hint': small_hint,
         'two_streams': {'achieved': ALGO_BYTES_PER_STEP * n / two_s / 1e9, 'frac': ALGO_BYTES_PER_STEP * n / two_s / 1e9 / HBM_PEAK_GBS,
                         'us_per_launch': two_s * 1e6,
                         'note': 'even / odd sets on two streams (independent batches may overlap): aggregate bytes / time, not a '
