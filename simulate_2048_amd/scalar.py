@@ -9,11 +9,15 @@ no device allocations and no torch operators on the call path -- the Python side
 those buffers, launches, waits for the stream and reads the views.  Tile values <-> log2 exponents are
 converted on the host (16 integers).
 
-Not thread-safe (one scratch set per runtime), like the module-level generator of the reference.
+Thread-safe: every host thread gets its own scratch set (created on its first call, ~1 KiB of pinned memory), so two
+threads stepping their own ``TwentyFortyEight`` objects never share an operand buffer.  (The reference's unseeded
+draws share one module-level generator; here they share one atomic counter of a Philox stream, ``runtime.entropy_stream``.)
 With an injected host library (tests) the buffers are ordinary host memory and the same code runs.
 """
 
 from __future__ import annotations
+
+import threading
 
 import numpy as np
 import torch
@@ -107,13 +111,16 @@ class ScalarOps:
         return self.values(self.outcomes[:count], dtype), count
 
 
+_per_thread = threading.local()
+
+
 def current() -> ScalarOps:
-    """The ScalarOps of the current runtime (created on first use, dropped when the runtime changes)."""
+    """The calling thread's ScalarOps for the current runtime (created on first use, replaced when the runtime changes)."""
     rt = runtime.current()
-    ops = getattr(rt, '_scalar_ops', None)
-    if ops is None:
+    ops = getattr(_per_thread, 'ops', None)
+    if ops is None or ops.rt is not rt:
         ops = ScalarOps(rt)
-        rt._scalar_ops = ops
+        _per_thread.ops = ops
     return ops
 
 

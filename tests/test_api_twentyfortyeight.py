@@ -253,3 +253,31 @@ def test_transforms_match_reference_vectors(golden):
         np.testing.assert_array_equal(encode_flatten(values, encodage_size=31), g['onehot31'][i])
     for r, want in zip(g['rewards'], g['normalized']):
         assert normalize_reward(float(r)) == pytest.approx(float(want), abs=1e-12)
+
+
+def test_single_board_calls_from_several_threads(api_runtime):
+    """Every host thread has its own scratch operands (simulate_2048_amd/scalar.py): four threads stepping their own
+    environments concurrently get exactly the games they get one after the other."""
+    import threading
+
+    def play(seed, out):  # (the runtime selected by the fixture is process-wide: worker threads see it too)
+        state = np.zeros((4, 4), dtype=np.int64)
+        fill_cells(state, 2, seed=seed)
+        rng = np.random.default_rng(seed)
+        total = 0.0
+        for t in range(60):
+            state, r = next_state(state, int(rng.integers(0, 4)), seed=seed * 1000 + t)
+            total += float(r)
+        out[seed] = (state.copy(), total)
+
+    serial, threaded = {}, {}
+    for seed in (1, 2, 3, 4):
+        play(seed, serial)
+    threads = [threading.Thread(target=play, args=(seed, threaded)) for seed in (1, 2, 3, 4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for seed in (1, 2, 3, 4):
+        np.testing.assert_array_equal(threaded[seed][0], serial[seed][0])
+        assert threaded[seed][1] == serial[seed][1]
