@@ -192,6 +192,21 @@ def cpu_baseline(boards_np, seconds: float):
         if single_elapsed >= 2.0:
             break
     single = f'; 1 thread: {n * single_steps / single_elapsed:.2e} steps/s' if single_steps else ''
+    # the reference-shaped per-board NumPy engine (oracle/numpy_shaped.py: same algorithmic structure as the reference's
+    # gameboard.py, which cannot travel to this box) on one core, ~2 s of random play on one board
+    from oracle import numpy_shaped
+
+    board = oracle.unpack_values(boards_np[0]).reshape(4, 4)
+    shaped_steps, t2 = 0, time.perf_counter()
+    while True:
+        word = oracle.step_word(SEED, 0, 900_000 + shaped_steps)
+        board, _, finished = numpy_shaped.transition(board, word & 3, word)
+        if finished:
+            board = oracle.unpack_values(boards_np[(shaped_steps + 1) % n]).reshape(4, 4)
+        shaped_steps += 1
+        shaped_elapsed = time.perf_counter() - t2
+        if shaped_elapsed >= 2.0:
+            break
     return {
         'value': n * steps / elapsed,
         'unit': 'board-steps/s',
@@ -199,6 +214,12 @@ def cpu_baseline(boards_np, seconds: float):
         'kind': 'port',
         'sample': f'{steps} steps x {n} boards (same mid-game boards, auto-reset, host uint8 actions) in {elapsed:.1f} s{single}; '
                   f'oracle/env2048_oracle.c, gcc -O2 -fopenmp; reference NumPy engine itself: ~1.0e4 steps/s/core (BASELINE.md)',
+        'reference_shaped_numpy': {
+            'value': shaped_steps / shaped_elapsed, 'unit': 'board-steps/s', 'cores': 1, 'kind': 'port',
+            'sample': f'{shaped_steps} single-board steps in {shaped_elapsed:.1f} s with oracle/numpy_shaped.py -- a per-board NumPy engine with '
+                      f'the algorithmic structure of the reference\'s gameboard.py (rot90, per-row Python loop, argwhere spawn), checked against the '
+                      f'reference-generated fixtures; the reference itself measured 9.5-10.2e3 steps/s on one core of the build container',
+        },
     }
 
 

@@ -192,6 +192,32 @@ def test_chance_outcomes_vs_reference_after_state(golden):
     np.testing.assert_allclose(g['prob'].sum(axis=1), 1.0, atol=1e-12)
 
 
+def test_reference_shaped_numpy_baseline_against_the_fixtures(golden):
+    """oracle/numpy_shaped.py (the per-board NumPy engine bench.py times as the reference-shaped CPU baseline) against the
+    reference-generated fixtures: afterstates + scores + validity, terminal flags, and full Philox-driven trajectories."""
+    from oracle import numpy_shaped as ns
+
+    g = golden['afterstates']
+    rng = np.random.default_rng(0)
+    for i in rng.choice(g['boards'].shape[0], size=400, replace=False):
+        board = oracle.unpack_values(g['boards'][i]).reshape(4, 4)
+        assert ns.terminal(board) == bool(g['done'][i])
+        for a in range(4):
+            after, gained = ns.afterstate(board, a)
+            np.testing.assert_array_equal(oracle.pack_values(after).reshape(16), g['after'][i, a])
+            assert gained == int(g['reward'][i, a])
+            assert ns.left_move_possible(np.rot90(board, k=a)) == bool(g['valid'][i, a])
+    t = golden['trajectories']
+    seed, base, step0 = int(t['plain_seed']), int(t['plain_env_base']), int(t['plain_step0'])
+    for j in (0, 7, 15):
+        board = oracle.unpack_values(t['plain_boards0'][j]).reshape(4, 4)
+        for step in range(t['plain_boards'].shape[0]):
+            w = oracle.step_word(seed, base + j, step0 + step)
+            board, reward, done = ns.transition(board, w & 3, w)
+            assert np.array_equal(oracle.pack_values(board).reshape(16), t['plain_boards'][step, j])
+            assert reward == int(t['plain_reward'][step, j]) and done == bool(t['plain_done'][step, j])
+
+
 def test_batch_is_independent_of_slicing(golden):
     """Multi-GPU determinism: slices with the right env_base equal the whole."""
     g = golden['trajectories']
