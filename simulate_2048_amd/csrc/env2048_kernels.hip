@@ -592,6 +592,9 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(RolloutArgs a)
     __shared__ uint4 dir_lds[8];
     __shared__ __attribute__((aligned(16))) uint32_t word_lds[WAVES_PER_BLOCK][WORD_STRIP];
     __shared__ unsigned long long stats_lds[STATS ? ENV2048_ROLLOUT_STATS_WORDS : 1];
+    // REPLAY, wide rows: per wave 256 reward words + 256 done bytes + 256 action bytes, to turn the lane's four boards
+    // (64j + l) into four ADJACENT ones (4l .. 4l+3) so that a row of the tile moves as one dwordx4 / dword per lane
+    __shared__ __attribute__((aligned(16))) uint32_t rows_lds[REPLAY ? WAVES_PER_BLOCK : 1][REPLAY ? TILE_BOARDS + 2 * (TILE_BOARDS / 4) : 1];
     if (STATS) {
         if (threadIdx.x < ENV2048_ROLLOUT_STATS_WORDS) stats_lds[threadIdx.x] = threadIdx.x == 4u ? ~0ull : 0ull;  // [4] = min
     }
@@ -625,20 +628,41 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(RolloutArgs a)
         cur_len[j] = (STATS && valid[j] && a.ep_length) ? a.ep_length[i] : 0u;
         cur_ret[j] = (STATS && valid[j] && a.ep_return) ? (unsigned long long)a.ep_return[i] : 0ull;
     }
+    // wide rows: the whole tile exists, four boards per lane, and the host found every row 4-/16-byte aligned
+    const bool wide_rows = REPLAY && BOARDS_PER_LANE == 4 && tile0 + TILE_BOARDS <= a.n && (a.flags & INTERNAL_FLAG_WIDE_OUTPUTS) != 0u;
+    uint32_t *rew_lds = rows_lds[REPLAY ? wave : 0];
+    uint8_t *done_lds = reinterpret_cast<uint8_t *>(rew_lds + (REPLAY ? TILE_BOARDS : 0));
+    uint8_t *act_lds = done_lds + (REPLAY ? TILE_BOARDS : 0);
     uint32_t next_act[BOARDS_PER_LANE];
+    uint32_t next_act4 = 0u;  // wide: the action bytes of boards 4l .. 4l+3 of the next row
     if (REPLAY) {
+        if (wide_rows) {
+            next_act4 = reinterpret_cast<const uint32_t *>(a.action_rows + tile0)[lane];
+        } else {
 #pragma unroll
-        for (int j = 0; j < BOARDS_PER_LANE; ++j) next_act[j] = (valid[j] && a.T) ? a.action_rows[tile0 + 64u * j + lane] : 0u;
+            for (int j = 0; j < BOARDS_PER_LANE; ++j) next_act[j] = (valid[j] && a.T) ? a.action_rows[tile0 + 64u * j + lane] : 0u;
+        }
     }
 
     for (uint32_t t = 0; t < a.T; ++t) {
         uint32_t act[BOARDS_PER_LANE];
         if (REPLAY) {
             const bool more = t + 1u < a.T;  // uniform
+            if (wide_rows) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // last step's reads of the action bytes are done
+                __builtin_amdgcn_wave_barrier();
+                reinterpret_cast<uint32_t *>(act_lds)[lane] = next_act4;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int j = 0; j < BOARDS_PER_LANE; ++j) {
-                act[j] = next_act[j];
-                if (more && valid[j]) next_act[j] = a.action_rows[(uint64_t)(t + 1u) * a.row_stride + tile0 + 64u * j + lane];
+                for (int j = 0; j < BOARDS_PER_LANE; ++j) act[j] = act_lds[64u * j + lane];
+                if (more) next_act4 = reinterpret_cast<const uint32_t *>(a.action_rows + (uint64_t)(t + 1u) * a.row_stride + tile0)[lane];
+            } else {
+#pragma unroll
+                for (int j = 0; j < BOARDS_PER_LANE; ++j) {
+                    act[j] = next_act[j];
+                    if (more && valid[j]) next_act[j] = a.action_rows[(uint64_t)(t + 1u) * a.row_stride + tile0 + 64u * j + lane];
+                }
             }
         }
         const uint64_t step = a.step0 + t;
@@ -657,7 +681,10 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(RolloutArgs a)
             eps[j] += done ? 1u : 0u;
             moves[j] += changed ? 1u : 0u;
             pending |= (done ? 1u : 0u) << j;
-            if (REPLAY && valid[j]) {
+            if (REPLAY && wide_rows) {
+                rew_lds[64u * j + lane] = reward;
+                done_lds[64u * j + lane] = done ? 1 : 0;
+            } else if (REPLAY && valid[j]) {
                 const uint64_t at = (uint64_t)t * a.row_stride + tile0 + 64u * j + lane;
                 if (a.reward_rows) __builtin_nontemporal_store((int32_t)reward, &a.reward_rows[at]);
                 if (a.done_rows) __builtin_nontemporal_store((uint8_t)(done ? 1 : 0), &a.done_rows[at]);
@@ -679,6 +706,18 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(RolloutArgs a)
                     cur_ret[j] = 0ull;
                 }
             }
+        }
+        if (REPLAY && wide_rows) {  // row t of the tile: one dwordx4 of rewards and one dword of done bytes per lane
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint64_t row0 = (uint64_t)t * a.row_stride + tile0;
+            if (a.reward_rows) {
+                const u32x4 r4 = reinterpret_cast<const u32x4 *>(rew_lds)[lane];
+                __builtin_nontemporal_store(r4, reinterpret_cast<u32x4 *>(a.reward_rows + row0) + lane);
+            }
+            if (a.done_rows) __builtin_nontemporal_store(reinterpret_cast<const uint32_t *>(done_lds)[lane], reinterpret_cast<uint32_t *>(a.done_rows + row0) + lane);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the next step rewrites these LDS rows
+            __builtin_amdgcn_wave_barrier();
         }
         if (auto_reset) {
             // one reset block per finished board; usually at most one lane of the wave has one
@@ -1735,6 +1774,8 @@ int env2048_replay(int device, void *stream, uint64_t n, uint64_t env_base, uint
     if (int rc = check_count(n)) return rc;
     DeviceScope scope(device);
     if (scope.rc) return scope.rc;
+    if ((row_stride & 3u) == 0u && !misaligned(actions, 4) && !misaligned(reward, 16) && !misaligned(done, 4))
+        flags |= INTERNAL_FLAG_WIDE_OUTPUTS;  // every row of a full tile can move as dwordx4 / dword per lane
     RolloutArgs a{n, env_base, boards, return_sum, episodes, valid_moves, (uint32_t)seed, (uint32_t)(seed >> 32), step0, T, flags,
                   nullptr, nullptr, nullptr, actions, reward, done, row_stride};
     hipLaunchKernelGGL((rollout_kernel<false, true>), tile_grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, a);
