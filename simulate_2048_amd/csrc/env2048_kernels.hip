@@ -176,10 +176,11 @@ __device__ __forceinline__ void store_obs_any_coalesced(void *obs, uint32_t *str
 // ------------------------------------------------------------------------------------------
 // Hot kernels: step and rollout.
 //
-// Work decomposition: a wave owns a TILE of 256 consecutive boards and each lane handles four of
+// Work decomposition (large tiling; the step kernel also exists with ONE board per lane for small launches, see
+// tile_boards() below): a wave owns a TILE of 256 consecutive boards and each lane handles four of
 // them, board j of lane l being tile board 64*j + l -- so every board load/store is one fully
 // coalesced 1 KiB wave access (global_load/store_dwordx4) and reward/done/action accesses are
-// dense too.  A block is 4 waves = 1024 boards.
+// dense too.  A block is 8 waves = 2048 boards.
 //
 // RNG: one Philox4x32-10 block yields the step words of FOUR neighbouring environments
 // (env >> 2 selects the block, env & 3 the word), so a wave needs 64 blocks (65 when its first
@@ -192,7 +193,7 @@ __device__ __forceinline__ void store_obs_any_coalesced(void *obs, uint32_t *str
 //
 // Auto-reset: terminal boards are rare (~0.7 % of steps in random play), so instead of every
 // wave paying a second Philox block whenever ANY of its lanes finished a game, finished boards
-// are queued in LDS and the block's first threads rebuild all of them after one barrier.
+// are queued in LDS and the LAST wave of the block to finish rebuilds all of them (no second barrier).
 // ------------------------------------------------------------------------------------------
 constexpr int WAVES_PER_BLOCK = BLOCK / 64;
 #ifndef ENV2048_BOARDS_PER_LANE
