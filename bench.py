@@ -410,7 +410,8 @@ def run_rank(args) -> None:
         working_set = n * (16 + 8 + 4 + 1) + (n * (1 + 16 * obs_bytes) if args.extras else 0)  # boards + 8-array action pool + outputs
         resident = working_set <= INFINITY_CACHE_BYTES
         prof = None if args.extras else load_step_profile(n, 'resident')
-        kernel = 'step_kernel<false, false>' if not args.extras else 'step_kernel<true, false>'
+        tiling = 1 if n <= (1 << 18) else 4  # the launch-size rule of env2048_step (one / four boards per lane)
+        kernel = f'step_kernel<false, false, {tiling}>' if not args.extras else f'step_kernel<true, false, {tiling}>'
         roofline = {
             'kernel': kernel,
             'avg_launch_us': launch_s * 1e6,

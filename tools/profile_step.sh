@@ -32,7 +32,7 @@ cd $R
 LABEL=${2:-$(basename $TAG)}
 # summaries first (then the raw per-dispatch CSVs, tens of MB, are dropped), and the fresh counter table goes where bench.py
 # reads it, so that the bench lines below carry the traffic / VALU counts of THIS kernel build
-python3 tools/summarize_profiles.py $TAG $LABEL $O/summary > $O/summary.log 2>&1 && rm -rf $O/pmc_*/ $O/stats_*/
+python3 tools/summarize_profiles.py $TAG $LABEL $O/summary > $O/summary.log 2>&1 && test -s $O/summary/step_pmc.json && rm -rf $O/pmc_*/ $O/stats_*/
 echo "summary rc=$?"
 cp $O/summary/step_pmc.json $R/profiles/step_pmc.json
 python3 bench.py > $O/summary/${LABEL}_bench_default.json 2> $O/bench_default.err

@@ -19,7 +19,7 @@ REPO = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(REPO))
 import bench  # noqa: E402  (kernel_source_sha only; nothing touches a GPU)
 
-KERNEL = 'step_kernel<false, false>'
+KERNEL = 'step_kernel<false, false, 4>'  # lean outputs, host actions, the large tiling (what 2^20-board launches run)
 BOARDS = 1 << 20
 
 
