@@ -21,7 +21,9 @@ def _board_tensor(board) -> torch.Tensor:
     t = to_tensor(board)
     if t.shape[-2:] != (4, 4):
         raise ValueError(f'expected a (4, 4) board, got shape {tuple(t.shape)}')
-    return t.to(device=rt.device, dtype=torch.int32).contiguous()
+    if t.dtype != torch.int32 or t.device != rt.device:
+        t = t.to(device=rt.device, dtype=torch.int32)
+    return t if t.is_contiguous() else t.contiguous()
 
 
 def _packed(board) -> torch.Tensor:

@@ -56,6 +56,8 @@ def _dev(x, dtype, n, rt) -> torch.Tensor:
     t = to_tensor(x)
     if t.dtype != dtype or t.device != rt.device:
         t = t.to(device=rt.device, dtype=dtype)
+    if t.dim() == 1 and t.shape[0] == n and t.is_contiguous():
+        return t
     return t.reshape(n).contiguous()
 
 
@@ -85,11 +87,13 @@ def batched_step(states: GameState, actions, keys):
     i32 = torch.empty((2, n), dtype=torch.int32, device=rt.device)   # step_count, max_tile
     f32 = torch.empty((2, n), dtype=torch.float32, device=rt.device)  # total_reward, reward
     done_u8 = torch.empty((n,), dtype=torch.uint8, device=rt.device)
-    step_count, max_tile, total, reward = wrap(i32[0]), wrap(i32[1]), wrap(f32[0]), wrap(f32[1])
     dev, stream = rt.handles()
+    i32_ptr, f32_ptr = i32.data_ptr(), f32.data_ptr()  # (addresses taken on the plain tensors: no __torch_function__ detour)
     rt.lib.step_state_i32_keyed(dev, stream, n, k.data_ptr(), board_in.data_ptr(), board.data_ptr(), acts.data_ptr(),
-                                steps_in.data_ptr(), step_count.data_ptr(), done_in.data_ptr(), done_u8.data_ptr(),
-                                total_in.data_ptr(), total.data_ptr(), reward.data_ptr(), max_tile.data_ptr())
+                                steps_in.data_ptr(), i32_ptr, done_in.data_ptr(), done_u8.data_ptr(),
+                                total_in.data_ptr(), f32_ptr, f32_ptr + 4 * n, i32_ptr + 4 * n)
+    step_count, max_tile = (wrap(t) for t in i32.unbind(0))
+    total, reward = (wrap(t) for t in f32.unbind(0))
     done = wrap(done_u8.view(torch.bool))
     new_state = GameState(board=wrap(board), step_count=step_count, done=done, total_reward=total)
     info = {'max_tile': max_tile, 'step_count': step_count, 'total_reward': total}

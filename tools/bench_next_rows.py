@@ -85,4 +85,29 @@ dt = (time.perf_counter() - t0) / 64
 out['N4_trajectory_step_2^20'] = {'us_per_step': dt * 1e6, 'board_steps_per_s': n / dt}
 dt = per_call(lambda: ops.onehot(e.boards[: 1 << 18], 31), 50)
 out['N4_onehot31_2^18'] = {'us_per_call': dt * 1e6, 'GB_per_s': (16 + 496) * (1 << 18) / dt / 1e9}
+
+# N4 (round 2): recording with max-tile rows, episode segmentation of a [512, 2^20]-row recording, rollout statistics
+e = BatchedEnv2048(n, 4, device='cuda:0', auto_reset=True)
+e.reset()
+T = 256
+traj = TrajectoryBuffer(e, T, record_obs=False, record_legal=False)
+traj.begin()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for t in range(T):
+    traj.step(None)
+torch.cuda.synchronize()
+out['N4_record_reward_done_maxexp_2^20'] = {'us_per_step': (time.perf_counter() - t0) / T * 1e6}
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+ep = traj.episodes()
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+out['N4_episodes_256x2^20_rows'] = {'ms': dt * 1e3, 'records': int(ep['env'].shape[0]), 'rows_per_s': T * n / dt,
+                                   'GB_per_s_rows_read_twice': T * n * (1 + 1 + 4 + 1) / dt / 1e9}
+e = BatchedEnv2048(n, 5, device='cuda:0', auto_reset=True)
+e.reset()
+dt = per_call(lambda: e.rollout(512), 3)
+dt_stats = per_call(lambda: e.rollout_episodes(512), 3)
+out['N4_rollout_512_plain_vs_episode_stats'] = {'ms_plain': dt * 1e3, 'ms_with_episode_statistics': dt_stats * 1e3}
 print(json.dumps(out, indent=1))
