@@ -775,20 +775,36 @@ struct EpisodeRows {
     const uint8_t *max_exp;  // may be NULL
 };
 
+constexpr uint32_t EPISODE_ROWS_IN_FLIGHT = 8;  // rows whose loads are issued together (the walk itself is sequential)
+
 __global__ __launch_bounds__(256) void count_episodes_kernel(EpisodeRows a, uint32_t *counts)
 {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= a.n) return;
     const bool frozen = (a.flags & ENV2048_EPISODES_FROZEN) != 0u;
     uint32_t count = 0u, open = 0u, phys = a.first_row;
-    for (uint32_t r = 0; r < a.rows; ++r) {
-        const uint8_t d = a.done[(uint64_t)phys * a.row_stride + i];
-        phys = phys + 1u == a.ring_rows ? 0u : phys + 1u;
-        ++open;
-        if (d) {
-            ++count;
-            open = 0u;
-            if (frozen) break;  // a finished game stops recording (self_play.py:359,368)
+    bool stop = false;
+    for (uint32_t r0 = 0; r0 < a.rows && !stop; r0 += EPISODE_ROWS_IN_FLIGHT) {
+        uint8_t d[EPISODE_ROWS_IN_FLIGHT];
+        const uint32_t batch = min(EPISODE_ROWS_IN_FLIGHT, a.rows - r0);
+#pragma unroll
+        for (uint32_t u = 0; u < EPISODE_ROWS_IN_FLIGHT; ++u) {
+            d[u] = 0;
+            if (u < batch) {
+                d[u] = a.done[(uint64_t)phys * a.row_stride + i];
+                phys = phys + 1u == a.ring_rows ? 0u : phys + 1u;
+            }
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < EPISODE_ROWS_IN_FLIGHT; ++u) {
+            if (u < batch && !stop) {
+                ++open;
+                if (d[u]) {
+                    ++count;
+                    open = 0u;
+                    stop = frozen;  // a finished game stops recording (self_play.py:359,368)
+                }
+            }
         }
     }
     counts[i] = count + (open ? 1u : 0u);
@@ -804,6 +820,7 @@ __global__ __launch_bounds__(256) void segment_episodes_kernel(EpisodeRows a, co
     uint64_t slot = offsets[i];
     uint32_t start = 0u, length = 0u, best = 0u, phys = a.first_row, r = 0u;
     double total = 0.0;
+    bool stop = false;
     auto emit = [&](bool terminated) {
         env2048_episode e;
         e.env = (uint32_t)i;
@@ -815,27 +832,49 @@ __global__ __launch_bounds__(256) void segment_episodes_kernel(EpisodeRows a, co
         e.total_reward = total;
         episodes[slot++] = e;
     };
-    for (; r < a.rows; ++r) {
-        const uint64_t at = (uint64_t)phys * a.row_stride + i;
-        phys = phys + 1u == a.ring_rows ? 0u : phys + 1u;
-        if (a.reward) total += reward_f32 ? (double)static_cast<const float *>(a.reward)[at] : (double)static_cast<const int32_t *>(a.reward)[at];
-        if (a.max_exp) best = max(best, (uint32_t)a.max_exp[at]);
-        ++length;
-        if (episode_of) episode_of[at] = (int32_t)slot;
-        if (a.done[at]) {
-            emit(true);
-            start = r + 1u;
-            length = 0u;
-            best = 0u;
-            total = 0.0;
-            if (frozen) {
-                ++r;
-                break;
+    while (r < a.rows && !stop) {
+        uint8_t d[EPISODE_ROWS_IN_FLIGHT], m[EPISODE_ROWS_IN_FLIGHT];
+        double w[EPISODE_ROWS_IN_FLIGHT];
+        uint64_t at[EPISODE_ROWS_IN_FLIGHT];
+        const uint32_t batch = min(EPISODE_ROWS_IN_FLIGHT, a.rows - r);
+#pragma unroll
+        for (uint32_t u = 0; u < EPISODE_ROWS_IN_FLIGHT; ++u) {
+            d[u] = m[u] = 0;
+            w[u] = 0.0;
+            at[u] = 0;
+            if (u < batch) {
+                at[u] = (uint64_t)phys * a.row_stride + i;
+                phys = phys + 1u == a.ring_rows ? 0u : phys + 1u;
+                d[u] = a.done[at[u]];
+                if (a.reward) w[u] = reward_f32 ? (double)static_cast<const float *>(a.reward)[at[u]] : (double)static_cast<const int32_t *>(a.reward)[at[u]];
+                if (a.max_exp) m[u] = a.max_exp[at[u]];
             }
         }
+#pragma unroll
+        for (uint32_t u = 0; u < EPISODE_ROWS_IN_FLIGHT; ++u) {
+            if (u < batch) {
+                if (stop) {  // frozen: rows after the end of the game belong to no episode
+                    if (episode_of) episode_of[at[u]] = -1;
+                } else {
+                    total += w[u];
+                    best = max(best, (uint32_t)m[u]);
+                    ++length;
+                    if (episode_of) episode_of[at[u]] = (int32_t)slot;
+                    if (d[u]) {
+                        emit(true);
+                        start = r + u + 1u;
+                        length = 0u;
+                        best = 0u;
+                        total = 0.0;
+                        stop = frozen;
+                    }
+                }
+            }
+        }
+        r += batch;
     }
     if (length) emit(false);
-    if (episode_of)  // frozen: the rows after the end of the game belong to no episode
+    if (episode_of)
         for (; r < a.rows; ++r) {
             episode_of[(uint64_t)phys * a.row_stride + i] = -1;
             phys = phys + 1u == a.ring_rows ? 0u : phys + 1u;
