@@ -55,7 +55,10 @@ for nn in (8, 1 << 20):
     st = genv.batched_reset(keys)
     acts = torch.randint(0, 4, (nn,), dtype=torch.int32).cuda()
     dt = per_call(lambda: genv.batched_step(st, acts, keys), 200)
-    out[f'N2_batched_step_n{nn}'] = {'us_per_call': dt * 1e6, 'board_steps_per_s': nn / dt}
+    out[f'N2_batched_step_numpy_keys_n{nn}'] = {'us_per_call': dt * 1e6, 'board_steps_per_s': nn / dt}
+    keys_dev = torch.from_numpy(keys.view(np.int32)).cuda()  # keys already on the device (what a DLPack hand-over gives)
+    dt = per_call(lambda: genv.batched_step(st, acts, keys_dev), 200)
+    out[f'N2_batched_step_device_keys_n{nn}'] = {'us_per_call': dt * 1e6, 'board_steps_per_s': nn / dt}
     dt = per_call(lambda: genv.batched_get_observation(st), 200)
     out[f'N2_batched_get_observation_n{nn}'] = {'us_per_call': dt * 1e6}
     dt = per_call(lambda: genv.batched_get_legal_actions(st), 200)
