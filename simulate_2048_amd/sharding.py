@@ -60,3 +60,26 @@ def global_stats(local: dict, group=None) -> dict:
     t = torch.tensor([float(local[k]) for k in keys], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return dict(zip(keys, t.tolist()))
+
+
+def reduce_episode_stats(stats: torch.Tensor, group=None) -> torch.Tensor:
+    """Combine the 40-word episode-statistics blocks of ``BatchedEnv2048.rollout_episodes`` over all ranks (sums, except
+    word 4 = minimum and word 5 = maximum of the total reward): three tiny all_reduces at the END of an evaluation run,
+    off the hot path.  Returns a new int64 tensor on the device of ``stats`` (unchanged without a process group)."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return stats.clone()
+    backend = dist.get_backend(group)
+    work = stats.to(torch.device('cuda', torch.cuda.current_device()) if backend == 'nccl' else 'cpu').clone()
+    # the words are uint64 bit patterns in an int64 tensor: sums wrap identically; min/max need the unsigned order, which
+    # for values below 2^63 (any real reward) is the signed order -- except the "no game yet" minimum UINT64_MAX = -1
+    lo = work[4:5].clone()
+    lo[lo < 0] = torch.iinfo(torch.int64).max
+    hi = work[5:6].clone()
+    dist.all_reduce(work, op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    work[4] = -1 if int(lo) == torch.iinfo(torch.int64).max else lo[0]
+    work[5] = hi[0]
+    return work.to(stats.device)

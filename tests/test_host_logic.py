@@ -208,6 +208,10 @@ if rank == 0:
     gathered.sort(key=lambda x: x[0])
     np.save(os.environ["OUT"], np.concatenate([b for _, b in gathered]))
     print("STATS", int(stats["reward"]), int(stats["episodes"]), int(stats["envs"]))
+from simulate_2048_amd.sharding import reduce_episode_stats
+ep = reduce_episode_stats(env.rollout_episodes(300))
+if rank == 0:
+    np.save(os.environ["OUT"] + ".stats.npy", ep.numpy())
 dist.destroy_process_group()
 '''
 
@@ -234,6 +238,11 @@ def test_two_process_gloo_sharding(tmp_path):
     np.testing.assert_array_equal(np.load(out), ref)
     stats = re.search(r'STATS (\d+) (\d+) (\d+)', proc.stdout)
     assert stats and [int(x) for x in stats.groups()] == [reward, episodes, total]
+    # per-episode statistics of a further 300-step rollout, reduced over the two ranks == the unsharded oracle run
+    # (each rank counts the games in progress from the start of ITS rollout call, like the oracle started on these boards)
+    want = oracle.rollout_episodes(ref, 123, 40, 300, flags=3)['stats']
+    got = np.load(str(out) + '.stats.npy').view(np.uint64)
+    np.testing.assert_array_equal(got, want)
 
 
 def test_trajectory_buffer_records_in_place():
