@@ -101,6 +101,7 @@ for t in range(T):
     traj.step(None)
 torch.cuda.synchronize()
 out['N4_record_reward_done_maxexp_2^20'] = {'us_per_step': (time.perf_counter() - t0) / T * 1e6}
+traj.episodes()  # (the first call pays torch's lazy loading of cumsum / where / shift kernels: ~0.1-0.4 s once per process)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 ep = traj.episodes()
