@@ -23,6 +23,8 @@ namespace {
 #endif
 constexpr int BLOCK = ENV2048_BLOCK;
 
+// [step-kernel-source-begin]  (bench.py hashes the text between these markers + board_ops.hpp to tell whether the committed
+// rocprofv3 counters in profiles/step_pmc.json still describe this step kernel)
 __device__ __forceinline__ Board load_board(const uint8_t *boards, uint64_t i)
 {
     uint4 v = reinterpret_cast<const uint4 *>(boards)[i];
@@ -536,6 +538,8 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(uint8_t *boards, const uint
     else
         step_block<EXTRAS, false, RANDOM, BPL>(a, dir_lds, word_lds, &queue_state, reset_slot);
 }
+
+// [step-kernel-source-end]
 
 struct ResetArgs {
     uint64_t n;
@@ -1510,6 +1514,7 @@ int validate_step(const env2048_step_args &a, const char *who)
     return check_count(a.n);
 }
 
+// [step-kernel-source-begin]
 // Enqueue one step launch (arguments already validated, device already selected).
 void launch_step(const env2048_step_args &a, hipStream_t stream)
 {
@@ -1552,6 +1557,7 @@ void launch_step(const env2048_step_args &a, hipStream_t stream)
         ENV2048_LAUNCH_STEP(false, false);
 #undef ENV2048_LAUNCH_STEP
 }
+// [step-kernel-source-end]
 
 }  // namespace
 
