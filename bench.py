@@ -651,13 +651,46 @@ def other_configs(torch, lib, device, device_index, h) -> dict:
         torch.cuda.synchronize()
         times.append((time.perf_counter() - t0, ev0.elapsed_time(ev1) * 1e-3))
     wall, ev = sorted(times)[len(times) // 2]
+    # the same per-step launches as a REPLAYABLE hipGraph: the step index lives in device memory (step_counter), so every
+    # replay continues the random stream; the host then costs one graph launch per 200 steps instead of 200 kernel launches
+    genv = BatchedEnv2048(n1, SEED, device=device, auto_reset=True, device_step_counter=True)
+    genv.boards.copy_(env.boards)
+    genv.step_index = 10_000
+    side = torch.cuda.Stream(device)
+    graph = torch.cuda.CUDAGraph()
+    captured = 200
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            for t in range(captured):
+                genv.step(pool[t & 7])
+            genv.commit_steps()  # last node of the graph: device counter += captured
+    torch.cuda.synchronize()
+    graph.replay()
+    graph_times = []
+    for rep in range(4):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        for _ in range(10):
+            graph.replay()
+        ev1.record(stream)
+        torch.cuda.synchronize()
+        graph_times.append((time.perf_counter() - t0, ev0.elapsed_time(ev1) * 1e-3))
+    gwall, gev = sorted(graph_times)[len(graph_times) // 2]
+    replayed = genv.step_index - 10_000
     out['configs[1]'] = {
         'workload': '65 536 parallel boards, uint8 log2-packed, uniform random host actions, auto-reset, 1 GPU',
         'value': n1 * count / wall, 'unit': 'board-steps/s', 'us_per_step_wall': wall / count * 1e6, 'us_per_step_event': ev / count * 1e6,
         'bound': 'launch rate: 1 MiB of boards is cache-resident and a launch (one-board-per-lane tiling, 128 workgroups) is shorter than '
                  'the host + command-processor cost of a dependent launch (see timing.host_enqueue_us_per_launch)',
+        'as_replayed_hipgraph': {'value': n1 * captured * 10 / gwall, 'unit': 'board-steps/s', 'us_per_step_wall': gwall / (captured * 10) * 1e6,
+                                 'us_per_step_event': gev / (captured * 10) * 1e6, 'steps_replayed_check': replayed == captured * 41,
+                                 'note': f'{captured} step launches + one counter-advance node captured once (device-side step counter), graph replayed: '
+                                         f'no per-step host cost'},
     }
-    del env, pool
+    del env, pool, genv, graph
 
     # configs[4]
     n4, T = 1 << 20, 512

@@ -148,8 +148,16 @@ typedef struct env2048_step_args {
     uint8_t *max_exp; /* optional, records only: max_exp[i] = log2(max tile) of board i after move + spawn and BEFORE an
                          auto-reset replaces it -- for a game that ends in this step, the max tile it reached
                          (info.max_tile, reinforce/game/env.py:127-131; Trajectory.max_tile, self_play.py:389) */
+    uint64_t *step_counter; /* optional, records only: a device uint64.  When given, the launch's step index is
+                               *step_counter + step_index (the field above becomes an OFFSET).  A hipGraph that captured K
+                               such launches with offsets 0 .. K-1 followed by env2048_advance_counter(counter, K) can be
+                               REPLAYED: every replay continues the random stream where the previous one stopped -- the
+                               launch-bound per-move loop (reinforce/training/self_play.py:314-368) then costs 2-3 us per
+                               step instead of the 3-4 us of host launch cost. */
 } env2048_step_args;
 ENV2048_EXPORT int env2048_step_many(int device, void *stream, uint64_t count, const env2048_step_args *args);
+/* *counter += delta on `stream` (one thread): the node that ends a captured graph of step_counter launches. */
+ENV2048_EXPORT int env2048_advance_counter(int device, void *stream, uint64_t *counter, uint64_t delta);
 
 /*
  * `count` consecutive transitions of ONE batch: launch t (t = 0 .. count-1) is

@@ -55,6 +55,12 @@ class BatchedEnv2048:
     with_legal, with_obs : bool
         Also emit the legal-action bitmask / the observation from the step kernel
         (what reinforce/training/self_play.py:316-317 asks the env for every move).
+    device_step_counter : bool
+        Keep the step index in device memory (``step_counter``, one int64) and let every ``step`` launch take its index
+        as counter + offset.  A ``torch.cuda.graph`` that captured ``step`` calls followed by ``commit_steps()`` can then be
+        REPLAYED -- each replay continues the random stream -- which takes the host out of a launch-bound per-move loop
+        (2-3 us per step as a graph instead of 3-4 us of launch cost at small batches).  ``step_index`` then reads the
+        counter back (a synchronisation).
     obs_dtype : torch.float32 | torch.float16 | torch.bfloat16
         Element type of ``obs``.  The values (log2(tile)/16) are exact in all three; the 16-bit forms halve
         the output that bounds the step-with-observations path and are what a bf16/fp16 network consumes.
@@ -64,7 +70,8 @@ class BatchedEnv2048:
 
 
     def __init__(self, num_envs: int, seed: int = 0, *, device='cuda', env_base: int = 0, auto_reset: bool = False,
-                 with_legal: bool = False, with_obs: bool = False, obs_dtype=torch.float32, lib=None):
+                 with_legal: bool = False, with_obs: bool = False, obs_dtype=torch.float32, device_step_counter: bool = False,
+                 lib=None):
         self.device = torch.device(device)
         if lib is None:
             if self.device.type != 'cuda':
@@ -83,8 +90,11 @@ class BatchedEnv2048:
         self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         self.env_base = int(env_base)
         self.auto_reset = bool(auto_reset)
-        self.step_index = 0
+        self._step_index = 0
         n = self.num_envs
+        self.step_counter = torch.zeros((1,), dtype=torch.int64, device=self.device) if device_step_counter else None
+        self._pending = 0  # steps enqueued since the device counter was last advanced (their offsets)
+        self._in_capture = False
         self.boards = torch.zeros((n, 16), dtype=torch.uint8, device=self.device)
         self.reward = torch.zeros((n,), dtype=torch.int32, device=self.device)
         self.done = torch.zeros((n,), dtype=torch.uint8, device=self.device)
@@ -98,6 +108,30 @@ class BatchedEnv2048:
         self._ptr_legal, self._ptr_obs = _p(self.legal), _p(self.obs)
 
     # ------------------------------------------------------------------------------------------
+    @property
+    def step_index(self) -> int:
+        """Index of the NEXT step (with ``device_step_counter``: read back from the device)."""
+        if self.step_counter is not None:
+            return int(self.step_counter[0]) + self._pending
+        return self._step_index
+
+    @step_index.setter
+    def step_index(self, value: int) -> None:
+        self._step_index = int(value)
+        if self.step_counter is not None:
+            self.step_counter[0] = int(value)
+            self._pending = 0
+
+    def commit_steps(self) -> None:
+        """``device_step_counter`` only: advance the device counter by the steps enqueued since the last commit (one
+        one-thread kernel on the current stream).  Call it at the END of a region captured into a graph, so that every
+        replay of the graph plays the NEXT steps; in eager use it is optional (offsets simply keep growing)."""
+        if self.step_counter is None or self._pending == 0:
+            return
+        dev, stream = _stream_handle(self.device)
+        self.lib.advance_counter(dev, stream, _p(self.step_counter), self._pending)
+        self._pending = 0
+
     @property
     def flags(self) -> int:
         return (capi.FLAG_AUTO_RESET if self.auto_reset else 0) | self._OBS_FLAGS[self.obs_dtype]
@@ -148,10 +182,14 @@ class BatchedEnv2048:
             if actions.numel() != self.num_envs:
                 raise ValueError(f'expected {self.num_envs} actions, got {actions.numel()}')
         dev, stream = _stream_handle(self.device)
-        if out_reward is None and out_done is None and out_legal is None and out_obs is None:  # the common, cheap path
+        if self.step_counter is not None:  # the launch reads and advances the device counter: nothing to track on the host
+            return self._step_with_counter(dev, stream, actions, flags, out_reward, out_done, out_legal, out_obs, out_max_exp,
+                                           normalized_reward)
+        if out_reward is None and out_done is None and out_legal is None and out_obs is None and out_max_exp is None \
+                and not normalized_reward:  # the common, cheap path
             self.lib.step(dev, stream, self.num_envs, self.env_base, self._ptr_boards, _p(actions), self._ptr_reward,
-                          self._ptr_done, self._ptr_legal, self._ptr_obs, self.seed, self.step_index, flags)
-            self.step_index += 1
+                          self._ptr_done, self._ptr_legal, self._ptr_obs, self.seed, self._step_index, flags)
+            self._step_index += 1
             return self.boards, self.reward, self.done
         if normalized_reward:
             if out_reward is None:
@@ -165,13 +203,37 @@ class BatchedEnv2048:
         obs = self.obs if out_obs is None else self._check_out(out_obs, self.obs_dtype, (self.num_envs, 16))
         if out_max_exp is None and not normalized_reward:
             self.lib.step(dev, stream, self.num_envs, self.env_base, self._ptr_boards, _p(actions), _p(reward),
-                          _p(done), _p(legal), _p(obs), self.seed, self.step_index, flags)
+                          _p(done), _p(legal), _p(obs), self.seed, self._step_index, flags)
         else:  # the record form carries the extra recording output
             max_exp = None if out_max_exp is None else self._check_out(out_max_exp, torch.uint8, (self.num_envs,))
             record = (capi.StepArgs * 1)(capi.StepArgs(self.num_envs, self.env_base, self._ptr_boards, _p(actions), _p(reward), _p(done),
-                                                       _p(legal), _p(obs), self.seed, self.step_index, flags, 0, _p(max_exp)))
+                                                       _p(legal), _p(obs), self.seed, self._step_index, flags, 0, _p(max_exp)))
             self.lib.step_many(dev, stream, record)
-        self.step_index += 1
+        self._step_index += 1
+        return self.boards, reward, done
+
+    def _step_with_counter(self, dev, stream, actions, flags, out_reward, out_done, out_legal, out_obs, out_max_exp, normalized_reward):
+        if self.device.type == 'cuda':
+            capturing = torch.cuda.is_current_stream_capturing()
+            if capturing and not self._in_capture and self._pending:
+                raise RuntimeError('call commit_steps() before capturing a graph: the captured launches must start at offset 0 of '
+                                   'the device step counter, or every replay would skip steps')
+            self._in_capture = capturing
+        if normalized_reward:
+            if out_reward is None:
+                raise ValueError('normalized_reward=True needs a float32 out_reward tensor (the persistent reward buffer is int32)')
+            reward = self._check_out(out_reward, torch.float32, (self.num_envs,))
+            flags |= capi.FLAG_REWARD_LOG2_F32
+        else:
+            reward = self.reward if out_reward is None else self._check_out(out_reward, torch.int32, (self.num_envs,))
+        done = self.done if out_done is None else self._check_out(out_done, torch.uint8, (self.num_envs,))
+        legal = self.legal if out_legal is None else self._check_out(out_legal, torch.uint8, (self.num_envs,))
+        obs = self.obs if out_obs is None else self._check_out(out_obs, self.obs_dtype, (self.num_envs, 16))
+        max_exp = None if out_max_exp is None else self._check_out(out_max_exp, torch.uint8, (self.num_envs,))
+        record = (capi.StepArgs * 1)(capi.StepArgs(self.num_envs, self.env_base, self._ptr_boards, _p(actions), _p(reward), _p(done),
+                                                   _p(legal), _p(obs), self.seed, self._pending, flags, 0, _p(max_exp), _p(self.step_counter)))
+        self.lib.step_many(dev, stream, record)
+        self._pending += 1
         return self.boards, reward, done
 
     def _check_out(self, t: torch.Tensor, dtype, shape) -> torch.Tensor:

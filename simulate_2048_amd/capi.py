@@ -45,7 +45,7 @@ class StepArgs(ctypes.Structure):
 
     _fields_ = [('n', _u64), ('env_base', _u64), ('boards', _ptr), ('actions', _ptr), ('reward', _ptr), ('done', _ptr),
                 ('legal', _ptr), ('obs', _ptr), ('seed', _u64), ('step_index', _u64), ('flags', _u32), ('reserved', _u32),
-                ('max_exp', _ptr)]
+                ('max_exp', _ptr), ('step_counter', _ptr)]
 
 
 class Episode(ctypes.Structure):
@@ -67,6 +67,7 @@ PROTOTYPES = {
     'env2048_reset': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _ptr, _u64, _u64]),
     'env2048_step': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _u64, _u64, _u32]),
     'env2048_step_many': (_c_int, [_c_int, _ptr, _u64, ctypes.POINTER(StepArgs)]),
+    'env2048_advance_counter': (_c_int, [_c_int, _ptr, _ptr, _u64]),
     'env2048_step_sequence': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, ctypes.POINTER(_ptr), _ptr, _ptr, _ptr, _ptr, _u64, _u64, _u64,
                                         _u32, _u32]),
     'env2048_step_state_i32': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _u64, _u64]),
@@ -153,6 +154,9 @@ class Library:
     def step_many(self, device, stream, records) -> None:
         """``records``: a ctypes array of StepArgs (build it once with ``(StepArgs * k)(...)`` and reuse it)."""
         self._check(self._dll.env2048_step_many(device, stream, len(records), records))
+
+    def advance_counter(self, device, stream, counter, delta) -> None:
+        self._check(self._dll.env2048_advance_counter(device, stream, counter, delta))
 
     def step_sequence(self, device, stream, n, env_base, boards, actions, reward, done, legal, obs, row_stride, seed, step_index,
                       count, flags) -> None:

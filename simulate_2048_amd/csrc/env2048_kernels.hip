@@ -525,8 +525,18 @@ template <bool EXTRAS, bool RANDOM, int BPL>
 __global__ __launch_bounds__(BLOCK) void step_kernel(uint8_t *boards, const uint8_t *actions, uint64_t n, uint64_t env_base,
                                                      uint32_t flags, uint32_t seed_lo, uint32_t seed_hi, uint32_t step_lo,
                                                      uint32_t step_hi, int32_t *reward, uint8_t *done, uint8_t *legal, void *obs,
-                                                     uint8_t *max_exp)
+                                                     uint8_t *max_exp, unsigned long long *step_counter)
 {
+    // Step index relative to a counter in device memory (records with `step_counter`): what makes a captured hipGraph of
+    // step launches replayable -- the graph's launches carry the offsets 0 .. K-1, a one-thread env2048_advance_counter
+    // node at its end adds K, and every replay continues the Philox stream instead of repeating it.  One scalar load per
+    // wave (wave-uniform), issued with the board loads.
+    if (step_counter) {
+        const unsigned long long s = __hip_atomic_load(step_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) +
+                                     (((unsigned long long)step_hi << 32) | step_lo);
+        step_lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)s);
+        step_hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(s >> 32));
+    }
     const StepArgs a{n, env_base, boards, actions, reward, done, legal, obs, RngKey{seed_lo, seed_hi, step_lo, step_hi}, flags, max_exp};
     __shared__ uint4 dir_lds[8];
     __shared__ __attribute__((aligned(16))) uint32_t word_lds[WAVES_PER_BLOCK][word_strip_words(BPL)];
@@ -539,6 +549,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(uint8_t *boards, const uint
         step_block<EXTRAS, false, RANDOM, BPL>(a, dir_lds, word_lds, &queue_state, reset_slot);
 }
 
+__global__ void advance_counter_kernel(unsigned long long *counter, unsigned long long delta) { *counter += delta; }
 // [step-kernel-source-end]
 
 struct ResetArgs {
@@ -1510,6 +1521,7 @@ int validate_step(const env2048_step_args &a, const char *who)
     if (misaligned(a.boards, 16)) return fail(ENV2048_ERR_ALIGNMENT, "%s: boards must be 16-byte aligned", who);
     if (misaligned(a.reward, 4)) return fail(ENV2048_ERR_ALIGNMENT, "%s: reward must be 4-byte aligned", who);
     if (misaligned(a.obs, 16)) return fail(ENV2048_ERR_ALIGNMENT, "%s: obs must be 16-byte aligned", who);
+    if (misaligned(a.step_counter, 8)) return fail(ENV2048_ERR_ALIGNMENT, "%s: step_counter must be 8-byte aligned", who);
     if (int rc = check_range(a.n, a.env_base)) return rc;
     return check_count(a.n);
 }
@@ -1537,15 +1549,17 @@ void launch_step(const env2048_step_args &a, hipStream_t stream)
     const dim3 grid((unsigned)((a.n + block_boards(small ? 1 : BOARDS_PER_LANE) - 1) / block_boards(small ? 1 : BOARDS_PER_LANE))), block(BLOCK);
     const uint32_t seed_lo = (uint32_t)a.seed, seed_hi = (uint32_t)(a.seed >> 32);
     const uint32_t step_lo = (uint32_t)a.step_index, step_hi = (uint32_t)(a.step_index >> 32);
+    unsigned long long *counter = reinterpret_cast<unsigned long long *>(a.step_counter);
 #define ENV2048_LAUNCH_STEP(EXTRAS, RANDOM)                                                                                        \
     do {                                                                                                                           \
         if (small)                                                                                                                 \
             hipLaunchKernelGGL((step_kernel<EXTRAS, RANDOM, 1>), grid, block, 0, stream, a.boards, a.actions, a.n, a.env_base,     \
-                               kernel_flags, seed_lo, seed_hi, step_lo, step_hi, a.reward, a.done, a.legal, a.obs, a.max_exp);     \
+                               kernel_flags, seed_lo, seed_hi, step_lo, step_hi, a.reward, a.done, a.legal, a.obs, a.max_exp,      \
+                               counter);                                                                                           \
         else                                                                                                                       \
             hipLaunchKernelGGL((step_kernel<EXTRAS, RANDOM, BOARDS_PER_LANE>), grid, block, 0, stream, a.boards, a.actions, a.n,   \
                                a.env_base, kernel_flags, seed_lo, seed_hi, step_lo, step_hi, a.reward, a.done, a.legal, a.obs,     \
-                               a.max_exp);                                                                                         \
+                               a.max_exp, counter);                                                                                \
     } while (0)
     if (extras && random_actions)
         ENV2048_LAUNCH_STEP(true, true);
@@ -1595,13 +1609,23 @@ int env2048_step(int device, void *stream, uint64_t n, uint64_t env_base, uint8_
                  const uint8_t *actions, int32_t *reward, uint8_t *done, uint8_t *legal, void *obs,
                  uint64_t seed, uint64_t step_index, uint32_t flags)
 {
-    const env2048_step_args a{n, env_base, boards, actions, reward, done, legal, obs, seed, step_index, flags, 0u, nullptr};
+    const env2048_step_args a{n, env_base, boards, actions, reward, done, legal, obs, seed, step_index, flags, 0u, nullptr, nullptr};
     if (int rc = validate_step(a, "env2048_step")) return rc;
     if (n == 0) return ENV2048_OK;
     DeviceScope scope(device);
     if (scope.rc) return scope.rc;
     launch_step(a, (hipStream_t)stream);
     return launched("env2048_step launch");
+}
+
+int env2048_advance_counter(int device, void *stream, uint64_t *counter, uint64_t delta)
+{
+    if (!counter || misaligned(counter, 8)) return fail(ENV2048_ERR_INVALID_ARG, "env2048_advance_counter: counter is NULL or misaligned");
+    DeviceScope scope(device);
+    if (scope.rc) return scope.rc;
+    hipLaunchKernelGGL(advance_counter_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, reinterpret_cast<unsigned long long *>(counter),
+                       (unsigned long long)delta);
+    return launched("env2048_advance_counter launch");
 }
 
 int env2048_step_many(int device, void *stream, uint64_t count, const env2048_step_args *args)
@@ -1644,6 +1668,7 @@ int env2048_step_sequence(int device, void *stream, uint64_t n, uint64_t env_bas
                                  step_index + t,
                                  flags,
                                  0u,
+                                 nullptr,
                                  nullptr};
     };
     for (uint32_t t = 0; t < count; ++t)

@@ -72,8 +72,14 @@ class OracleLibrary:
 
     def step_many(self, device, stream, records):
         for r in records:
-            self.step(device, stream, r.n, r.env_base, r.boards, r.actions, r.reward, r.done, r.legal, r.obs, r.seed, r.step_index,
+            step_index = r.step_index
+            if r.step_counter:  # step index = device counter + offset
+                step_index += int(_view(r.step_counter, 1, np.uint64)[0])
+            self.step(device, stream, r.n, r.env_base, r.boards, r.actions, r.reward, r.done, r.legal, r.obs, r.seed, step_index,
                       r.flags & (15 | 64), max_exp=r.max_exp)
+
+    def advance_counter(self, device, stream, counter, delta):
+        _view(counter, 1, np.uint64)[0] += np.uint64(delta)
 
     def step_sequence(self, device, stream, n, env_base, boards, actions, reward, done, legal, obs, row_stride, seed, step_index,
                       count, flags):

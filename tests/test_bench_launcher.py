@@ -138,5 +138,5 @@ def test_step_sequence_and_step_many_host_logic():
     lib.step_many(0, None, records)
     np.testing.assert_array_equal(b1, oracle.step_batch(start, acts[0], seed, 5, env_base=8, flags=1)['boards'])
     np.testing.assert_array_equal(b2, oracle.step_batch(start[:100], None, seed, 5, env_base=8, flags=3)['boards'])
-    assert ctypes.sizeof(capi.StepArgs) == 96  # the C struct of include/env2048.h: 2 u64 + 6 pointers + 2 u64 + 2 u32 + 1 pointer
+    assert ctypes.sizeof(capi.StepArgs) == 104  # the C struct of include/env2048.h: 2 u64 + 6 pointers + 2 u64 + 2 u32 + 2 pointers
     assert ctypes.sizeof(capi.Episode) == 24

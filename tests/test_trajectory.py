@@ -216,6 +216,60 @@ def test_replay_equals_the_same_steps_one_by_one(make_env):
         b.replay(actions[:, :10].contiguous())
 
 
+def test_device_step_counter_and_graph_replay(make_env):
+    """Records with ``step_counter``: the launch's step index is device counter + offset, so (a) stepping with the counter ==
+    stepping with explicit indices, and (b) on the GPU a captured hipGraph of K step launches + env2048_advance_counter(K)
+    can be replayed and CONTINUES the random stream (each replay == the next K explicit steps)."""
+    n, seed = 3000, 21
+    ref = make_env(n, seed, env_base=9, auto_reset=True, with_legal=True)
+    env = make_env(n, seed, env_base=9, auto_reset=True, with_legal=True, device_step_counter=True)
+    for e in (ref, env):
+        e.reset()
+        e.rollout(100)
+    assert env.step_index == ref.step_index == 100
+    rng = np.random.default_rng(8)
+    acts = [torch.from_numpy(rng.integers(0, 4, size=n).astype(np.uint8)).to(env.device) for _ in range(4)]
+    for t in range(12):
+        ref.step(acts[t & 3])
+        env.step(acts[t & 3])
+    assert env.step_index == 112 and int(env.step_counter[0]) == 100  # offsets 0..11 pending on top of the device counter
+    env.commit_steps()
+    assert env.step_index == 112 and int(env.step_counter[0]) == 112
+    assert torch.equal(env.boards, ref.boards) and torch.equal(env.legal, ref.legal) and torch.equal(env.reward, ref.reward)
+    env.step_index = 500  # re-synchronise both sides somewhere else
+    ref.step_index = 500
+    env.step(None)
+    ref.step(None)
+    assert torch.equal(env.boards, ref.boards) and env.step_index == 501
+    if env.device.type != 'cuda':
+        return
+    K = 6
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match='commit_steps'):  # one uncommitted step is pending: a capture must start at offset 0
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(torch.cuda.CUDAGraph(), stream=side):
+                env.step(acts[0])
+    torch.cuda.synchronize()
+    env.commit_steps()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            for t in range(K):
+                env.step(acts[t & 3])
+            env.commit_steps()  # the graph's last node: counter += K
+    torch.cuda.synchronize()
+    assert env.step_index == 501  # capture launched nothing
+    for replay in range(3):
+        graph.replay()
+        for t in range(K):
+            ref.step(acts[t & 3])
+        torch.cuda.synchronize()
+        assert torch.equal(env.boards, ref.boards) and torch.equal(env.done, ref.done), f'replay {replay}'
+        assert env.step_index == 501 + K * (replay + 1) == ref.step_index
+
+
 def test_episode_entry_points_reject_bad_arguments(make_env):
     env = make_env(8, 1)
     if isinstance(env.lib, OracleLibrary):
