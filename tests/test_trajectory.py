@@ -216,6 +216,7 @@ def test_replay_equals_the_same_steps_one_by_one(make_env):
         b.replay(actions[:, :10].contiguous())
 
 
+@pytest.mark.filterwarnings('ignore:The CUDA Graph is empty')  # the capture that is refused on purpose below
 def test_device_step_counter_and_graph_replay(make_env):
     """Records with ``step_counter``: the launch's step index is device counter + offset, so (a) stepping with the counter ==
     stepping with explicit indices, and (b) on the GPU a captured hipGraph of K step launches + env2048_advance_counter(K)
