@@ -19,10 +19,30 @@ after game and every game is a record.
 
 from __future__ import annotations
 
+from typing import NamedTuple
+
+import numpy as np
 import torch
 
 from . import capi
 from .batch import BatchedEnv2048, _p, _stream_handle
+
+
+class Trajectory(NamedTuple):
+    """One finished (or cut) game in the field layout of the reference's ``Trajectory``
+    (reinforce/training/replay_buffer.py:35-66): host NumPy arrays, ready for ``ReplayBuffer.add``."""
+
+    observations: np.ndarray  # (T, 16) float32
+    actions: np.ndarray       # (T,) int32
+    rewards: np.ndarray       # (T,) float32
+    policies: np.ndarray      # (T, A) float32 (zeros when no policy rows were recorded)
+    values: np.ndarray        # (T,) float32 (zeros when no value rows were recorded)
+    done: bool = True
+    total_reward: float = 0.0
+    max_tile: int = 0
+
+    def __len__(self) -> int:
+        return len(self.observations)
 
 
 class TrajectoryBuffer:
@@ -188,3 +208,38 @@ class TrajectoryBuffer:
             'total_reward': float(episodes['total_reward'][k]),
             'max_tile': int(episodes['max_tile'][k]),
         }
+
+    def export_trajectories(self, *, frozen: bool | None = None, min_length: int = 1) -> list[Trajectory]:
+        """Every recorded game as a host-side ``Trajectory`` -- what ``play_parallel_games`` returns
+        (reinforce/training/self_play.py:372-392) -- with ONE device-to-host copy per row array instead of one per move:
+        the episode records are cut on device (``episodes``), the rows travel once, and the per-game arrays are NumPy
+        slices of them.  Needs observation rows (``record_obs=True``)."""
+        if self.obs is None:
+            raise ValueError('export_trajectories needs observation rows (record_obs=True)')
+        ep = self.episodes(frozen=frozen)
+        first, count = ep['first_step'], ep['num_steps']
+        order = [self._row(first + r) for r in range(count)]  # logical step -> physical row, once
+        rows = torch.as_tensor(order, dtype=torch.int64, device=self.env.device)
+        obs = self.obs[rows].to(torch.float32).cpu().numpy()           # (count, N, 16)
+        actions = self.actions[rows].cpu().numpy().astype(np.int32)    # (count, N)
+        rewards = self.reward[rows].to(torch.float32).cpu().numpy()
+        num_actions = self.policy.shape[-1] if self.policy is not None else 4
+        policies = self.policy[rows].cpu().numpy() if self.policy is not None else None
+        values = self.value[rows].cpu().numpy() if self.value is not None else None
+        env_idx = ep['env'].cpu().numpy()
+        start = (ep['start'].cpu().numpy() - first).astype(np.int64)
+        length = ep['length'].cpu().numpy().astype(np.int64)
+        terminated = ep['terminated'].cpu().numpy()
+        total = ep['total_reward'].cpu().numpy()
+        max_tile = ep['max_tile'].cpu().numpy()
+        out = []
+        for k in range(len(env_idx)):
+            e, s, n = int(env_idx[k]), int(start[k]), int(length[k])
+            if n < min_length:
+                continue
+            out.append(Trajectory(
+                observations=obs[s:s + n, e], actions=actions[s:s + n, e], rewards=rewards[s:s + n, e],
+                policies=policies[s:s + n, e] if policies is not None else np.zeros((n, num_actions), dtype=np.float32),
+                values=values[s:s + n, e] if values is not None else np.zeros((n,), dtype=np.float32),
+                done=bool(terminated[k]), total_reward=float(total[k]), max_tile=int(max_tile[k])))
+        return out

@@ -106,6 +106,15 @@ def test_frozen_episodes_equal_the_reference_cut(make_env):
         assert host(tr['actions']).tolist() == lists[i]['act'] and host(tr['rewards']).astype(float).tolist() == lists[i]['rew']
         assert tr['done'] is True and tr['total_reward'] == float(sum(lists[i]['rew']))
         assert tr['max_tile'] == 1 << int(final_boards[i].max())  # frozen games keep their last board
+    # ... and all games at once, in the reference's Trajectory layout (host arrays, one copy per row array)
+    exported = traj.export_trajectories()
+    assert len(exported) == n and all(t.done for t in exported)
+    for i in (0, 3, n - 1):
+        t = exported[i]
+        assert len(t) == len(lists[i]['act']) and t.observations.dtype == np.float32 and t.actions.dtype == np.int32
+        assert np.array_equal(t.observations, np.stack(lists[i]['obs'])) and t.actions.tolist() == lists[i]['act']
+        assert t.rewards.dtype == np.float32 and t.rewards.tolist() == lists[i]['rew'] and t.total_reward == float(sum(lists[i]['rew']))
+        assert t.max_tile == 1 << int(final_boards[i].max()) and t.policies.shape == (len(t), 4) and t.values.shape == (len(t),)
     lengths = host(ep['length'])
     eo = host(ep['episode_of'])
     for i in (0, 5, n - 1):
