@@ -16,7 +16,7 @@ SEED = 0x2048
 
 
 def main():
-    lib = capi.library()
+    lib = capi.Library(sys.argv[1]) if len(sys.argv) > 1 else capi.library()
     res = {}
     K = 1000
     for n in (8, 1 << 12, 1 << 16, 1 << 18, 1 << 20):
