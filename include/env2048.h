@@ -277,6 +277,9 @@ ENV2048_EXPORT int env2048_replay(int device, void *stream, uint64_t n, uint64_t
  * [replaces: evaluate_games, reinforce/training/self_play.py:476-521, on random-action rollouts]
  */
 #define ENV2048_ROLLOUT_STATS_WORDS 40
+/* Without AUTO_RESET a finished game stays on its board: it is counted once, and its ep_length becomes this marker (its
+ * ep_return keeps the game's total), so that further calls leave it alone. */
+#define ENV2048_EPISODE_OVER 0xFFFFFFFFu
 ENV2048_EXPORT int env2048_rollout_episodes(int device, void *stream, uint64_t n, uint64_t env_base, uint8_t *boards, uint64_t seed,
                                             uint64_t step0, uint32_t T, uint32_t flags, uint32_t *ep_length, int64_t *ep_return,
                                             uint64_t *stats);

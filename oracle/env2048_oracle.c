@@ -449,7 +449,9 @@ ORACLE_API int oracle_rollout_episodes(uint64_t n, uint64_t env_base, uint8_t *b
             uint64_t step = step0 + t;
             uint32_t w = step_word(seed, env_base + i, step);
             int d = 0, m = 0;
-            sum += (uint64_t)step_one_ex(b, (int)(w & 3u), seed, env_base + i, step, flags, w, &d, NULL, &m);
+            uint64_t r = (uint64_t)step_one_ex(b, (int)(w & 3u), seed, env_base + i, step, flags, w, &d, NULL, &m);
+            if (len == 0xFFFFFFFFu) continue;            /* no auto-reset: this game is over and was counted */
+            sum += r;
             len += 1;
             if (d) {
                 stats[0] += 1; stats[1] += len; stats[2] += sum; stats[3] += sum * sum;
@@ -457,7 +459,7 @@ ORACLE_API int oracle_rollout_episodes(uint64_t n, uint64_t env_base, uint8_t *b
                 if (sum > stats[5]) stats[5] = sum;
                 stats[6] += len * len;
                 stats[8 + (m & 31)] += 1;
-                len = 0; sum = 0;
+                if (flags & FLAG_AUTO_RESET) { len = 0; sum = 0; } else { len = 0xFFFFFFFFu; }
             }
         }
         if (ep_length) ep_length[i] = (uint32_t)len;

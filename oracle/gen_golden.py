@@ -21,6 +21,8 @@ Fixture sets:
   resets.npz        G5  reset boards under the Philox contract (two sequential injected spawns)
   transforms.npz        encode_flatten(...,31) one-hot observations and normalize_reward values
   chance_outcomes.npz   after_state(board): every (empty cell, value) outcome in the reference's order + float64 probabilities
+  random_play_stats.npz per-game length / total reward / max tile of 3000 uniformly-random games played by the REFERENCE engine
+                        with its own NumPy RNG: the distribution the build's Philox-driven play must reproduce
 """
 
 from __future__ import annotations
@@ -321,6 +323,34 @@ def gen_chance_outcomes():
     return n, int(count.max()), int((count == 1).sum())
 
 
+def gen_random_play_stats(games: int = 3000):
+    """Whole games of the reference engine under uniformly random actions with ITS OWN spawn RNG (seeded per step):
+    the bitstream cannot be reproduced, the DISTRIBUTION of game length / score / max tile can -- it pins
+    P(tile 4) = 0.1, the uniform choice of the spawn cell and the invalid-move handling end to end."""
+    rng = np.random.default_rng(20482)
+    length = np.zeros(games, dtype=np.int32)
+    total = np.zeros(games, dtype=np.int64)
+    max_tile = np.zeros(games, dtype=np.int32)
+    invalid = np.zeros(games, dtype=np.int32)
+    seed = 5_000_000
+    for g in range(games):
+        state = np.zeros((4, 4), dtype=np.int64)
+        state = ref_board.fill_cells(state=state, number_tile=2, seed=seed)
+        seed += 1
+        steps = 0
+        while not ref_board.is_done(state):
+            new_state, reward = ref_board.next_state(state, int(rng.integers(0, 4)), seed=seed)
+            seed += 1
+            steps += 1
+            invalid[g] += int(new_state is state)
+            total[g] += int(reward)
+            state = new_state
+        length[g] = steps
+        max_tile[g] = int(state.max())
+    np.savez_compressed(OUT / 'random_play_stats.npz', length=length, total_reward=total, max_tile=max_tile, invalid_moves=invalid)
+    return games, float(length.mean()), float(total.mean()), float(invalid.sum() / length.sum())
+
+
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
     rng = np.random.default_rng(20480)
@@ -331,6 +361,7 @@ def main():
     print('resets', gen_resets())
     print('transforms', gen_transforms(rng))
     print('chance_outcomes', gen_chance_outcomes())
+    print('random_play_stats', gen_random_play_stats())
     with open(OUT / 'SHA256SUMS', 'w') as fh:
         for p in sorted(OUT.glob('*.npz')):
             fh.write(f'{hashlib.sha256(p.read_bytes()).hexdigest()}  {p.name}\n')

@@ -705,7 +705,7 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(RolloutArgs a)
                 if (a.reward_rows) __builtin_nontemporal_store((int32_t)reward, &a.reward_rows[at]);
                 if (a.done_rows) __builtin_nontemporal_store((uint8_t)(done ? 1 : 0), &a.done_rows[at]);
             }
-            if (STATS) {
+            if (STATS && cur_len[j] != ENV2048_EPISODE_OVER) {
                 cur_len[j] += 1u;
                 cur_ret[j] += reward;
                 if (done && valid[j]) {  // the game of this board slot ended with this move: bd[j] is its last board
@@ -718,8 +718,10 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(RolloutArgs a)
                     atomicMax(&stats_lds[5], sum);
                     atomicAdd(&stats_lds[6], len * len);
                     atomicAdd(&stats_lds[8u + (max_exponent(bd[j]) & 31u)], 1ull);
-                    cur_len[j] = 0u;
-                    cur_ret[j] = 0ull;
+                    // with auto-reset the slot starts its next game; without, the finished game stays on the board and is
+                    // counted ONCE: the slot is marked over (also across calls, through ep_length)
+                    cur_len[j] = auto_reset ? 0u : ENV2048_EPISODE_OVER;
+                    cur_ret[j] = auto_reset ? 0ull : cur_ret[j];
                 }
             }
         }

@@ -17,7 +17,7 @@ from simulate_2048_amd.trajectory import TrajectoryBuffer
 
 
 @pytest.fixture(params=['host-logic', pytest.param('hip', marks=pytest.mark.gpu)])
-def make_env(request):
+def make_env(request):  # noqa: D103
     if request.param == 'hip':
         return lambda n, seed, **kw: BatchedEnv2048(n, seed, device='cuda:0', **kw)
     return lambda n, seed, **kw: BatchedEnv2048(n, seed, device='cpu', lib=OracleLibrary(), **kw)
@@ -191,6 +191,37 @@ def test_rollout_episode_statistics(make_env):
     plain.reset()
     plain.rollout(400)
     assert torch.equal(plain.boards, env.boards)
+
+
+def test_random_play_distribution_matches_the_reference_engine(make_env, golden):
+    """Distribution-level parity of the STOCHASTIC half (the reference's spawn bitstream cannot be reproduced, its distribution
+    can): 3000 whole games of uniformly random play by the reference engine with its own NumPy RNG
+    (tests/golden/random_play_stats.npz, oracle/gen_golden.py) against first games of this build's Philox-driven play --
+    mean game length, mean total reward (z-tests, |z| < 4.5 with the reference sample's standard error) and the max-tile
+    histogram (chi-square of the reference counts against this build's shares, p > 1e-4).  Also exercises the
+    no-auto-reset form of env2048_rollout_episodes: every environment's game is counted exactly once."""
+    from scipy import stats as scipy_stats
+
+    g = golden['random_play_stats']
+    n = 40_000
+    env = make_env(n, 20481, auto_reset=False)
+    env.reset()
+    block = env.rollout_episodes(900)
+    block = env.rollout_episodes(900, block)  # long enough for every game to end; finished games are not counted twice
+    rep = BatchedEnv2048.episode_statistics(block)
+    assert rep['games'] == n and int((env._ep_length == -1).sum()) == n  # the ENV2048_EPISODE_OVER marker, as int32
+    ref_len, ref_rew = g['length'].astype(np.float64), g['total_reward'].astype(np.float64)
+    z_len = (rep['mean_length'] - ref_len.mean()) / (ref_len.std(ddof=1) / np.sqrt(len(ref_len)))
+    z_rew = (rep['mean_reward'] - ref_rew.mean()) / (ref_rew.std(ddof=1) / np.sqrt(len(ref_rew)))
+    assert abs(z_len) < 4.5 and abs(z_rew) < 4.5, (z_len, z_rew, rep['mean_length'], ref_len.mean())
+    assert abs(rep['std_length'] / ref_len.std(ddof=1) - 1.0) < 0.08 and abs(rep['std_reward'] / ref_rew.std(ddof=1) - 1.0) < 0.08
+    tiles = [32, 64, 128, 256]  # the bins with enough reference games; the rest pooled
+    ours = np.array([rep['max_tile_histogram'].get(t, 0) for t in tiles], dtype=np.float64)
+    ours = np.append(ours, n - ours.sum()) / n
+    theirs = np.array([(g['max_tile'] == t).sum() for t in tiles], dtype=np.float64)
+    theirs = np.append(theirs, len(g['max_tile']) - theirs.sum())
+    chi2 = scipy_stats.chisquare(theirs, ours * theirs.sum())
+    assert chi2.pvalue > 1e-4, (chi2, ours, theirs / theirs.sum())
 
 
 def test_replay_equals_the_same_steps_one_by_one(make_env):
