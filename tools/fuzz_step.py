@@ -19,6 +19,7 @@ lib = capi.library()
 rng = np.random.default_rng(int(time.time()))
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 30.0
 t0, cases, boards_total = time.time(), 0, 0
+last_report = t0
 OBS = [(0, torch.float32), (capi.FLAG_OBS_F16, torch.float16), (capi.FLAG_OBS_BF16, torch.bfloat16)]
 while time.time() - t0 < budget:
     n = int(rng.choice([1, 2, 63, 64, 65, 255, 256, 257, 2047, 2048, 2049, int(rng.integers(1, 40000))]))
@@ -74,4 +75,7 @@ while time.time() - t0 < budget:
         np.testing.assert_array_equal(obs.to(torch.float32).cpu().numpy(), ref['obs'], err_msg=tag)
     cases += 1
     boards_total += n
+    if time.time() - last_report > 30:  # a long run keeps talking (a silent GPU job is taken for hung)
+        last_report = time.time()
+        print(f'fuzz_step: {cases} cases so far, all identical', flush=True)
 print(f'fuzz_step: {cases} random cases, {boards_total} board-steps, all bit-identical to the oracle')
