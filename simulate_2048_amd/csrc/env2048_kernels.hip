@@ -213,9 +213,6 @@ constexpr int word_strip(int bpl)                                               
     return (tile_boards(bpl) + 4 + 4 + tile_boards(bpl) / 4 + 3) / 4 * 4;                // 16 B) + a byte per board, >= 256 words
 }                                                                                        // where the obs transposition uses it
 constexpr int word_strip_words(int bpl) { return word_strip(bpl) < 256 ? 256 : word_strip(bpl); }
-constexpr int TILE_BOARDS = tile_boards(BOARDS_PER_LANE);
-constexpr int BLOCK_BOARDS = block_boards(BOARDS_PER_LANE);
-constexpr int WORD_STRIP = word_strip_words(BOARDS_PER_LANE);
 constexpr uint64_t SMALL_TILING_MAX_BOARDS = 1ull << 18;  // launches up to this size use the BPL = 1 tiling
 
 __constant__ uint32_t DIR_TABLE[32] = {ENV2048_DIR_SELECTOR_VALUES};
@@ -602,9 +599,12 @@ struct RolloutArgs {
 // reward / done of every step are written as rows (6 B per board-step instead of the 38 B of a step launch): T
 // env2048_step calls with staged actions in ONE launch, boards in registers.  Row t+1's action bytes are requested
 // before step t is computed, so their latency hides behind a whole step of arithmetic.
-template <bool STATS, bool REPLAY = false>
+// BPL: boards per lane, as for step_kernel -- 4 for large batches (Philox blocks shared, VALU-bound), 1 up to 2^18
+// environments (four times as many waves: a batch that small leaves most SIMDs idle otherwise).
+template <bool STATS, bool REPLAY = false, int BPL = ENV2048_BOARDS_PER_LANE>
 __global__ __launch_bounds__(BLOCK) void rollout_kernel(RolloutArgs a)
 {
+    constexpr int BOARDS_PER_LANE = BPL, TILE_BOARDS = tile_boards(BPL), WORD_STRIP = word_strip_words(BPL);  // (shadow the globals)
     __shared__ uint4 dir_lds[8];
     __shared__ __attribute__((aligned(16))) uint32_t word_lds[WAVES_PER_BLOCK][WORD_STRIP];
     __shared__ unsigned long long stats_lds[STATS ? ENV2048_ROLLOUT_STATS_WORDS : 1];
@@ -685,7 +685,7 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(RolloutArgs a)
         const RngKey key{a.seed_lo, a.seed_hi, (uint32_t)step, (uint32_t)(step >> 32)};
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // last step's strip reads precede this rewrite
         __builtin_amdgcn_wave_barrier();
-        fill_word_strip(strip, key, env0, lane);
+        fill_word_strip<BPL>(strip, key, env0, lane);
         uint32_t pending = 0u;  // bit j: my board j finished a game this step
 #pragma unroll
         for (int j = 0; j < BOARDS_PER_LANE; ++j) {
@@ -1488,7 +1488,13 @@ int check_count(uint64_t n)
 }
 
 inline dim3 grid_for(uint64_t n) { return dim3((unsigned)((n + BLOCK - 1) / BLOCK)); }
-inline dim3 tile_grid_for(uint64_t n) { return dim3((unsigned)((n + BLOCK_BOARDS - 1) / BLOCK_BOARDS)); }
+inline dim3 rollout_grid(uint64_t n, int bpl) { return dim3((unsigned)((n + block_boards(bpl) - 1) / block_boards(bpl))); }
+constexpr uint64_t ROLLOUT_SMALL_MAX_ENVS = 1ull << 18;  // up to here one board per lane (more waves) beats shared Philox blocks
+                                                          // (512 steps: 0.44-0.87 ms vs 1.29-1.41 ms; at 2^20: 3.04 vs 2.64 ms)
+inline bool rollout_small(uint64_t n, uint32_t flags)
+{
+    return (flags & ENV2048_FLAG_TILE_SMALL) ? true : (flags & ENV2048_FLAG_TILE_LARGE) ? false : n <= ROLLOUT_SMALL_MAX_ENVS;
+}
 
 int launched(const char *what)
 {
@@ -1812,7 +1818,7 @@ int env2048_rollout(int device, void *stream, uint64_t n, uint64_t env_base, uin
                     uint32_t flags)
 {
     if (n == 0) return ENV2048_OK;
-    if (flags & ~(ENV2048_FLAG_AUTO_RESET | ENV2048_FLAG_RANDOM_ACTIONS))
+    if (flags & ~(ENV2048_FLAG_AUTO_RESET | ENV2048_FLAG_RANDOM_ACTIONS | ENV2048_FLAG_TILE_SMALL | ENV2048_FLAG_TILE_LARGE))
         return fail(ENV2048_ERR_INVALID_ARG, "env2048_rollout: unknown flag bits 0x%x", flags);
     if (!boards) return fail(ENV2048_ERR_INVALID_ARG, "env2048_rollout: boards is NULL");
     if (misaligned(boards, 16)) return fail(ENV2048_ERR_ALIGNMENT, "env2048_rollout: boards must be 16-byte aligned");
@@ -1825,7 +1831,10 @@ int env2048_rollout(int device, void *stream, uint64_t n, uint64_t env_base, uin
     if (scope.rc) return scope.rc;
     RolloutArgs a{n, env_base, boards, return_sum, episodes, valid_moves, (uint32_t)seed, (uint32_t)(seed >> 32),
                   step0, T, flags, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
-    hipLaunchKernelGGL(rollout_kernel<false>, tile_grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, a);
+    if (rollout_small(n, flags))
+        hipLaunchKernelGGL((rollout_kernel<false, false, 1>), rollout_grid(n, 1), dim3(BLOCK), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL((rollout_kernel<false, false, BOARDS_PER_LANE>), rollout_grid(n, BOARDS_PER_LANE), dim3(BLOCK), 0, (hipStream_t)stream, a);
     return launched("env2048_rollout launch");
 }
 
@@ -1834,7 +1843,10 @@ int env2048_replay(int device, void *stream, uint64_t n, uint64_t env_base, uint
                    int64_t *return_sum, uint32_t *episodes, uint32_t *valid_moves)
 {
     if (n == 0 || T == 0) return ENV2048_OK;
-    if (flags & ~ENV2048_FLAG_AUTO_RESET) return fail(ENV2048_ERR_INVALID_ARG, "env2048_replay: unknown flag bits 0x%x", flags);
+    if (flags & ~(ENV2048_FLAG_AUTO_RESET | ENV2048_FLAG_TILE_SMALL | ENV2048_FLAG_TILE_LARGE))
+        return fail(ENV2048_ERR_INVALID_ARG, "env2048_replay: unknown flag bits 0x%x", flags);
+    const uint32_t tile_hint = flags & (ENV2048_FLAG_TILE_SMALL | ENV2048_FLAG_TILE_LARGE);
+    flags &= ENV2048_FLAG_AUTO_RESET;
     if (!boards || !actions) return fail(ENV2048_ERR_INVALID_ARG, "env2048_replay: boards and actions are required");
     if (row_stride < n)
         return fail(ENV2048_ERR_INVALID_ARG, "env2048_replay: row_stride %llu is smaller than n = %llu", (unsigned long long)row_stride,
@@ -1851,7 +1863,10 @@ int env2048_replay(int device, void *stream, uint64_t n, uint64_t env_base, uint
         flags |= INTERNAL_FLAG_WIDE_OUTPUTS;  // every row of a full tile can move as dwordx4 / dword per lane
     RolloutArgs a{n, env_base, boards, return_sum, episodes, valid_moves, (uint32_t)seed, (uint32_t)(seed >> 32), step0, T, flags,
                   nullptr, nullptr, nullptr, actions, reward, done, row_stride};
-    hipLaunchKernelGGL((rollout_kernel<false, true>), tile_grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, a);
+    if (rollout_small(n, tile_hint))
+        hipLaunchKernelGGL((rollout_kernel<false, true, 1>), rollout_grid(n, 1), dim3(BLOCK), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL((rollout_kernel<false, true, BOARDS_PER_LANE>), rollout_grid(n, BOARDS_PER_LANE), dim3(BLOCK), 0, (hipStream_t)stream, a);
     return launched("env2048_replay launch");
 }
 
@@ -1859,7 +1874,7 @@ int env2048_rollout_episodes(int device, void *stream, uint64_t n, uint64_t env_
                              uint32_t T, uint32_t flags, uint32_t *ep_length, int64_t *ep_return, uint64_t *stats)
 {
     if (n == 0) return ENV2048_OK;
-    if (flags & ~(ENV2048_FLAG_AUTO_RESET | ENV2048_FLAG_RANDOM_ACTIONS))
+    if (flags & ~(ENV2048_FLAG_AUTO_RESET | ENV2048_FLAG_RANDOM_ACTIONS | ENV2048_FLAG_TILE_SMALL | ENV2048_FLAG_TILE_LARGE))
         return fail(ENV2048_ERR_INVALID_ARG, "env2048_rollout_episodes: unknown flag bits 0x%x", flags);
     if (!boards || !stats) return fail(ENV2048_ERR_INVALID_ARG, "env2048_rollout_episodes: boards and stats are required");
     if (misaligned(boards, 16)) return fail(ENV2048_ERR_ALIGNMENT, "env2048_rollout_episodes: boards must be 16-byte aligned");
@@ -1872,7 +1887,10 @@ int env2048_rollout_episodes(int device, void *stream, uint64_t n, uint64_t env_
     if (scope.rc) return scope.rc;
     RolloutArgs a{n, env_base, boards, nullptr, nullptr, nullptr, (uint32_t)seed, (uint32_t)(seed >> 32), step0, T, flags,
                   ep_length, ep_return, reinterpret_cast<unsigned long long *>(stats), nullptr, nullptr, nullptr, 0};
-    hipLaunchKernelGGL(rollout_kernel<true>, tile_grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, a);
+    if (rollout_small(n, flags))
+        hipLaunchKernelGGL((rollout_kernel<true, false, 1>), rollout_grid(n, 1), dim3(BLOCK), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL((rollout_kernel<true, false, BOARDS_PER_LANE>), rollout_grid(n, BOARDS_PER_LANE), dim3(BLOCK), 0, (hipStream_t)stream, a);
     return launched("env2048_rollout_episodes launch");
 }
 

@@ -116,6 +116,15 @@ def hip_reset(lib, n, seed, step_index, env_base=0):
 
 
 def hip_rollout(lib, boards, seed, step0, T, env_base=0, flags=0):
+    """Both tilings of the rollout kernel (one / four boards per lane) must agree; returns the default-policy result."""
+    outs = [_hip_rollout(lib, boards, seed, step0, T, env_base, flags | tile) for tile in (0, capi.FLAG_TILE_SMALL, capi.FLAG_TILE_LARGE)]
+    for other in outs[1:]:
+        for k in outs[0]:
+            np.testing.assert_array_equal(other[k], outs[0][k], err_msg=f'rollout tilings differ in {k}')
+    return outs[0]
+
+
+def _hip_rollout(lib, boards, seed, step0, T, env_base=0, flags=0):
     n = boards.shape[0]
     b = cu(boards)
     ret = torch.zeros((n,), dtype=torch.int64, device='cuda')

@@ -254,6 +254,21 @@ def test_replay_equals_the_same_steps_one_by_one(make_env):
         assert torch.equal(c.boards, a.boards)
     with pytest.raises(ValueError):
         b.replay(actions[:, :10].contiguous())
+    if a.device.type == 'cuda':  # both tilings of the rollout / replay / statistics kernels give the same results
+        lib, s = a.lib, torch.cuda.current_stream().cuda_stream
+        results = []
+        for tile in (capi.FLAG_TILE_SMALL, capi.FLAG_TILE_LARGE):
+            boards = c.boards.clone()
+            rr = torch.zeros((T, n), dtype=torch.int32, device='cuda')
+            lib.replay(0, s, n, 5, boards.data_ptr(), actions.data_ptr(), rr.data_ptr(), None, n, seed, 0, T, tile, None, None, None)
+            st = torch.zeros((40,), dtype=torch.int64, device='cuda')
+            st[4] = -1
+            b2 = c.boards.clone()
+            lib.rollout_episodes(0, s, n, 5, b2.data_ptr(), seed, 0, 300, 3 | tile, None, None, st.data_ptr())
+            torch.cuda.synchronize()
+            results.append((boards, rr, b2, st))
+        for x, y in zip(*results):
+            assert torch.equal(x, y)
 
 
 @pytest.mark.filterwarnings('ignore:The CUDA Graph is empty')  # the capture that is refused on purpose below
