@@ -225,15 +225,19 @@ def cpu_baseline(boards_np, seconds: float):
 
 def kernel_source_sha() -> str:
     """Hash of what the step kernel is built from: board_ops.hpp and the regions of env2048_kernels.hip between the
-    [step-kernel-source-begin] / [step-kernel-source-end] markers (device code of step_kernel and its host launch policy).
-    Edits to other kernels of the file do not invalidate the committed counters."""
+    [step-kernel-source-begin] / [step-kernel-source-end] markers (device code of step_kernel and its host launch policy),
+    with comments and whitespace removed.  Edits to other kernels of the file, or to comments, do not invalidate the
+    committed counters."""
     import re
 
     h = hashlib.sha256()
     for rel in KERNEL_SOURCES:
         text = (REPO / rel).read_text()
         regions = re.findall(r'\[step-kernel-source-begin\](.*?)\[step-kernel-source-end\]', text, flags=re.S)
-        h.update(''.join(regions).encode() if regions else text.encode())
+        code = ''.join(regions) if regions else text
+        code = re.sub(r'/\*.*?\*/', '', code, flags=re.S)       # block comments
+        code = re.sub(r'//[^\n]*', '', code)                    # line comments (no string literal of these files contains //)
+        h.update(''.join(code.split()).encode())
     return h.hexdigest()[:16]
 
 

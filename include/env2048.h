@@ -77,7 +77,7 @@ extern "C" {
 #define ENV2048_FLAG_STORES_WRITE_THROUGH 16u
 #define ENV2048_FLAG_STORES_WRITE_BACK 32u
 /* env2048_step* only, tuning hints that change no result: the step kernel exists in two tilings -- one board per lane
- * (short dependent chain, eight times as many workgroups: faster up to 2^18 boards per launch, where latency is the
+ * (short dependent chain, four times as many workgroups: faster up to 2^18 boards per launch, where latency is the
  * limit) and four boards per lane (shared Philox blocks, amortised constants: faster above, where instruction issue is
  * the limit).  By default the launch size decides; these two bits override it (they exclude each other).  The rollout /
  * replay / rollout_episodes kernels have the same two tilings (switch at 2^18 environments) and accept the same hints. */

@@ -204,7 +204,7 @@ constexpr int WAVES_PER_BLOCK = BLOCK / 64;
 constexpr int BOARDS_PER_LANE = ENV2048_BOARDS_PER_LANE;  // the large-launch tiling (and the rollout kernels')
 // Tile geometry as a function of the boards each lane handles.  The step kernel exists in two tilings: BPL = 4 (one
 // Philox block feeds four boards of a lane's neighbourhood, constants and selector fetches amortise: best from 2^19
-// boards up, where VALU issue is the limit) and BPL = 1 (a wave's dependent chain is one board long and eight times
+// boards up, where VALU issue is the limit) and BPL = 1 (a wave's dependent chain is one board long and four times
 // as many CUs get work: 4.2 vs 5.2 us per step at 4 096 ... 262 144 boards, where latency is the limit).
 constexpr int tile_boards(int bpl) { return 64 * bpl; }                                  // per wave
 constexpr int block_boards(int bpl) { return tile_boards(bpl) * WAVES_PER_BLOCK; }       // per block
