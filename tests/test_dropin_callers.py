@@ -74,6 +74,9 @@ def test_returns_are_numpy_convertible_device_arrays(api_runtime):
         assert isinstance(host, np.ndarray) and host.shape == tuple(x.shape)
         assert isinstance(x[0], DeviceArray) and np.asarray(x[0]).shape == host.shape[1:]
     assert np.array(states.done).dtype == np.bool_ and np.array(states.board).dtype == np.int32
+    # .dtype answers in both vocabularies (interop.ArrayDType)
+    assert states.board.dtype == np.int32 and states.board.dtype == torch.int32 and states.done.dtype == np.bool_ and states.done.dtype != np.int32
+    assert np.zeros(2, dtype=states.total_reward.dtype).dtype == np.float32 and states.total_reward.dtype.torch is torch.float32
     assert hasattr(states.board, '__dlpack__')
     back = torch.from_dlpack(states.board.as_subclass(torch.Tensor))
     assert back.data_ptr() == states.board.data_ptr()  # zero-copy hand-over of the device buffer

@@ -8,9 +8,9 @@ its own suite cannot tell the difference.
 tests/test_jax_game.py (37 tests of ``reinforce.game``) imports ``jax``, which is not installed here and cannot be.  It is run
 too, against the ``reinforce.game`` mirrors, with a TEST DOUBLE of the few jax / jax.numpy / jax.random names the test file
 itself uses (tests/ref_alias/jax_shim: NumPy underneath, jit = identity, vmap = a loop) -- the engine under test is this
-repo's, never the reference's.  35 of its 37 tests pass; the other two assert ``obs.dtype == jnp.float32`` /
-``mask.dtype == jnp.bool_``: a DeviceArray's ``.dtype`` is a torch dtype (``np.array(x).dtype`` is float32 / bool as the
-caller expects), and that one visible difference is left visible rather than papered over in the double.
+repo's, never the reference's.  All 37 pass, including the two that assert ``obs.dtype == jnp.float32`` /
+``mask.dtype == jnp.bool_`` (a DeviceArray's ``.dtype`` compares equal to the torch AND the NumPy dtype of its elements,
+``interop.ArrayDType``; the double's ``jnp.float32`` is plain ``numpy.float32``, nothing is special-cased there).
 (The same known-answer vectors are also transcribed in tests/test_api_reinforce_game.py, which runs on the GPU box.)
 """
 
@@ -48,8 +48,6 @@ def test_reference_jax_game_suite_on_the_mirrors_with_a_jax_test_double(tmp_path
     proc = subprocess.run(cmd, env=env, cwd=tmp_path, capture_output=True, text=True, timeout=600)
     out = proc.stdout + proc.stderr
     assert 'refalias: reinforce.game.env -> ' + str(REPO / 'simulate_2048_amd') in out, out[-2000:]
-    failed = sorted(set(re.findall(r'^FAILED \S+::(\w+::\w+)', out, flags=re.M)))
+    assert proc.returncode == 0, out[-3000:]
     passed = re.search(r'(\d+) passed', out)
-    assert passed and int(passed.group(1)) >= 35, out[-3000:]
-    assert failed == ['TestEnvironment::test_get_legal_actions', 'TestEnvironment::test_get_observation'], failed  # the dtype-object identity
-    assert out.count('.dtype == jnp.') >= 2  # ... and for exactly that reason
+    assert passed and int(passed.group(1)) >= 37 and 'failed' not in out.splitlines()[-1], out[-1500:]
