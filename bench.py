@@ -632,6 +632,29 @@ def other_configs(torch, lib, device, device_index, h) -> dict:
     from simulate_2048_amd.batch import BatchedEnv2048
 
     out = {}
+    # configs[0]: one board, 1000 random-action steps through the TwentyFortyEight env API (reset on done) -- the mirror runs
+    # every step as one kernel launch on pinned host operands + one stream synchronisation
+    import numpy as np
+
+    from simulate_2048_amd.twentyfortyeight.envs.twentyfortyeight import TwentyFortyEight
+
+    single = TwentyFortyEight()
+    single.reset(seed=0)
+    picks = np.random.default_rng(0).integers(0, 4, 1000)
+    for a in picks[:50]:
+        single.step(int(a))
+    t0 = time.perf_counter()
+    for a in picks:
+        _, _, finished = single.step(int(a))
+        if finished:
+            single.reset()
+    dt = time.perf_counter() - t0
+    out['configs[0]'] = {
+        'workload': 'single 4x4 board, 1000 random-action steps via the TwentyFortyEight env API (mirror on the GPU: one launch on pinned '
+                    'host operands + one synchronisation per step)',
+        'value': 1000 / dt, 'unit': 'board-steps/s', 'us_per_step': dt * 1e3,
+        'reference': 'the reference NumPy env: 9.5-10.2e3 steps/s on one core of the build container (BASELINE.md section 2)',
+    }
     # configs[1]
     n1 = 1 << 16
     env = BatchedEnv2048(n1, SEED, device=device, auto_reset=True)
