@@ -56,7 +56,7 @@ extern "C" {
 #define ENV2048_EXPORT
 #endif
 
-#define ENV2048_ABI_VERSION 2
+#define ENV2048_ABI_VERSION 3
 
 #define ENV2048_OK 0
 #define ENV2048_ERR_INVALID_ARG (-1) /* NULL required pointer, bad flag bits */
@@ -130,11 +130,24 @@ ENV2048_EXPORT int env2048_step(int device, void *stream, uint64_t n, uint64_t e
                  uint64_t seed, uint64_t step_index, uint32_t flags);
 
 /*
- * Several step launches enqueued by ONE call, in order, on `stream` -- for callers whose per-call host cost
- * (argument marshalling, device selection) would otherwise rival the 8-microsecond kernel: replaying staged
- * actions, stepping several independent batches, rotating buffer sets.  Every record is one env2048_step call
- * with the same meaning and the same checks; all records are validated before the first launch, so a failing
- * call has enqueued nothing.  `reserved` must be 0.
+ * Several steps enqueued by ONE call on `stream`, with the RESULT of executing the records in order -- for callers whose
+ * per-call host cost (argument marshalling, device selection) would otherwise rival the 8-microsecond kernel: replaying
+ * staged actions, stepping several independent batches, rotating buffer sets.  Every record is one env2048_step call with
+ * the same meaning and the same checks; all records are validated before the first launch, so a failing call has enqueued
+ * nothing.  `reserved` must be 0.
+ *
+ * Independent records share a launch.  Two records depend on each other iff one WRITES bytes the other reads or writes
+ * (boards: read + written; actions: read; reward / done / legal / obs / max_exp: written).  A run of consecutive records
+ * that are pairwise independent -- disjoint batches -- yields the same bytes in any order, so the library enqueues it as
+ * ONE kernel launch whose workgroups walk the records one after the other (at most 32 records per launch; the records must
+ * also want the same outputs kind -- plain vs legal/obs/max_exp/normalised reward --, the same action source and the same
+ * tiling hint, sizes within 2x of each other, and none may use `step_counter`).  No kernel boundary separates those
+ * batches, so the stores of one overlap the loads of the next: batches that do not live in the 256 MiB Infinity Cache
+ * run at the memory floor of the access pattern instead of paying a pipeline fill and drain per launch, and small batches
+ * stop being bound by the launch rate.  Dependent records (the same boards stepped K times) are launched one by one, in
+ * order, as before.  The decision depends on the records alone (addresses, sizes, flags); env2048_step_many_plan reports
+ * it.  Tiling and store policy of a shared launch follow the size rules of env2048_step applied to the launch's TOTAL
+ * board count.
  */
 typedef struct env2048_step_args {
     uint64_t n, env_base;
@@ -157,6 +170,22 @@ typedef struct env2048_step_args {
                                step instead of the 3-4 us of host launch cost. */
 } env2048_step_args;
 ENV2048_EXPORT int env2048_step_many(int device, void *stream, uint64_t count, const env2048_step_args *args);
+
+/*
+ * How env2048_step would run a launch of n boards with these flags: boards_per_lane (1 = the small tiling, 4 = the large
+ * one) and write_through (1 = write-through stores, 0 = write-back), each may be NULL.  No device is touched.
+ * [no reference counterpart: launch policy of this build, exposed so that callers and benchmarks need not restate it]
+ */
+ENV2048_EXPORT int env2048_step_plan(uint64_t n, uint32_t flags, int32_t *boards_per_lane, int32_t *write_through);
+
+/*
+ * How env2048_step_many would run these records: launch_of[k] = index of the kernel launch record k goes out with
+ * (records with equal values share one launch; required, `count` entries), and per record the tiling / store policy of
+ * that launch (each may be NULL).  Returns the number of launches (>= 0) or a negative error code; validates the records
+ * exactly like env2048_step_many and touches no device.
+ */
+ENV2048_EXPORT int env2048_step_many_plan(uint64_t count, const env2048_step_args *args, uint32_t *launch_of, int32_t *boards_per_lane,
+                                          int32_t *write_through);
 /* *counter += delta on `stream` (one thread): the node that ends a captured graph of step_counter launches. */
 ENV2048_EXPORT int env2048_advance_counter(int device, void *stream, uint64_t *counter, uint64_t delta);
 

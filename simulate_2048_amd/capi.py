@@ -12,7 +12,7 @@ from __future__ import annotations
 import ctypes
 from pathlib import Path
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 OK = 0
 ERR_INVALID_ARG = -1
@@ -67,6 +67,9 @@ PROTOTYPES = {
     'env2048_reset': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _ptr, _u64, _u64]),
     'env2048_step': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _u64, _u64, _u32]),
     'env2048_step_many': (_c_int, [_c_int, _ptr, _u64, ctypes.POINTER(StepArgs)]),
+    'env2048_step_plan': (_c_int, [_u64, _u32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
+    'env2048_step_many_plan': (_c_int, [_u64, ctypes.POINTER(StepArgs), ctypes.POINTER(_u32), ctypes.POINTER(ctypes.c_int32),
+                                        ctypes.POINTER(ctypes.c_int32)]),
     'env2048_advance_counter': (_c_int, [_c_int, _ptr, _ptr, _u64]),
     'env2048_step_sequence': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, ctypes.POINTER(_ptr), _ptr, _ptr, _ptr, _ptr, _u64, _u64, _u64,
                                         _u32, _u32]),
@@ -154,6 +157,24 @@ class Library:
     def step_many(self, device, stream, records) -> None:
         """``records``: a ctypes array of StepArgs (build it once with ``(StepArgs * k)(...)`` and reuse it)."""
         self._check(self._dll.env2048_step_many(device, stream, len(records), records))
+
+    def step_plan(self, n: int, flags: int = 0) -> dict:
+        """How env2048_step would launch n boards: {'boards_per_lane': 1 | 4, 'write_through': bool}. No device needed."""
+        bpl, through = ctypes.c_int32(), ctypes.c_int32()
+        self._check(self._dll.env2048_step_plan(n, flags, ctypes.byref(bpl), ctypes.byref(through)))
+        return {'boards_per_lane': bpl.value, 'write_through': bool(through.value)}
+
+    def step_many_plan(self, records) -> dict:
+        """How env2048_step_many would run ``records``: {'launches': L, 'launch_of': [...], 'boards_per_lane': [...],
+        'write_through': [...]} -- records with the same ``launch_of`` value share one kernel launch. No device needed."""
+        count = len(records)
+        launch_of = (_u32 * count)()
+        bpl = (ctypes.c_int32 * count)()
+        through = (ctypes.c_int32 * count)()
+        rc = self._dll.env2048_step_many_plan(count, records, launch_of, bpl, through)
+        if rc < 0:
+            raise Env2048Error(rc, self.last_error())
+        return {'launches': rc, 'launch_of': list(launch_of), 'boards_per_lane': list(bpl), 'write_through': [bool(x) for x in through]}
 
     def advance_counter(self, device, stream, counter, delta) -> None:
         self._check(self._dll.env2048_advance_counter(device, stream, counter, delta))

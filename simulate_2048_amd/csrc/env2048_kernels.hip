@@ -323,7 +323,7 @@ __device__ __forceinline__ void step_block(const StepArgs &a, uint4 *dir_lds, ui
     const bool auto_reset = (a.flags & ENV2048_FLAG_AUTO_RESET) != 0u;
     const bool through = (a.flags & INTERNAL_FLAG_WRITE_THROUGH) != 0u;
     // the LDS transposition of reward/done only pays together with write-through stores (measured)
-    const bool wide_outputs = through && FULL && BOARDS_PER_LANE == 4 && (a.flags & INTERNAL_FLAG_WIDE_OUTPUTS) != 0u;
+    const bool wide_outputs = through && FULL && BOARDS_PER_LANE >= 2 && (a.flags & INTERNAL_FLAG_WIDE_OUTPUTS) != 0u;
 
 #ifdef ENV2048_EXP_STAMPS  // diagnostic build: wave timeline stamps into the (otherwise unused) obs buffer
     uint64_t stamp0 = __builtin_amdgcn_s_memrealtime(), stamp1 = 0, stamp2 = 0, stamp3 = 0, stamp4 = 0;
@@ -477,10 +477,12 @@ __device__ __forceinline__ void step_block(const StepArgs &a, uint4 *dir_lds, ui
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const uint4 r4 = reinterpret_cast<const uint4 *>(strip)[lane];
-        const uint32_t d4 = reinterpret_cast<const uint32_t *>(done_bytes)[lane];
-        if (a.reward) store_x4_through(a.reward + tile0 + 4u * lane, u32x4{r4.x, r4.y, r4.z, r4.w});
-        store_x1_through(a.done + tile0 + 4u * lane, d4);
+        if (BOARDS_PER_LANE == 4 || lane < (uint32_t)TILE_BOARDS / 4u) {  // (with two boards per lane the first 32 lanes carry the tile)
+            const uint4 r4 = reinterpret_cast<const uint4 *>(strip)[lane];
+            const uint32_t d4 = reinterpret_cast<const uint32_t *>(done_bytes)[lane];
+            if (a.reward) store_x4_through(a.reward + tile0 + 4u * lane, u32x4{r4.x, r4.y, r4.z, r4.w});
+            store_x1_through(a.done + tile0 + 4u * lane, d4);
+        }
     }
 #endif
 #ifdef ENV2048_EXP_STAMPS
@@ -541,6 +543,48 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(uint8_t *boards, const uint
     __shared__ uint16_t reset_slot[block_boards(BPL)];
     const uint64_t block0 = (uint64_t)blockIdx.x * block_boards(BPL);
     if (block0 + block_boards(BPL) <= a.n)  // block-uniform: every block but the last takes the unchecked path
+        step_block<EXTRAS, true, RANDOM, BPL>(a, dir_lds, word_lds, &queue_state, reset_slot);
+    else
+        step_block<EXTRAS, false, RANDOM, BPL>(a, dir_lds, word_lds, &queue_state, reset_slot);
+}
+
+// Several mutually INDEPENDENT step launches as ONE launch (env2048_step_many groups them on the host): blockIdx.y picks the
+// record, blockIdx.x the block inside it -- the dispatcher hands out x fastest, so the records stream through the chip one
+// after the other with no kernel boundary between them: the stores of record k drain while record k+1 computes and the
+// loads of record k+2 are already in flight.  That is what a dependent chain of launches cannot have (every launch there is
+// load-everything -> compute -> store-everything -> boundary), and it is what brings batches that do NOT live in the
+// Infinity Cache from 0.45 to the memory-only floor of the access pattern.  The record table travels in the kernel
+// argument block (96 B per record, read with scalar loads at a wave-uniform offset); the per-block code is step_block,
+// unchanged, so results are bit-identical to the separate launches.
+struct FusedRecord {
+    uint8_t *boards;
+    const uint8_t *actions;
+    uint64_t n, env_base;
+    uint32_t flags, seed_lo, seed_hi, step_lo, step_hi, blocks;
+    int32_t *reward;
+    uint8_t *done;
+    uint8_t *legal;
+    void *obs;
+    uint8_t *max_exp;
+};
+constexpr int MAX_FUSED_RECORDS = 32;  // 32 x 96 B = 3 KiB of the 4 KiB argument block
+struct FusedTable {
+    FusedRecord rec[MAX_FUSED_RECORDS];
+};
+
+template <bool EXTRAS, bool RANDOM, int BPL>
+__global__ __launch_bounds__(BLOCK) void step_many_kernel(const FusedTable table)
+{
+    const FusedRecord &r = table.rec[blockIdx.y];
+    if (blockIdx.x >= r.blocks) return;  // the records of a group may differ in size: surplus blocks retire at once
+    const StepArgs a{r.n, r.env_base, r.boards, r.actions, r.reward, r.done, r.legal, r.obs, RngKey{r.seed_lo, r.seed_hi, r.step_lo, r.step_hi},
+                     r.flags, r.max_exp};
+    __shared__ uint4 dir_lds[8];
+    __shared__ __attribute__((aligned(16))) uint32_t word_lds[WAVES_PER_BLOCK][word_strip_words(BPL)];
+    __shared__ uint32_t queue_state;
+    __shared__ uint16_t reset_slot[block_boards(BPL)];
+    const uint64_t block0 = (uint64_t)blockIdx.x * block_boards(BPL);
+    if (block0 + block_boards(BPL) <= a.n)
         step_block<EXTRAS, true, RANDOM, BPL>(a, dir_lds, word_lds, &queue_state, reset_slot);
     else
         step_block<EXTRAS, false, RANDOM, BPL>(a, dir_lds, word_lds, &queue_state, reset_slot);
@@ -1579,6 +1623,230 @@ void launch_step(const env2048_step_args &a, hipStream_t stream)
         ENV2048_LAUNCH_STEP(false, false);
 #undef ENV2048_LAUNCH_STEP
 }
+
+// ---- env2048_step_many: records that do not depend on each other become ONE launch ---------------------------------------
+// The call's contract is "the records, in order".  Two records depend on each other iff one WRITES memory the other reads or
+// writes (boards are read and written; actions are read; reward / done / legal / obs / max_exp are written); records that
+// touch disjoint memory give the same bytes in any order, so a run of consecutive, pairwise independent records may execute
+// concurrently -- as one step_many_kernel launch.  The policy is a function of the argument records alone (addresses, sizes,
+// flags): no caller hint, no environment variable, no timing.
+struct MemRange {
+    uintptr_t lo, hi;
+    uint32_t record;
+    bool write;
+};
+
+inline int record_ranges(const env2048_step_args &a, uint32_t record, MemRange *out)
+{
+    int c = 0;
+    auto add = [&](const void *p, uint64_t bytes, bool write) {
+        if (p && bytes) out[c++] = MemRange{reinterpret_cast<uintptr_t>(p), reinterpret_cast<uintptr_t>(p) + bytes, record, write};
+    };
+    add(a.boards, 16 * a.n, true);
+    if (!(a.flags & ENV2048_FLAG_RANDOM_ACTIONS)) add(a.actions, a.n, false);
+    add(a.reward, 4 * a.n, true);
+    add(a.done, a.n, true);
+    add(a.legal, a.n, true);
+    add(a.obs, a.n * 16u * (obs_format(a.flags) == OBS_F32 ? 4u : 2u), true);
+    add(a.max_exp, a.n, true);
+    return c;
+}
+
+// A set of byte ranges kept as sorted, pairwise disjoint intervals (overlapping or touching insertions are merged), so that
+// "does [lo, hi) meet the set" is one binary search.  Fixed capacity: a group has at most MAX_FUSED_RECORDS x 7 ranges.
+struct IntervalSet {
+    static constexpr int CAP = MAX_FUSED_RECORDS * 7;
+    uintptr_t lo[CAP], hi[CAP];
+    int n = 0;
+    int first_ending_after(uintptr_t x) const  // smallest i with hi[i] > x (hi is sorted because the intervals are disjoint)
+    {
+        int a = 0, b = n;
+        while (a < b) {
+            const int m = (a + b) / 2;
+            if (hi[m] > x)
+                b = m;
+            else
+                a = m + 1;
+        }
+        return a;
+    }
+    bool meets(uintptr_t l, uintptr_t h) const
+    {
+        const int i = first_ending_after(l);
+        return i < n && lo[i] < h;
+    }
+    void insert(uintptr_t l, uintptr_t h)
+    {
+        int i = first_ending_after(l);
+        int j = i;  // intervals [i, j) overlap [l, h): swallow them
+        while (j < n && lo[j] < h) {
+            l = lo[j] < l ? lo[j] : l;
+            h = hi[j] > h ? hi[j] : h;
+            ++j;
+        }
+        if (j == i) {  // nothing swallowed: open a slot
+            for (int k = n; k > i; --k) {
+                lo[k] = lo[k - 1];
+                hi[k] = hi[k - 1];
+            }
+            ++n;
+        } else if (j > i + 1) {  // several swallowed: close the gap
+            const int drop = j - i - 1;
+            for (int k = i + 1; k + drop < n; ++k) {
+                lo[k] = lo[k + drop];
+                hi[k] = hi[k + drop];
+            }
+            n -= drop;
+        }
+        lo[i] = l;
+        hi[i] = h;
+    }
+};
+
+struct StepVariant {
+    bool extras, random_actions;
+    bool operator==(const StepVariant &o) const { return extras == o.extras && random_actions == o.random_actions; }
+};
+
+inline StepVariant variant_of(const env2048_step_args &a)
+{
+    return StepVariant{a.legal || a.obs || a.max_exp || (a.flags & ENV2048_FLAG_REWARD_LOG2_F32) != 0u, (a.flags & ENV2048_FLAG_RANDOM_ACTIONS) != 0u};
+}
+
+// Tiling and store policy of a launch over `total` boards (one record, or all records of a fused group together).
+inline bool plan_small_tiling(uint64_t total, uint32_t flags)
+{
+    return (flags & ENV2048_FLAG_TILE_SMALL) ? true : (flags & ENV2048_FLAG_TILE_LARGE) ? false : total <= SMALL_TILING_MAX_BOARDS;
+}
+inline bool plan_write_through(uint64_t total, uint32_t flags)
+{
+    return (flags & ENV2048_FLAG_STORES_WRITE_THROUGH) ? true : (flags & ENV2048_FLAG_STORES_WRITE_BACK) ? false : total <= WRITE_THROUGH_MAX_BOARDS;
+}
+
+// group[k] = index of the launch record k belongs to (consecutive records with the same index form one fused launch; a group
+// of one is an ordinary env2048_step launch); returns the number of launches.  Greedy and order-preserving: a record joins the
+// running group iff it is independent of every member, asks for the same kernel variant and tiling, does not read its step
+// index from device memory, and the group stays within the argument-block table and within 2x of its smallest member's
+// block count (surplus blocks of a ragged 2-D grid are cheap, not free).
+uint64_t plan_groups(uint64_t count, const env2048_step_args *args, uint32_t *group)
+{
+    uint64_t launches = 0, k = 0;
+    IntervalSet written, read;  // what the running group's members write / only read
+    MemRange ranges[7];
+    auto join = [&](const env2048_step_args &a, bool check) {
+        const int c = record_ranges(a, 0, ranges);
+        if (check)
+            for (int i = 0; i < c; ++i)
+                if (written.meets(ranges[i].lo, ranges[i].hi) || (ranges[i].write && read.meets(ranges[i].lo, ranges[i].hi))) return false;
+        for (int i = 0; i < c; ++i) (ranges[i].write ? written : read).insert(ranges[i].lo, ranges[i].hi);
+        return true;
+    };
+    while (k < count) {
+        if (args[k].n == 0) {  // enqueues nothing; rides along with whatever comes next
+            group[k++] = (uint32_t)launches;
+            continue;
+        }
+        const StepVariant variant = variant_of(args[k]);
+        const uint32_t tile_hint = args[k].flags & (ENV2048_FLAG_TILE_SMALL | ENV2048_FLAG_TILE_LARGE);
+        uint64_t lo_n = args[k].n, hi_n = args[k].n;
+        int members = 0;
+        if (!args[k].step_counter) {
+            written.n = read.n = 0;
+            join(args[k], false);
+            members = 1;
+        }
+        group[k++] = (uint32_t)launches;
+        while (members && members < MAX_FUSED_RECORDS && k < count) {
+            const env2048_step_args &a = args[k];
+            if (a.n == 0 || a.step_counter || !(variant_of(a) == variant) ||
+                (a.flags & (ENV2048_FLAG_TILE_SMALL | ENV2048_FLAG_TILE_LARGE)) != tile_hint)
+                break;
+            const uint64_t new_lo = a.n < lo_n ? a.n : lo_n, new_hi = a.n > hi_n ? a.n : hi_n;
+            if (new_hi > 2 * new_lo && new_hi > (uint64_t)block_boards(1)) break;  // ragged beyond 2x (sizes within one block never are)
+            if (!join(a, true)) break;  // it reads or writes what a member writes, or writes what a member reads: a new launch
+            lo_n = new_lo;
+            hi_n = new_hi;
+            ++members;
+            group[k++] = (uint32_t)launches;
+        }
+        ++launches;
+    }
+    return launches;
+}
+
+// The launches of an env2048_step_many call, in order: fn(first, last, live, total) for every group of records [first, last)
+// that goes out together (live = records with n > 0, total = their boards).  Planning runs over windows of
+// 2 x MAX_FUSED_RECORDS records so that its state stays on the stack; a group cut by the end of a window is planned again
+// with the next window, so a long run of independent records is only ever cut where a full table ends.
+template <typename Fn>
+void for_each_launch(uint64_t count, const env2048_step_args *args, Fn fn)
+{
+    constexpr uint64_t WINDOW = 2 * MAX_FUSED_RECORDS;
+    uint32_t group[WINDOW];
+    for (uint64_t base = 0; base < count;) {
+        const uint64_t window = count - base < WINDOW ? count - base : WINDOW;
+        plan_groups(window, args + base, group);
+        uint64_t take = window;
+        if (base + window < count) {  // (a full window holds at least two groups: a group has at most MAX_FUSED_RECORDS members)
+            while (take > 0 && group[take - 1] == group[window - 1]) --take;
+        }
+        for (uint64_t k = 0; k < take;) {
+            uint64_t e = k + 1, live = 0, total = 0;
+            while (e < take && group[e] == group[k]) ++e;
+            for (uint64_t r = k; r < e; ++r) {
+                live += args[base + r].n ? 1u : 0u;
+                total += args[base + r].n;
+            }
+            fn(base + k, base + e, live, total);
+            k = e;
+        }
+        base += take;
+    }
+}
+
+// Enqueue records [first, last) -- pairwise independent, same variant -- as one step_many_kernel launch.
+void launch_group(const env2048_step_args *args, uint64_t first, uint64_t last, hipStream_t stream)
+{
+    uint64_t total = 0;
+    for (uint64_t k = first; k < last; ++k) total += args[k].n;
+    while (first < last && args[first].n == 0) ++first;  // (an empty record may lead the group: it decides nothing)
+    if (first == last) return;
+    const bool small = plan_small_tiling(total, args[first].flags);
+    const int bpl = small ? 1 : BOARDS_PER_LANE;
+    FusedTable table;
+    uint32_t max_blocks = 0, records = 0;
+    for (uint64_t k = first; k < last; ++k) {
+        const env2048_step_args &a = args[k];
+        if (a.n == 0) continue;
+        uint32_t kernel_flags = a.flags & ~(ENV2048_FLAG_STORES_WRITE_THROUGH | ENV2048_FLAG_STORES_WRITE_BACK | ENV2048_FLAG_TILE_SMALL |
+                                            ENV2048_FLAG_TILE_LARGE);
+        if (!misaligned(a.reward, 16) && !misaligned(a.done, 4)) kernel_flags |= INTERNAL_FLAG_WIDE_OUTPUTS;
+        if (plan_write_through(total, a.flags)) kernel_flags |= INTERNAL_FLAG_WRITE_THROUGH;
+        const uint32_t blocks = (uint32_t)((a.n + block_boards(bpl) - 1) / block_boards(bpl));
+        max_blocks = blocks > max_blocks ? blocks : max_blocks;
+        table.rec[records++] = FusedRecord{a.boards, a.actions, a.n, a.env_base, kernel_flags, (uint32_t)a.seed, (uint32_t)(a.seed >> 32),
+                                           (uint32_t)a.step_index, (uint32_t)(a.step_index >> 32), blocks, a.reward, a.done, a.legal, a.obs,
+                                           a.max_exp};
+    }
+    const StepVariant v = variant_of(args[first]);
+    const dim3 grid(max_blocks, records), block(BLOCK);
+#define ENV2048_LAUNCH_MANY(EXTRAS, RANDOM)                                                                         \
+    do {                                                                                                            \
+        if (small)                                                                                                  \
+            hipLaunchKernelGGL((step_many_kernel<EXTRAS, RANDOM, 1>), grid, block, 0, stream, table);               \
+        else                                                                                                        \
+            hipLaunchKernelGGL((step_many_kernel<EXTRAS, RANDOM, BOARDS_PER_LANE>), grid, block, 0, stream, table); \
+    } while (0)
+    if (v.extras && v.random_actions)
+        ENV2048_LAUNCH_MANY(true, true);
+    else if (v.extras)
+        ENV2048_LAUNCH_MANY(true, false);
+    else if (v.random_actions)
+        ENV2048_LAUNCH_MANY(false, true);
+    else
+        ENV2048_LAUNCH_MANY(false, false);
+#undef ENV2048_LAUNCH_MANY
+}
 // [step-kernel-source-end]
 
 }  // namespace
@@ -1644,9 +1912,42 @@ int env2048_step_many(int device, void *stream, uint64_t count, const env2048_st
         if (int rc = validate_step(args[k], "env2048_step_many")) return rc;
     DeviceScope scope(device);
     if (scope.rc) return scope.rc;
-    for (uint64_t k = 0; k < count; ++k)
-        if (args[k].n) launch_step(args[k], (hipStream_t)stream);
+    for_each_launch(count, args, [&](uint64_t first, uint64_t last, uint64_t live, uint64_t) {
+        if (live == 1) {
+            for (uint64_t r = first; r < last; ++r)
+                if (args[r].n) launch_step(args[r], (hipStream_t)stream);
+        } else if (live > 1) {
+            launch_group(args, first, last, (hipStream_t)stream);
+        }
+    });
     return launched("env2048_step_many launch");
+}
+
+int env2048_step_plan(uint64_t n, uint32_t flags, int32_t *boards_per_lane, int32_t *write_through)
+{
+    if (flags & ~STEP_FLAGS) return fail(ENV2048_ERR_INVALID_ARG, "env2048_step_plan: unknown flag bits 0x%x", flags);
+    if (boards_per_lane) *boards_per_lane = plan_small_tiling(n, flags) ? 1 : BOARDS_PER_LANE;
+    if (write_through) *write_through = plan_write_through(n, flags) ? 1 : 0;
+    return ENV2048_OK;
+}
+
+int env2048_step_many_plan(uint64_t count, const env2048_step_args *args, uint32_t *launch_of, int32_t *boards_per_lane,
+                           int32_t *write_through)
+{
+    if (count == 0) return 0;
+    if (!args || !launch_of) return fail(ENV2048_ERR_INVALID_ARG, "env2048_step_many_plan: args and launch_of are required");
+    for (uint64_t k = 0; k < count; ++k)
+        if (int rc = validate_step(args[k], "env2048_step_many_plan")) return rc;
+    uint32_t launches = 0;
+    for_each_launch(count, args, [&](uint64_t first, uint64_t last, uint64_t live, uint64_t total) {
+        for (uint64_t r = first; r < last; ++r) {
+            launch_of[r] = launches;
+            if (boards_per_lane) boards_per_lane[r] = plan_small_tiling(total, args[last - 1].flags) ? 1 : BOARDS_PER_LANE;
+            if (write_through) write_through[r] = plan_write_through(total, args[r].flags) ? 1 : 0;
+        }
+        if (live) ++launches;
+    });
+    return (int)launches;
 }
 
 int env2048_step_sequence(int device, void *stream, uint64_t n, uint64_t env_base, uint8_t *boards,

@@ -3,7 +3,9 @@ Array interchange at the edge of the API mirrors, so that the reference's caller
 (reinforce/training/self_play.py:298-300,316-317,346-356,374-375 and reinforce/evaluate.py:89-128):
 
 * what the mirrors RETURN is a ``DeviceArray`` -- a ``torch.Tensor`` (same storage, still on the GPU, every torch
-  operation works and yields DeviceArrays again) that NumPy can swallow: ``np.array(x)`` / ``np.asarray(x)`` make ONE
+  operation works and yields DeviceArrays again; ``.dtype`` is the real ``torch.dtype``, so ``torch.zeros(n, dtype=x.dtype)``,
+  ``y.to(x.dtype)``, ``torch.finfo(x.dtype)`` and dtype-keyed dicts behave as for any tensor -- NumPy-side questions are
+  answered by ``np.array(x).dtype``) that NumPy can swallow: ``np.array(x)`` / ``np.asarray(x)`` make ONE
   device-to-host copy, which is what the caller's ``np.array(observations)`` etc. mean on a JAX array too.
   ``__dlpack__`` (inherited from torch) hands the device buffer to any DLPack consumer (JAX on ROCm, CuPy, torch)
   without a copy; ``bool() / int() / float()`` read a scalar back as on a JAX array.
@@ -17,62 +19,8 @@ import numpy as np
 import torch
 
 
-_NUMPY_OF = {torch.float32: 'float32', torch.float64: 'float64', torch.float16: 'float16', torch.bool: 'bool', torch.uint8: 'uint8',
-             torch.int8: 'int8', torch.int16: 'int16', torch.int32: 'int32', torch.int64: 'int64'}
-
-
-class ArrayDType:
-    """What ``DeviceArray.dtype`` returns: ONE object that is equal to the torch dtype AND to the NumPy dtype / scalar type of
-    the same element type, so that both worlds' idioms work on a returned array -- ``x.dtype == torch.float32`` and
-    ``x.dtype == np.float32`` / ``== jnp.float32`` (what the reference's callers and tests write) are all True, and
-    ``np.zeros(n, dtype=x.dtype)`` works (NumPy's ``.dtype`` attribute protocol).  Attributes resolve on the torch dtype first
-    (``is_floating_point``, ``itemsize``, ...), then on the NumPy dtype (``kind``, ``name``, ...).  Pass ``x.dtype.torch`` where
-    a torch function needs a dtype argument."""
-
-    __slots__ = ('torch', 'numpy')
-
-    def __init__(self, torch_dtype):
-        self.torch = torch_dtype
-        self.numpy = np.dtype(_NUMPY_OF[torch_dtype])
-
-    @property
-    def dtype(self):  # NumPy's protocol: np.dtype(obj) takes obj.dtype
-        return self.numpy
-
-    def __eq__(self, other):
-        if isinstance(other, ArrayDType):
-            return self.torch == other.torch
-        if isinstance(other, torch.dtype):
-            return self.torch == other
-        try:
-            return self.numpy == np.dtype(other)
-        except TypeError:
-            return NotImplemented
-
-    def __ne__(self, other):
-        result = self.__eq__(other)
-        return result if result is NotImplemented else not result
-
-    def __hash__(self):
-        return hash(self.numpy)
-
-    def __getattr__(self, name):
-        try:
-            return getattr(object.__getattribute__(self, 'torch'), name)
-        except AttributeError:
-            return getattr(object.__getattribute__(self, 'numpy'), name)
-
-    def __repr__(self):
-        return f'{self.torch}'
-
-
 class DeviceArray(torch.Tensor):
     """A torch tensor (usually on the GPU) that converts to NumPy on demand -- see the module docstring."""
-
-    @property
-    def dtype(self):
-        real = torch.Tensor.dtype.__get__(self)
-        return ArrayDType(real) if real in _NUMPY_OF else real  # (bfloat16 has no NumPy counterpart: the torch dtype itself)
 
     def __deepcopy__(self, memo):
         return self.as_subclass(torch.Tensor).clone().as_subclass(DeviceArray)
@@ -86,8 +34,6 @@ class DeviceArray(torch.Tensor):
 
     def __array__(self, dtype=None, copy=None):
         plain = self.as_subclass(torch.Tensor).detach()
-        if isinstance(dtype, ArrayDType):
-            dtype = dtype.numpy
         if plain.dtype == torch.bfloat16:  # NumPy has no bfloat16: widen (exact)
             plain = plain.to(torch.float32)
         host = plain.cpu().numpy()

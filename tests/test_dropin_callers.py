@@ -74,9 +74,14 @@ def test_returns_are_numpy_convertible_device_arrays(api_runtime):
         assert isinstance(host, np.ndarray) and host.shape == tuple(x.shape)
         assert isinstance(x[0], DeviceArray) and np.asarray(x[0]).shape == host.shape[1:]
     assert np.array(states.done).dtype == np.bool_ and np.array(states.board).dtype == np.int32
-    # .dtype answers in both vocabularies (interop.ArrayDType)
-    assert states.board.dtype == np.int32 and states.board.dtype == torch.int32 and states.done.dtype == np.bool_ and states.done.dtype != np.int32
-    assert np.zeros(2, dtype=states.total_reward.dtype).dtype == np.float32 and states.total_reward.dtype.torch is torch.float32
+    # .dtype is the real torch.dtype: every torch consumer of a returned array works unchanged
+    obs = batched_get_observation(states)
+    for x, want in ((states.board, torch.int32), (states.done, torch.bool), (states.step_count, torch.int32),
+                    (states.total_reward, torch.float32), (obs, torch.float32), (batched_get_legal_actions(states), torch.bool)):
+        assert type(x.dtype) is torch.dtype and x.dtype is want and x.dtype in {want} and {want: 1}.get(x.dtype) == 1
+        assert torch.zeros(1, dtype=x.dtype).dtype is want and torch.ones(2).to(x.dtype).dtype is want
+        assert torch.promote_types(x.dtype, x.dtype) is want
+    assert torch.finfo(obs.dtype).bits == 32 and torch.iinfo(states.board.dtype).bits == 32
     assert hasattr(states.board, '__dlpack__')
     back = torch.from_dlpack(states.board.as_subclass(torch.Tensor))
     assert back.data_ptr() == states.board.data_ptr()  # zero-copy hand-over of the device buffer

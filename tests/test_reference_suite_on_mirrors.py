@@ -8,9 +8,10 @@ its own suite cannot tell the difference.
 tests/test_jax_game.py (37 tests of ``reinforce.game``) imports ``jax``, which is not installed here and cannot be.  It is run
 too, against the ``reinforce.game`` mirrors, with a TEST DOUBLE of the few jax / jax.numpy / jax.random names the test file
 itself uses (tests/ref_alias/jax_shim: NumPy underneath, jit = identity, vmap = a loop) -- the engine under test is this
-repo's, never the reference's.  All 37 pass, including the two that assert ``obs.dtype == jnp.float32`` /
-``mask.dtype == jnp.bool_`` (a DeviceArray's ``.dtype`` compares equal to the torch AND the NumPy dtype of its elements,
-``interop.ArrayDType``; the double's ``jnp.float32`` is plain ``numpy.float32``, nothing is special-cased there).
+repo's, never the reference's.  All 37 pass; the two that assert ``obs.dtype == jnp.float32`` / ``mask.dtype == jnp.bool_``
+do so because the DOUBLE's ``jnp.float32`` / ``jnp.bool_`` compare equal to the torch dtype of the same element type
+(jax_shim/jax/numpy.py) -- the product's ``.dtype`` is a plain ``torch.dtype`` (round 2 bent the product's return type for
+these two assertions).
 (The same known-answer vectors are also transcribed in tests/test_api_reinforce_game.py, which runs on the GPU box.)
 """
 
