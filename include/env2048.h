@@ -255,6 +255,22 @@ ENV2048_EXPORT int env2048_step_state_i32_keyed(int device, void *stream, uint64
 ENV2048_EXPORT int env2048_reset_keyed_i32(int device, void *stream, uint64_t n, const uint32_t *keys, int32_t *boards);
 
 /*
+ * The two keyed entry points above with what the caller asks about the NEW state right after them, written by the SAME
+ * launch: obs (n x 16 float32, log2(tile)/16) and legal4 (n x 4 bytes, 0/1 per action: a bool array) of the boards the
+ * call leaves behind (a frozen game's unchanged board included); each may be NULL.  The self-play loop asks the
+ * environment for exactly these between two moves (reinforce/training/self_play.py:316-317 after :354 / :300), so a move
+ * costs ONE launch instead of three.  [replaces: batched_step + batched_get_observation + batched_get_legal_actions,
+ * reinforce/game/env.py:193-245]
+ */
+ENV2048_EXPORT int env2048_step_state_i32_keyed_status(int device, void *stream, uint64_t n, const uint32_t *keys, const int32_t *boards_in,
+                                                       int32_t *boards_out, const int32_t *actions, const int32_t *step_count_in,
+                                                       int32_t *step_count_out, const uint8_t *done_in, uint8_t *done_out,
+                                                       const float *total_reward_in, float *total_reward_out, float *reward,
+                                                       int32_t *max_tile, float *obs, uint8_t *legal4);
+ENV2048_EXPORT int env2048_reset_keyed_i32_status(int device, void *stream, uint64_t n, const uint32_t *keys, int32_t *boards, float *obs,
+                                                  uint8_t *legal4);
+
+/*
  * Per-move queries of the reinforce/game callers on int32 tile VALUE boards (n x 16), one launch, each
  * output optional:
  *     obs[16*i..]    float32 log2(tile)/16, 0 for empty      (encode_observation, core.py:346-377)

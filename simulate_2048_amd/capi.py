@@ -79,6 +79,9 @@ PROTOTYPES = {
     'env2048_step_state_i32_keyed': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
                                                _ptr]),
     'env2048_reset_keyed_i32': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr]),
+    'env2048_step_state_i32_keyed_status': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
+                                                      _ptr, _ptr, _ptr, _ptr]),
+    'env2048_reset_keyed_i32_status': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr]),
     'env2048_status_i32': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr]),
     'env2048_rollout': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _u64, _u64, _u32, _ptr, _ptr, _ptr, _u32]),
     'env2048_replay': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _ptr, _ptr, _ptr, _u64, _u64, _u64, _u32, _u32, _ptr, _ptr, _ptr]),
@@ -204,6 +207,15 @@ class Library:
 
     def reset_keyed_i32(self, device, stream, n, keys, boards) -> None:
         self._check(self._dll.env2048_reset_keyed_i32(device, stream, n, keys, boards))
+
+    def step_state_i32_keyed_status(self, device, stream, n, keys, boards_in, boards_out, actions, step_count_in, step_count_out,
+                                    done_in, done_out, total_in, total_out, reward, max_tile, obs, legal4) -> None:
+        self._check(self._dll.env2048_step_state_i32_keyed_status(device, stream, n, keys, boards_in, boards_out, actions,
+                                                                  step_count_in, step_count_out, done_in, done_out, total_in,
+                                                                  total_out, reward, max_tile, obs, legal4))
+
+    def reset_keyed_i32_status(self, device, stream, n, keys, boards, obs, legal4) -> None:
+        self._check(self._dll.env2048_reset_keyed_i32_status(device, stream, n, keys, boards, obs, legal4))
 
     def status_i32(self, device, stream, n, boards, obs, legal4, done) -> None:
         self._check(self._dll.env2048_status_i32(device, stream, n, boards, obs, legal4, done))

@@ -961,7 +961,8 @@ __global__ __launch_bounds__(BLOCK) void step_state_i32_kernel(uint64_t n, uint6
                                                                const int32_t *step_count_in, int32_t *step_count_out,
                                                                const uint8_t *done_in, uint8_t *done_out,
                                                                const float *total_in, float *total_out, float *reward_out,
-                                                               int32_t *max_tile, RngKey key, const uint2 *keys)
+                                                               int32_t *max_tile, RngKey key, const uint2 *keys, float *obs_out,
+                                                               uint32_t *legal4_out)
 {
     const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
@@ -986,6 +987,7 @@ __global__ __launch_bounds__(BLOCK) void step_state_i32_kernel(uint64_t n, uint6
     int32_t steps = step_count_in ? step_count_in[i] : 0;
     float total = total_in ? total_in[i] : 0.0f;
     uint8_t done = 1;
+    uint32_t legal_bits = 0u;
     if (!was_done) {
         uint32_t score;
         bool changed;
@@ -996,10 +998,18 @@ __global__ __launch_bounds__(BLOCK) void step_state_i32_kernel(uint64_t n, uint6
         rows_out[1] = unpack4(bd.r1);
         rows_out[2] = unpack4(bd.r2);
         rows_out[3] = unpack4(bd.r3);
-        done = legal_mask(bd) == 0u ? 1 : 0;
+        legal_bits = legal_mask(bd);
+        done = legal_bits == 0u ? 1 : 0;
         steps += 1;
         total += reward;
-    } else if (!in_place) {  // the values as they came in (not re-derived from the packed form)
+    } else if (legal4_out) {
+        legal_bits = legal_mask(bd);  // (a frozen game: the mask of the board as it stands)
+    }
+    // what the caller asks about the NEW state right after a move (reinforce/training/self_play.py:316-317), in the same
+    // launch: observation and (N, 4) legal bytes of the board this step leaves behind -- a finished game's unchanged board
+    if (obs_out) store_obs(obs_out, i, bd);
+    if (legal4_out) legal4_out[i] = (legal_bits & 1u) | ((legal_bits & 2u) << 7) | ((legal_bits & 4u) << 14) | ((legal_bits & 8u) << 21);
+    if (was_done && !in_place) {  // the values as they came in (not re-derived from the packed form)
         rows_out[0] = v0;
         rows_out[1] = v1;
         rows_out[2] = v2;
@@ -1027,7 +1037,8 @@ __global__ __launch_bounds__(BLOCK) void step_state_i32_kernel(uint64_t n, uint6
 
 // batched_reset with one PRNG key per environment, straight to int32 value boards: board i = the fresh board of
 // environment 0 at step 0 of the stream seeded with keys[i] (= create_initial_board(keys[i])).
-__global__ __launch_bounds__(BLOCK) void reset_keyed_i32_kernel(uint64_t n, const uint2 *keys, int32_t *boards)
+__global__ __launch_bounds__(BLOCK) void reset_keyed_i32_kernel(uint64_t n, const uint2 *keys, int32_t *boards, float *obs_out,
+                                                                uint32_t *legal4_out)
 {
     const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
@@ -1040,6 +1051,11 @@ __global__ __launch_bounds__(BLOCK) void reset_keyed_i32_kernel(uint64_t n, cons
     rows[1] = unpack4(bd.r1);
     rows[2] = unpack4(bd.r2);
     rows[3] = unpack4(bd.r3);
+    if (obs_out) store_obs(obs_out, i, bd);
+    if (legal4_out) {
+        const uint32_t bits = legal_mask(bd);
+        legal4_out[i] = (bits & 1u) | ((bits & 2u) << 7) | ((bits & 4u) << 14) | ((bits & 8u) << 21);
+    }
 }
 
 // What the reinforce/game callers ask about a batch of int32 value boards, in one launch: the f32
@@ -1992,9 +2008,11 @@ int env2048_step_sequence(int device, void *stream, uint64_t n, uint64_t env_bas
 static int step_state_i32_common(const char *who, int device, void *stream, uint64_t n, uint64_t env_base, const uint32_t *keys,
                                  const int32_t *boards_in, int32_t *boards_out, const int32_t *actions, const int32_t *step_count_in,
                                  int32_t *step_count_out, const uint8_t *done_in, uint8_t *done_out, const float *total_reward_in,
-                                 float *total_reward_out, float *reward, int32_t *max_tile, uint64_t seed, uint64_t step_index)
+                                 float *total_reward_out, float *reward, int32_t *max_tile, uint64_t seed, uint64_t step_index,
+                                 float *obs_out = nullptr, uint8_t *legal4_out = nullptr)
 {
     if (n == 0) return ENV2048_OK;
+    if (misaligned(obs_out, 16) || misaligned(legal4_out, 4)) return fail(ENV2048_ERR_ALIGNMENT, "%s: obs must be 16-byte, legal4 4-byte aligned", who);
     if (!boards_in || !boards_out || !actions || !done_in || !done_out || !reward)
         return fail(ENV2048_ERR_INVALID_ARG, "%s: boards, actions, done and reward are required", who);
     if ((step_count_in == nullptr) != (step_count_out == nullptr) || (total_reward_in == nullptr) != (total_reward_out == nullptr))
@@ -2011,7 +2029,7 @@ static int step_state_i32_common(const char *who, int device, void *stream, uint
     const RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)step_index, (uint32_t)(step_index >> 32)};
     hipLaunchKernelGGL(step_state_i32_kernel, grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, n, env_base, boards_in, boards_out,
                        actions, step_count_in, step_count_out, done_in, done_out, total_reward_in, total_reward_out, reward,
-                       max_tile, key, reinterpret_cast<const uint2 *>(keys));
+                       max_tile, key, reinterpret_cast<const uint2 *>(keys), obs_out, reinterpret_cast<uint32_t *>(legal4_out));
     return launched(who);
 }
 
@@ -2036,18 +2054,35 @@ int env2048_step_state_i32_keyed(int device, void *stream, uint64_t n, const uin
                                  0, 0);
 }
 
-int env2048_reset_keyed_i32(int device, void *stream, uint64_t n, const uint32_t *keys, int32_t *boards)
+int env2048_reset_keyed_i32_status(int device, void *stream, uint64_t n, const uint32_t *keys, int32_t *boards, float *obs,
+                                   uint8_t *legal4)
 {
     if (n == 0) return ENV2048_OK;
     if (!keys || !boards) return fail(ENV2048_ERR_INVALID_ARG, "env2048_reset_keyed_i32: keys and boards are required");
-    if (misaligned(keys, 8) || misaligned(boards, 16))
-        return fail(ENV2048_ERR_ALIGNMENT, "env2048_reset_keyed_i32: keys must be 8-byte, boards 16-byte aligned");
+    if (misaligned(keys, 8) || misaligned(boards, 16) || misaligned(obs, 16) || misaligned(legal4, 4))
+        return fail(ENV2048_ERR_ALIGNMENT, "env2048_reset_keyed_i32: keys must be 8-byte, boards / obs 16-byte, legal4 4-byte aligned");
     if (int rc = check_count(n)) return rc;
     DeviceScope scope(device);
     if (scope.rc) return scope.rc;
     hipLaunchKernelGGL(reset_keyed_i32_kernel, grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, n, reinterpret_cast<const uint2 *>(keys),
-                       boards);
+                       boards, obs, reinterpret_cast<uint32_t *>(legal4));
     return launched("env2048_reset_keyed_i32 launch");
+}
+
+int env2048_reset_keyed_i32(int device, void *stream, uint64_t n, const uint32_t *keys, int32_t *boards)
+{
+    return env2048_reset_keyed_i32_status(device, stream, n, keys, boards, nullptr, nullptr);
+}
+
+int env2048_step_state_i32_keyed_status(int device, void *stream, uint64_t n, const uint32_t *keys, const int32_t *boards_in,
+                                        int32_t *boards_out, const int32_t *actions, const int32_t *step_count_in,
+                                        int32_t *step_count_out, const uint8_t *done_in, uint8_t *done_out, const float *total_reward_in,
+                                        float *total_reward_out, float *reward, int32_t *max_tile, float *obs, uint8_t *legal4)
+{
+    if (n && !keys) return fail(ENV2048_ERR_INVALID_ARG, "env2048_step_state_i32_keyed_status: keys is NULL");
+    return step_state_i32_common("env2048_step_state_i32_keyed_status", device, stream, n, 0, keys, boards_in, boards_out, actions,
+                                 step_count_in, step_count_out, done_in, done_out, total_reward_in, total_reward_out, reward, max_tile,
+                                 0, 0, obs, legal4);
 }
 
 int env2048_step_state_i32(int device, void *stream, uint64_t n, uint64_t env_base, int32_t *boards, const int32_t *actions,

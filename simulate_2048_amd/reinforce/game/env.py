@@ -4,7 +4,8 @@ per function): ``GameState``, ``reset``/``step``, the ``batched_*`` forms and th
 ``Environment`` wrapper.  State fields are ``torch`` tensors on the GPU.
 
 The batched forms are what ``reinforce/training/self_play.py:300,316-317,354`` calls once per
-move; each is ONE kernel launch here (int32 value boards in, int32 value boards out).  Everything
+move; ``batched_step`` / ``batched_reset`` are ONE kernel launch (int32 value boards in, int32 value boards out) that also
+writes the observation and the legal mask of the new state, so the two getters the loop calls next cost no launch.  Everything
 returned is an ``interop.DeviceArray`` -- a GPU-resident torch tensor that ``np.array(...)`` copies to
 the host in one go -- and every argument may be a torch tensor, a NumPy array or any ``__dlpack__`` /
 ``__array__`` producer (JAX ``(N, 2)`` uint32 keys, ``(N,)`` int32 actions), so the caller's loop runs
@@ -17,10 +18,12 @@ from __future__ import annotations
 
 from typing import NamedTuple
 
+import numpy as np
 import torch
 
 from ... import runtime
 from ...interop import key_words, keys_on_device, to_tensor, wrap
+from ...resultpool import STAGE_MAX_BYTES, pool, stager
 from .core import _board_tensor
 
 
@@ -34,21 +37,80 @@ class GameState(NamedTuple):
     total_reward: torch.Tensor
 
 
+def _host_small(x):
+    """`x` as a NumPy array if it lives on the host and is small enough for the pinned staging ring, else None."""
+    if isinstance(x, torch.Tensor):
+        return None
+    if isinstance(x, np.ndarray):
+        a = x
+    elif isinstance(x, (list, tuple, int, np.integer)):
+        a = np.asarray(x)
+    elif hasattr(x, '__dlpack__') and getattr(x, 'device', None) is not None and 'cpu' not in str(x.device).lower():
+        return None  # a device array of another framework: DLPack hand-over, no host round trip
+    else:
+        a = np.asarray(x)
+    return a if a.nbytes <= STAGE_MAX_BYTES else None
+
+
+def _keys_ptr(keys, rt):
+    """(device-visible pointer, n, keep-alive) of (N, 2) PRNG keys: small host arrays go through the pinned ring."""
+    a = _host_small(keys)
+    if a is not None and a.dtype.kind in 'iu':
+        if a.ndim == 1 and a.size == 2:
+            a = a.reshape(1, 2)
+        if a.ndim != 2 or a.shape[1] != 2:
+            raise ValueError(f'expected PRNG keys of shape (N, 2), got {a.shape}')
+        if a.dtype != np.uint32:
+            a = (a.astype(np.int64) & 0xFFFFFFFF).astype(np.uint32)  # keep the low 32 bits as a bit pattern
+        return stager(rt.device).stage(np.ascontiguousarray(a)), a.shape[0], None
+    k = keys_on_device(keys, rt.device)
+    return k.data_ptr(), int(k.shape[0]), k
+
+
+def _actions_ptr(actions, n, rt):
+    a = _host_small(actions)
+    if a is not None and a.dtype.kind in 'iub':
+        if a.size != n:
+            raise ValueError(f'batched_step: {n} environments but {a.size} actions')
+        return stager(rt.device).stage(np.ascontiguousarray(a.reshape(n), dtype=np.int32)), None
+    t = _dev(actions, torch.int32, n, rt)
+    return t.data_ptr(), t
+
+
+def _state_ptrs(states: GameState, rt):
+    """Pointers of a state's four fields + n + keep-alive list.  Tensors that ARE the tensors of a pooled result set (the
+    state came out of batched_step / batched_reset) are recognised by identity: nothing to check, nothing to convert."""
+    hit = pool.lookup(states.board)
+    if hit is not None and hit[1] == 'board':
+        rs = hit[0]
+        if states.step_count is rs.step_count and states.done is rs.done and states.total_reward is rs.total:
+            p = rs.ptr
+            return p['board'], p['step_count'], p['done'], p['total'], rs.n, None
+    board_in = _board_tensor(states.board).reshape(-1, 4, 4)
+    n = board_in.shape[0]
+    steps_in = _dev(states.step_count, torch.int32, n, rt)
+    total_in = _dev(states.total_reward, torch.float32, n, rt)
+    d = to_tensor(states.done)
+    if d.dtype == torch.bool and d.device == rt.device:
+        done_in = d.reshape(n).contiguous().view(torch.uint8)  # same bytes, no copy
+    else:
+        done_in = _dev(d.to(torch.uint8), torch.uint8, n, rt)
+    return board_in.data_ptr(), steps_in.data_ptr(), done_in.data_ptr(), total_in.data_ptr(), n, (board_in, steps_in, total_in, done_in)
+
+
 def batched_reset(keys) -> GameState:
     """[ref env.py:176-190] fresh games, one per key row: keys (N, 2) -> GameState with leading N.
-    One launch (env2048_reset_keyed_i32); board i depends on keys[i] only (= reset(keys[i]))."""
+    One launch (env2048_reset_keyed_i32_status); board i depends on keys[i] only (= reset(keys[i])).  The observation and
+    the legal mask of the fresh boards are written by the same launch and kept with the state (see batched_get_observation)."""
     rt = runtime.current()
-    k = keys_on_device(keys, rt.device)
-    n = int(k.shape[0])
-    board = torch.empty((n, 4, 4), dtype=torch.int32, device=rt.device)
+    kptr, n, keep = _keys_ptr(keys, rt)
+    rs = pool.acquire(n, rt.device)
     dev, stream = rt.handles()
-    rt.lib.reset_keyed_i32(dev, stream, n, k.data_ptr(), board.data_ptr())
-    return GameState(
-        board=wrap(board),
-        step_count=wrap(torch.zeros((n,), dtype=torch.int32, device=rt.device)),
-        done=wrap(torch.zeros((n,), dtype=torch.bool, device=rt.device)),
-        total_reward=wrap(torch.zeros((n,), dtype=torch.float32, device=rt.device)),
-    )
+    p = rs.ptr
+    rt.lib.reset_keyed_i32_status(dev, stream, n, kptr, p['board'], p['obs'], p['legal'])
+    rs.zero_region.zero_()  # step_count, total_reward, done (adjacent in the set: one fill)
+    rs.versions = tuple(t._version for t in rs.tensors)
+    return GameState(board=rs.board, step_count=rs.step_count, done=rs.done, total_reward=rs.total)
 
 
 def _dev(x, dtype, n, rt) -> torch.Tensor:
@@ -64,44 +126,43 @@ def _dev(x, dtype, n, rt) -> torch.Tensor:
 def batched_step(states: GameState, actions, keys):
     """[ref env.py:193-211] one move per environment -> (GameState, reward (N,) f32, done (N,) bool, info).
 
-    One fused, out-of-place kernel (env2048_step_state_i32_keyed): the input state is only read (functional
-    API) and the new state is written to fresh tensors -- no copies on either side.  Finished games are
-    frozen exactly like the reference's done-guard (env.py:103-104): state unchanged, reward 0.0, done True,
-    step_count not advanced.  Environment i draws its tile from keys[i] alone (vmap semantics).
+    ONE fused, out-of-place kernel (env2048_step_state_i32_keyed_status): the input state is only read (functional API), the
+    new state, reward, done, max_tile AND the observation / legal mask of the new state are written by the same launch into a
+    result set that is reused once the caller has let go of it (``resultpool``) -- a move of the reference's self-play loop
+    (self_play.py:316-317,354: observation, legal mask, step) is one launch and creates no tensor.  Finished games are frozen
+    exactly like the reference's done-guard (env.py:103-104): state unchanged, reward 0.0, done True, step_count not advanced.
+    Environment i draws its tile from keys[i] alone (vmap semantics).
     """
     rt = runtime.current()
-    board_in = _board_tensor(states.board).reshape(-1, 4, 4)
-    n = board_in.shape[0]
-    k = keys_on_device(keys, rt.device)
-    if k.shape[0] != n:
-        raise ValueError(f'batched_step: {n} environments but {k.shape[0]} keys')
-    steps_in = _dev(states.step_count, torch.int32, n, rt)
-    total_in = _dev(states.total_reward, torch.float32, n, rt)
-    acts = _dev(actions, torch.int32, n, rt)
-    d = to_tensor(states.done)
-    if d.dtype == torch.bool and d.device == rt.device:
-        done_in = d.reshape(n).contiguous().view(torch.uint8)  # same bytes, no copy
-    else:
-        done_in = _dev(d.to(torch.uint8), torch.uint8, n, rt)
-    board = torch.empty_like(board_in)
-    i32 = torch.empty((2, n), dtype=torch.int32, device=rt.device)   # step_count, max_tile
-    f32 = torch.empty((2, n), dtype=torch.float32, device=rt.device)  # total_reward, reward
-    done_u8 = torch.empty((n,), dtype=torch.uint8, device=rt.device)
+    b_in, s_in, d_in, t_in, n, keep_state = _state_ptrs(states, rt)
+    kptr, nk, keep_keys = _keys_ptr(keys, rt)
+    if nk != n:
+        raise ValueError(f'batched_step: {n} environments but {nk} keys')
+    aptr, keep_actions = _actions_ptr(actions, n, rt)
+    rs = pool.acquire(n, rt.device)  # (never the set the input state lives in: the caller still holds that one)
+    p = rs.ptr
     dev, stream = rt.handles()
-    i32_ptr, f32_ptr = i32.data_ptr(), f32.data_ptr()  # (addresses taken on the plain tensors: no __torch_function__ detour)
-    rt.lib.step_state_i32_keyed(dev, stream, n, k.data_ptr(), board_in.data_ptr(), board.data_ptr(), acts.data_ptr(),
-                                steps_in.data_ptr(), i32_ptr, done_in.data_ptr(), done_u8.data_ptr(),
-                                total_in.data_ptr(), f32_ptr, f32_ptr + 4 * n, i32_ptr + 4 * n)
-    step_count, max_tile = (wrap(t) for t in i32.unbind(0))
-    total, reward = (wrap(t) for t in f32.unbind(0))
-    done = wrap(done_u8.view(torch.bool))
-    new_state = GameState(board=wrap(board), step_count=step_count, done=done, total_reward=total)
-    info = {'max_tile': max_tile, 'step_count': step_count, 'total_reward': total}
-    return new_state, reward, done, info
+    rt.lib.step_state_i32_keyed_status(dev, stream, n, kptr, b_in, p['board'], aptr, s_in, p['step_count'], d_in, p['done'], t_in,
+                                       p['total'], p['reward'], p['max_tile'], p['obs'], p['legal'])
+    new_state = GameState(board=rs.board, step_count=rs.step_count, done=rs.done, total_reward=rs.total)
+    info = {'max_tile': rs.max_tile, 'step_count': rs.step_count, 'total_reward': rs.total}
+    return new_state, rs.reward, rs.done, info
+
+
+def _stashed(states: GameState, field: str):
+    """obs / legal written by the launch that produced `states`, if the state is a pooled one and still as written."""
+    hit = pool.lookup(states.board)
+    if hit is not None and hit[1] == 'board' and hit[0].stash_valid():
+        return getattr(hit[0], field)
+    return None
 
 
 def batched_get_observation(states: GameState) -> torch.Tensor:
-    """[ref env.py:214-228] (N, 16) float32 log2/16 observations -- one kernel on the int32 boards."""
+    """[ref env.py:214-228] (N, 16) float32 log2/16 observations.  For a state that came out of batched_step / batched_reset
+    this is the array the same launch already wrote (no kernel); any other board gets one status kernel."""
+    obs = _stashed(states, 'obs')
+    if obs is not None:
+        return obs
     rt = runtime.current()
     boards = _board_tensor(states.board).reshape(-1, 16)
     n = boards.shape[0]
@@ -112,7 +173,10 @@ def batched_get_observation(states: GameState) -> torch.Tensor:
 
 
 def batched_get_legal_actions(states: GameState) -> torch.Tensor:
-    """[ref env.py:231-245] (N, 4) bool legal-action masks -- one kernel, written as bool bytes."""
+    """[ref env.py:231-245] (N, 4) bool legal-action masks (stashed by the producing launch, else one status kernel)."""
+    legal = _stashed(states, 'legal')
+    if legal is not None:
+        return legal
     rt = runtime.current()
     boards = _board_tensor(states.board).reshape(-1, 16)
     n = boards.shape[0]

@@ -1,0 +1,199 @@
+"""
+Allocation-free results and inputs for the ``reinforce.game`` mirrors at the reference's batch sizes (N = 2 ... 8,
+reinforce/training/config.py:79,151,177), where a move's kernel takes 4 microseconds and everything else is host time.
+
+``ResultSet``  -- ALL outputs of one ``batched_step`` / ``batched_reset`` (board, step_count, done, total_reward, reward,
+max_tile AND the observation / legal bytes of the new state) carved ONCE out of one device allocation and wrapped ONCE as
+``DeviceArray`` objects.  A set is handed out again only when nobody else can still see it: every tensor object's Python
+reference count is back at its idle value (the caller dropped the ``GameState``, the reward array ...) and the allocation's
+storage use count is back at its idle value (no view such as ``states.board[0]`` is alive either).  That is the rule torch's
+caching allocator applies to a freed block -- reuse in stream order once the last reference is gone -- applied one level up,
+so that a move creates no tensor object at all.  A caller that keeps every state it ever received simply finds no idle set
+and gets fresh ones (the pool is capped; beyond the cap sets are created and dropped as before).
+
+``registry``   -- ``id(tensor) -> (set, pointer)`` for the tensors of live sets: the next ``batched_step`` recognises "its own"
+state tensors without asking torch for dtype / device / contiguity, and ``batched_get_observation`` /
+``batched_get_legal_actions`` return the stash written by the launch that produced the state (valid while torch's version
+counters say neither the board nor the stash was modified in place).
+
+``HostStager`` -- small host arrays (PRNG keys, actions) reach the kernel through a ring of PINNED host memory, which is
+device-accessible on HIP: one NumPy copy into the ring instead of a pageable H2D copy (8-12 microseconds each at N = 8).  The
+ring has two halves; the half being left gets an event on the launch stream, and that event is waited for before the half
+is written again, so a kernel never reads a slot that is being refilled -- with no per-call synchronisation.
+"""
+
+from __future__ import annotations
+
+import sys
+import threading
+
+import numpy as np
+import torch
+
+from .interop import DeviceArray
+
+_use_count = getattr(torch._C, '_storage_Use_Count', None)  # references to a StorageImpl (tensors, views, wrappers)
+
+MAX_SETS_PER_KEY = 6
+STAGE_MAX_BYTES = 16 << 10  # larger host arrays take an ordinary H2D copy (the kernel would read them across the bus)
+
+
+def _align(x: int, a: int = 16) -> int:
+    return (x + a - 1) // a * a
+
+
+class ResultSet:
+    __slots__ = ('n', 'arena', 'storage', 'cdata', 'board', 'obs', 'step_count', 'max_tile', 'total', 'reward', 'legal', 'done',
+                 'tensors', 'ptr', 'idle_refs', 'idle_use', 'versions', 'zero_region', 'pooled')
+
+    def __init__(self, n: int, device: torch.device):
+        self.n = n
+        sizes = (('board', 64 * n), ('obs', 64 * n), ('step_count', 4 * n), ('total', 4 * n), ('done', n), ('max_tile', 4 * n),
+                 ('reward', 4 * n), ('legal', 4 * n))
+        offsets, at = {}, 0
+        for name, size in sizes:
+            offsets[name] = at
+            at = _align(at + size)
+        arena = torch.empty((max(at, 16),), dtype=torch.uint8, device=device)
+        self.arena = arena
+        self.storage = arena.untyped_storage()
+        self.cdata = self.storage._cdata
+        base = arena.data_ptr()
+
+        def carve(name, size, dtype, shape):
+            o = offsets[name]
+            return arena[o:o + size].view(dtype).view(shape).as_subclass(DeviceArray)
+
+        self.board = carve('board', 64 * n, torch.int32, (n, 4, 4))
+        self.obs = carve('obs', 64 * n, torch.float32, (n, 16))
+        self.step_count = carve('step_count', 4 * n, torch.int32, (n,))
+        self.total = carve('total', 4 * n, torch.float32, (n,))
+        self.done = carve('done', n, torch.bool, (n,))
+        self.max_tile = carve('max_tile', 4 * n, torch.int32, (n,))
+        self.reward = carve('reward', 4 * n, torch.float32, (n,))
+        self.legal = carve('legal', 4 * n, torch.bool, (n, 4))
+        # step_count | total | done are adjacent: batched_reset clears them with ONE fill
+        z0, z1 = offsets['step_count'], offsets['done'] + n
+        self.zero_region = arena[z0:z1]
+        self.tensors = (self.board, self.obs, self.step_count, self.total, self.done, self.max_tile, self.reward, self.legal)
+        self.ptr = {name: base + offsets[name] for name, _ in sizes}
+        self.versions = tuple(t._version for t in self.tensors)
+        ts = self.tensors  # (measured exactly the way idle() measures: indexing adds no reference, a loop variable would)
+        self.idle_refs = (sys.getrefcount(ts[0]), sys.getrefcount(ts[1]), sys.getrefcount(ts[2]), sys.getrefcount(ts[3]),
+                          sys.getrefcount(ts[4]), sys.getrefcount(ts[5]), sys.getrefcount(ts[6]), sys.getrefcount(ts[7]))
+        self.idle_use = _use_count(self.cdata) if _use_count else -1
+        self.pooled = False
+
+    def idle(self) -> bool:
+        """Nobody but this set references its tensors or their memory."""
+        if _use_count is None or _use_count(self.cdata) != self.idle_use:
+            return False
+        refs = self.idle_refs
+        ts = self.tensors
+        return (sys.getrefcount(ts[0]) == refs[0] and sys.getrefcount(ts[1]) == refs[1] and sys.getrefcount(ts[2]) == refs[2]
+                and sys.getrefcount(ts[3]) == refs[3] and sys.getrefcount(ts[4]) == refs[4] and sys.getrefcount(ts[5]) == refs[5]
+                and sys.getrefcount(ts[6]) == refs[6] and sys.getrefcount(ts[7]) == refs[7])
+
+    def stash_valid(self) -> bool:
+        """board, obs and legal are as the kernel wrote them (no in-place torch operation touched them since)."""
+        v = self.versions
+        return self.board._version == v[0] and self.obs._version == v[1] and self.legal._version == v[7]
+
+
+class ResultPool:
+    """Per (n, device) a few ResultSets; ``acquire`` returns an idle one or a new one."""
+
+    def __init__(self):
+        self._sets: dict = {}
+        self._lock = threading.Lock()
+        self.registry: dict = {}  # id(tensor) -> (ResultSet, field name); only tensors of POOLED sets (kept alive by the pool)
+        self.created = 0  # sets ever created (tests read it)
+
+    def acquire(self, n: int, device: torch.device) -> ResultSet:
+        key = (n, device)
+        with self._lock:
+            sets = self._sets.get(key)
+            if sets is None:
+                sets = self._sets[key] = []
+            for rs in sets:
+                if rs.idle():
+                    return rs
+            rs = ResultSet(n, device)
+            self.created += 1
+            if len(sets) < MAX_SETS_PER_KEY and _use_count is not None:
+                sets.append(rs)
+                rs.pooled = True
+                reg = self.registry
+                for name, t in zip(('board', 'obs', 'step_count', 'total', 'done', 'max_tile', 'reward', 'legal'), rs.tensors):
+                    reg[id(t)] = (rs, name)
+            return rs
+
+    def lookup(self, tensor):
+        """(set, field) if `tensor` IS one of a pooled set's tensors (the very object), else None."""
+        hit = self.registry.get(id(tensor))
+        if hit is not None and getattr(hit[0], hit[1]) is tensor:
+            return hit
+        return None
+
+    def clear(self) -> None:
+        with self._lock:
+            self._sets.clear()
+            self.registry.clear()
+
+
+class HostStager:
+    """Ring of pinned (device-accessible) host memory for small kernel inputs that live on the host."""
+
+    def __init__(self, device: torch.device, capacity: int = 1 << 20):
+        self.device = device
+        self.gpu = device.type == 'cuda'
+        self.buf = torch.empty((capacity,), dtype=torch.uint8, pin_memory=self.gpu)
+        self.host = self.buf.numpy()
+        self.base = self.buf.data_ptr()
+        self.capacity = capacity
+        self.half = capacity // 2
+        self.offset = 0
+        self.events = [None, None]  # per half: recorded when the writer LEFT it (every kernel reading it was enqueued before)
+
+    def _enter_half(self, h: int) -> None:
+        if not self.gpu:
+            return
+        left = 1 - h
+        ev = self.events[left]
+        if ev is None:
+            ev = self.events[left] = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))  # all launches that read the half we are leaving are on the stream by now
+        pending = self.events[h]
+        if pending is not None:
+            pending.synchronize()  # (long done in any real loop: half a MiB of 100-byte inputs ago)
+
+    def stage(self, array: np.ndarray) -> int:
+        """Copy a small contiguous host array into the ring; returns the device-visible address (16-byte aligned)."""
+        nbytes = array.nbytes
+        size = _align(max(nbytes, 1))
+        off = self.offset
+        h0 = 0 if off < self.half else 1
+        if off + size > (self.half if h0 == 0 else self.capacity):  # does not fit the rest of this half: move to the other one
+            h0 = 1 - h0
+            off = 0 if h0 == 0 else self.half
+            self._enter_half(h0)
+        self.host[off:off + nbytes] = array.reshape(-1).view(np.uint8)
+        self.offset = off + size
+        return self.base + off
+
+
+_local = threading.local()
+
+
+def stager(device: torch.device) -> HostStager:
+    """This thread's stager for `device` (a kernel launch follows every stage() before the thread stages again)."""
+    table = getattr(_local, 'stagers', None)
+    if table is None:
+        table = _local.stagers = {}
+    s = table.get(device)
+    if s is None:
+        s = table[device] = HostStager(device)
+    return s
+
+
+pool = ResultPool()

@@ -145,6 +145,23 @@ class OracleLibrary:
         self.calls.append(('reset_keyed_i32', n))
         _view(boards, n * 16, np.int32)[:] = oracle.reset_keyed_i32(_view(keys, 2 * n, np.uint32)).reshape(-1)
 
+    # the *_status forms = the plain call + the status of the boards it leaves behind (one launch on the GPU; here composed)
+    def step_state_i32_keyed_status(self, device, stream, n, keys, boards_in, boards_out, actions, step_count_in, step_count_out,
+                                    done_in, done_out, total_in, total_out, reward, max_tile, obs, legal4):
+        self.step_state_i32_keyed(device, stream, n, keys, boards_in, boards_out, actions, step_count_in, step_count_out, done_in,
+                                  done_out, total_in, total_out, reward, max_tile)
+        self.calls[-1] = ('step_state_i32_keyed_status', n)
+        if obs is not None or legal4 is not None:
+            self.status_i32(device, stream, n, boards_out, obs, legal4, None)
+            self.calls.pop()
+
+    def reset_keyed_i32_status(self, device, stream, n, keys, boards, obs, legal4):
+        self.reset_keyed_i32(device, stream, n, keys, boards)
+        self.calls[-1] = ('reset_keyed_i32_status', n)
+        if obs is not None or legal4 is not None:
+            self.status_i32(device, stream, n, boards, obs, legal4, None)
+            self.calls.pop()
+
     def rollout(self, device, stream, n, env_base, boards, seed, step0, T, return_sum, episodes, valid_moves, flags):
         self.calls.append(('rollout', n))
         b = _view(boards, n * 16, np.uint8)

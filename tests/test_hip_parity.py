@@ -685,6 +685,61 @@ def test_keyed_step_and_reset_match_oracle(lib):
     assert e.value.code == capi.ERR_INVALID_ARG
 
 
+def test_keyed_step_and_reset_with_fused_status_match_oracle(lib):
+    """env2048_step_state_i32_keyed_status / env2048_reset_keyed_i32_status: the plain results are unchanged and the
+    observation / (N, 4) legal bytes of the boards the call leaves behind equal the oracle's status of those boards --
+    frozen (done) games included; pinned HOST memory works as the key / action source (what the mirrors stage small
+    inputs through)."""
+    rng = np.random.default_rng(21)
+    n = 9_001
+    keys = rng.integers(0, 1 << 32, size=(n, 2), dtype=np.uint64).astype(np.uint32)
+    values = oracle.unpack_values(random_boards(rng, n)).astype(np.int32)
+    actions = rng.integers(0, 4, size=n).astype(np.int32)
+    step_count = rng.integers(0, 500, size=n).astype(np.int32)
+    done = (rng.random(n) < 0.3).astype(np.uint8)
+    total = rng.integers(0, 5000, size=n).astype(np.float32)
+    ref = oracle.step_state_i32_keyed(values, actions, step_count, done, total, keys)
+    status = oracle.status_batch(oracle.pack_values(ref['boards']).reshape(n, 16))
+    want_legal4 = ((status['legal'][:, None] >> np.arange(4)) & 1).astype(np.uint8)
+    k_pinned = torch.from_numpy(keys.view(np.int32).copy()).pin_memory()  # device-accessible host memory
+    a_pinned = torch.from_numpy(actions.copy()).pin_memory()
+    b_in, sc_in, d_in, tr_in = cu(values), cu(step_count), cu(done), cu(total)
+    b_out = torch.full((n, 16), -5, dtype=torch.int32, device='cuda')
+    sc_out = torch.full((n,), -5, dtype=torch.int32, device='cuda')
+    d_out = torch.full((n,), 9, dtype=torch.uint8, device='cuda')
+    tr_out = torch.full((n,), -5.0, dtype=torch.float32, device='cuda')
+    reward = torch.full((n,), -1.0, dtype=torch.float32, device='cuda')
+    max_tile = torch.full((n,), -1, dtype=torch.int32, device='cuda')
+    obs = torch.full((n, 16), -1.0, dtype=torch.float32, device='cuda')
+    legal4 = torch.full((n, 4), 7, dtype=torch.uint8, device='cuda')
+    lib.step_state_i32_keyed_status(DEV, stream(), n, p(k_pinned), p(b_in), p(b_out), p(a_pinned), p(sc_in), p(sc_out), p(d_in),
+                                    p(d_out), p(tr_in), p(tr_out), p(reward), p(max_tile), p(obs), p(legal4))
+    torch.cuda.synchronize()
+    for got, key in ((b_out, 'boards'), (sc_out, 'step_count'), (d_out, 'done'), (tr_out, 'total_reward'), (reward, 'reward'),
+                     (max_tile, 'max_tile')):
+        np.testing.assert_array_equal(got.cpu().numpy(), ref[key], err_msg=key)
+    np.testing.assert_array_equal(obs.cpu().numpy(), status['obs'])
+    np.testing.assert_array_equal(legal4.cpu().numpy(), want_legal4)
+    # obs only / legal only
+    obs.fill_(-1.0)
+    lib.step_state_i32_keyed_status(DEV, stream(), n, p(k_pinned), p(b_in), p(b_out), p(a_pinned), p(sc_in), p(sc_out), p(d_in),
+                                    p(d_out), p(tr_in), p(tr_out), p(reward), p(max_tile), p(obs), None)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(obs.cpu().numpy(), status['obs'])
+    # reset + status
+    fresh = torch.full((n, 16), -1, dtype=torch.int32, device='cuda')
+    lib.reset_keyed_i32_status(DEV, stream(), n, p(k_pinned), p(fresh), p(obs), p(legal4))
+    torch.cuda.synchronize()
+    want = oracle.reset_keyed_i32(keys)
+    np.testing.assert_array_equal(fresh.cpu().numpy(), want)
+    st0 = oracle.status_batch(oracle.pack_values(want).reshape(n, 16))
+    np.testing.assert_array_equal(obs.cpu().numpy(), st0['obs'])
+    np.testing.assert_array_equal(legal4.cpu().numpy(), ((st0['legal'][:, None] >> np.arange(4)) & 1).astype(np.uint8))
+    with pytest.raises(capi.Env2048Error) as e:
+        lib.reset_keyed_i32_status(DEV, stream(), n, p(k_pinned), p(fresh), p(obs) + 4, None)
+    assert e.value.code == capi.ERR_ALIGNMENT
+
+
 def test_step_state_i32_matches_oracle(lib):
     """Fused reinforce/game step on int32 value boards: done-guard, bookkeeping, JAX is_done."""
     rng = np.random.default_rng(11)

@@ -42,6 +42,16 @@ struct Stamp {
     asm volatile(".rept 16\n\t" I0 "\n\t" I1 "\n\t" I2 "\n\t" I3 "\n\t" I4 "\n\t" I5 "\n\t" I6 "\n\t" I7 "\n\t.endr"             \
                  : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7)                               \
                  : "v"(a), "v"(b), "s"(sa), "s"(sb))
+// the same with VCC clobbered, and with a 64-bit SGPR mask operand %12
+#define PROBE_ASM_V(I0, I1, I2, I3, I4, I5, I6, I7)                                                                           \
+    asm volatile(".rept 16\n\t" I0 "\n\t" I1 "\n\t" I2 "\n\t" I3 "\n\t" I4 "\n\t" I5 "\n\t" I6 "\n\t" I7 "\n\t.endr"             \
+                 : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7)                               \
+                 : "v"(a), "v"(b), "s"(sa), "s"(sb)                                                                            \
+                 : "vcc")
+#define PROBE_ASM_M(I0, I1, I2, I3, I4, I5, I6, I7)                                                                           \
+    asm volatile(".rept 16\n\t" I0 "\n\t" I1 "\n\t" I2 "\n\t" I3 "\n\t" I4 "\n\t" I5 "\n\t" I6 "\n\t" I7 "\n\t.endr"             \
+                 : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7)                               \
+                 : "v"(a), "v"(b), "s"(sa), "s"(sb), "s"(mask))
 // 64-bit destinations (v_mad_u64_u32)
 #define PROBE_ASM64(I0, I1, I2, I3, I4, I5, I6, I7)                                                                           \
     asm volatile(".rept 16\n\t" I0 "\n\t" I1 "\n\t" I2 "\n\t" I3 "\n\t" I4 "\n\t" I5 "\n\t" I6 "\n\t" I7 "\n\t.endr"             \
@@ -83,6 +93,16 @@ enum Op {
     OP_PK_ADD_U16_INDEP,
     OP_BFE_INDEP,
     OP_ALIGNBIT_INDEP,
+    OP_CMP_VCC,
+    OP_CMP_SGPR,
+    OP_CNDMASK_SGPR,
+    OP_CMP_CNDMASK_PAIR,
+    OP_CNDMASK_VCC_CONSTS,
+    OP_MIN_INDEP,
+    OP_SUB_INDEP,
+    OP_XOR_VARIED,
+    OP_LSHRREV_INDEP,
+    OP_ADD_CO_VCC,
     OP_MIX_PERM_BITOP,  // alternating v_perm_b32 / v_bitop3_b32 / v_add_u32 (the step kernel's staple diet)
     OP_COUNT
 };
@@ -121,6 +141,16 @@ static const char *OP_NAMES[OP_COUNT] = {
     "v_pk_add_u16 indep",
     "v_bfe_u32 indep",
     "v_alignbit_b32 indep",
+    "v_cmp_gt_u32 (e32 -> vcc) indep",
+    "v_cmp_gt_u32 (e64 -> SGPR pair) indep",
+    "v_cndmask_b32 (e64, SGPR-pair mask) indep",
+    "v_cmp_gt_u32 vcc + v_cndmask_b32 vcc pairs",
+    "v_cndmask_b32 (e64, 0, 1, vcc) indep",
+    "v_min_u32 (e32) indep",
+    "v_sub_u32 (e32) indep",
+    "v_xor_b32 (e32) varied registers",
+    "v_lshrrev_b32 (e32) indep",
+    "v_add_co_u32 (e32 -> vcc) indep",
     "mix: perm, bitop3, add (chain of 8)",
 };
 
@@ -132,6 +162,7 @@ __global__ void probe_kernel(Stamp *out, uint32_t seed, uint32_t *sink)
     uint64_t q0 = d0, q1 = d1, q2 = d2, q3 = d3, q4 = d4, q5 = d5, q6 = d6, q7 = d7;
     uint32_t a = d0 * 0x9E3779B9u + 1u, b = d1 * 0x85EBCA6Bu + 7u;
     const uint32_t sa = __builtin_amdgcn_readfirstlane(seed * 0x27D4EB2Fu + 3u), sb = __builtin_amdgcn_readfirstlane(seed ^ 0x5bd1e995u);
+    uint64_t mask = __builtin_amdgcn_ballot_w64((threadIdx.x ^ seed) & 1u);  // a wave-uniform lane mask in an SGPR pair
     if (seed == 0xFFFFFFFFu) lds_pad[threadIdx.x] = a;  // keeps the dynamic LDS allocation alive
     __syncthreads();
     unsigned long long t0, t1, r0, r1;
@@ -258,11 +289,41 @@ __global__ void probe_kernel(Stamp *out, uint32_t seed, uint32_t *sink)
         else if constexpr (OP == OP_ALIGNBIT_INDEP)
             PROBE_ASM("v_alignbit_b32 %0, %8, %9, 8", "v_alignbit_b32 %1, %8, %9, 8", "v_alignbit_b32 %2, %8, %9, 8", "v_alignbit_b32 %3, %8, %9, 8",
                       "v_alignbit_b32 %4, %8, %9, 8", "v_alignbit_b32 %5, %8, %9, 8", "v_alignbit_b32 %6, %8, %9, 8", "v_alignbit_b32 %7, %8, %9, 8");
+        else if constexpr (OP == OP_CMP_VCC) {
+            asm volatile(".rept 128\n\tv_cmp_gt_u32_e32 vcc, %0, %1\n\t.endr" ::"s"(sa), "v"(a) : "vcc");
+        } else if constexpr (OP == OP_CMP_SGPR) {
+            asm volatile(".rept 128\n\tv_cmp_gt_u32_e64 %0, %1, %2\n\t.endr" : "=s"(mask)  : "s"(sa), "v"(a));
+        } else if constexpr (OP == OP_CNDMASK_SGPR)
+            PROBE_ASM_M("v_cndmask_b32_e64 %0, %8, %9, %12", "v_cndmask_b32_e64 %1, %8, %9, %12", "v_cndmask_b32_e64 %2, %8, %9, %12",
+                        "v_cndmask_b32_e64 %3, %8, %9, %12", "v_cndmask_b32_e64 %4, %8, %9, %12", "v_cndmask_b32_e64 %5, %8, %9, %12",
+                        "v_cndmask_b32_e64 %6, %8, %9, %12", "v_cndmask_b32_e64 %7, %8, %9, %12");
+        else if constexpr (OP == OP_CMP_CNDMASK_PAIR)
+            PROBE_ASM_V("v_cmp_gt_u32_e32 vcc, %10, %8", "v_cndmask_b32_e32 %1, %8, %9, vcc", "v_cmp_gt_u32_e32 vcc, %10, %9", "v_cndmask_b32_e32 %3, %8, %9, vcc",
+                        "v_cmp_gt_u32_e32 vcc, %10, %8", "v_cndmask_b32_e32 %5, %8, %9, vcc", "v_cmp_gt_u32_e32 vcc, %10, %9", "v_cndmask_b32_e32 %7, %8, %9, vcc");
+        else if constexpr (OP == OP_CNDMASK_VCC_CONSTS)
+            PROBE_ASM_V("v_cndmask_b32_e64 %0, 0, 1, vcc", "v_cndmask_b32_e64 %1, 0, 1, vcc", "v_cndmask_b32_e64 %2, 0, 1, vcc", "v_cndmask_b32_e64 %3, 0, 1, vcc",
+                        "v_cndmask_b32_e64 %4, 0, 1, vcc", "v_cndmask_b32_e64 %5, 0, 1, vcc", "v_cndmask_b32_e64 %6, 0, 1, vcc", "v_cndmask_b32_e64 %7, 0, 1, vcc");
+        else if constexpr (OP == OP_MIN_INDEP)
+            PROBE_ASM("v_min_u32_e32 %0, %8, %9", "v_min_u32_e32 %1, %8, %9", "v_min_u32_e32 %2, %8, %9", "v_min_u32_e32 %3, %8, %9",
+                      "v_min_u32_e32 %4, %8, %9", "v_min_u32_e32 %5, %8, %9", "v_min_u32_e32 %6, %8, %9", "v_min_u32_e32 %7, %8, %9");
+        else if constexpr (OP == OP_SUB_INDEP)
+            PROBE_ASM("v_sub_u32_e32 %0, %8, %9", "v_sub_u32_e32 %1, %8, %9", "v_sub_u32_e32 %2, %8, %9", "v_sub_u32_e32 %3, %8, %9",
+                      "v_sub_u32_e32 %4, %8, %9", "v_sub_u32_e32 %5, %8, %9", "v_sub_u32_e32 %6, %8, %9", "v_sub_u32_e32 %7, %8, %9");
+        else if constexpr (OP == OP_XOR_VARIED)
+            PROBE_ASM("v_xor_b32_e32 %0, %1, %2", "v_xor_b32_e32 %1, %2, %3", "v_xor_b32_e32 %2, %3, %4", "v_xor_b32_e32 %3, %4, %5",
+                      "v_xor_b32_e32 %4, %5, %6", "v_xor_b32_e32 %5, %6, %7", "v_xor_b32_e32 %6, %7, %8", "v_xor_b32_e32 %7, %8, %9");
+        else if constexpr (OP == OP_LSHRREV_INDEP)
+            PROBE_ASM("v_lshrrev_b32_e32 %0, 8, %9", "v_lshrrev_b32_e32 %1, 8, %9", "v_lshrrev_b32_e32 %2, 8, %9", "v_lshrrev_b32_e32 %3, 8, %9",
+                      "v_lshrrev_b32_e32 %4, 8, %9", "v_lshrrev_b32_e32 %5, 8, %9", "v_lshrrev_b32_e32 %6, 8, %9", "v_lshrrev_b32_e32 %7, 8, %9");
+        else if constexpr (OP == OP_ADD_CO_VCC)
+            PROBE_ASM_V("v_add_co_u32_e32 %0, vcc, %8, %9", "v_add_co_u32_e32 %1, vcc, %8, %9", "v_add_co_u32_e32 %2, vcc, %8, %9", "v_add_co_u32_e32 %3, vcc, %8, %9",
+                        "v_add_co_u32_e32 %4, vcc, %8, %9", "v_add_co_u32_e32 %5, vcc, %8, %9", "v_add_co_u32_e32 %6, vcc, %8, %9", "v_add_co_u32_e32 %7, vcc, %8, %9");
         else if constexpr (OP == OP_MIX_PERM_BITOP)
             PROBE_ASM("v_perm_b32 %0, %0, %9, %8", "v_bitop3_b32 %1, %8, %9, %1 bitop3:0x96", "v_add_u32_e32 %2, %8, %2", "v_perm_b32 %3, %3, %9, %8",
                       "v_bitop3_b32 %4, %8, %9, %4 bitop3:0x96", "v_add_u32_e32 %5, %8, %5", "v_perm_b32 %6, %6, %9, %8", "v_bitop3_b32 %7, %8, %9, %7 bitop3:0x96");
     }
     asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1)::"memory");
+    d0 ^= (uint32_t)mask;
     uint32_t acc = d0 ^ d1 ^ d2 ^ d3 ^ d4 ^ d5 ^ d6 ^ d7 ^ (uint32_t)(q0 ^ q1 ^ q2 ^ q3 ^ q4 ^ q5 ^ q6 ^ q7) ^ (uint32_t)((q0 ^ q3 ^ q7) >> 32);
     if (acc == 0x12345678u && seed == 0xFFFFFFFEu) sink[0] = acc;  // never true in practice: keeps the results live
     if ((threadIdx.x & 63u) == 0u) {
