@@ -52,8 +52,11 @@ sys.path.insert(0, str(REPO))
 ALGO_BYTES_PER_STEP = 38  # 16 board in + 1 action in + 16 board out + 4 reward out + 1 done out
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling ~6290
 INFINITY_CACHE_BYTES = 256 << 20
-# VALU issue ceiling: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles per SIMD, 2.4 GHz peak clock
-VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 4
+# VALU issue ceiling of the step kernel's OWN instruction mix, measured: tools/issue_probe (per-opcode cycles per wave64
+# instruction per SIMD at 1/2/4/8 waves per SIMD, on an MI355X) weighted with the kernel's opcode histogram by
+# tools/valu_ceiling.py -> profiles/valu_ceiling.json.  A 2^20-board launch of the four-boards-per-lane tiling puts 4 waves on
+# every SIMD.  The fallback is the figure of the committed table (2.85 cycles per instruction -> 862 G wave-instr/s).
+VALU_PEAK_GINSTR_FALLBACK = 256 * 4 * 2.4 / 2.85
 SEED = 0x2048
 KERNEL_SOURCES = ['simulate_2048_amd/csrc/env2048_kernels.hip', 'simulate_2048_amd/csrc/board_ops.hpp']
 
@@ -76,6 +79,10 @@ def parse_args(argv=None):
     ap.add_argument('--no-other-configs', action='store_true', help='skip the BASELINE configs[1] / configs[4] legs')
     ap.add_argument('--extras', action='store_true', help='also emit legal mask + obs (not the headline)')
     ap.add_argument('--obs-dtype', choices=['f32', 'f16', 'bf16'], default='f32', help='with --extras: element type of obs')
+    ap.add_argument('--single-process', action='store_true', help='ONE process drives all --gpus devices through ShardedEnv2048 (a worker '
+                    'thread + stream per device) instead of one rank per GPU; no torch.distributed at all')
+    ap.add_argument('--shards-on-device-0', action='store_true', help='with --single-process: put all --gpus shards on device 0 (REHEARSAL of '
+                    'the fan-out on a box with fewer GPUs; not a scaling measurement)')
     ap.add_argument('--dist-backend', default='nccl', help="'nccl' (= RCCL, one GPU per rank); 'gloo' = REHEARSAL of the "
                     'multi-rank logic on a box with fewer GPUs than ranks (all ranks then share device 0; numbers are not a '
                     'scaling measurement and the JSON says so)')
@@ -256,6 +263,68 @@ def load_step_profile(boards: int, leg: str):
         return None
 
 
+def valu_ceiling(waves_per_simd: int = 4):
+    """(G wave-instructions/s, source text) of the measured VALU ceiling for the step kernel's mix."""
+    path = REPO / 'profiles' / 'valu_ceiling.json'
+    try:
+        table = json.loads(path.read_text())
+        row = table['ceiling'][str(waves_per_simd)]
+        return row['g_wave_instr_per_s'], (f'profiles/valu_ceiling.json: {row["cycles_per_wave_instruction"]} cycles per wave64 instruction for this '
+                                           f'kernel\'s opcode mix at {waves_per_simd} waves per SIMD (tools/issue_probe on MI355X: {table["probe"]}), '
+                                           f'1024 SIMDs x 2.4 GHz')
+    except Exception:
+        return VALU_PEAK_GINSTR_FALLBACK, 'fallback constant of bench.py (profiles/valu_ceiling.json not readable)'
+
+
+def build_roofline(args, lib, n: int, flags: int, launch_s: float, obs_bytes: int) -> dict:
+    """The roofline object of a run whose dominant kernel is one env2048_step launch over n boards taking launch_s."""
+    bytes_per_launch = ALGO_BYTES_PER_STEP * n + (n * (1 + 16 * obs_bytes) if args.extras else 0)
+    algo_gbs = bytes_per_launch / launch_s / 1e9
+    working_set = n * (16 + 8 + 4 + 1) + (n * (1 + 16 * obs_bytes) if args.extras else 0)  # boards + 8-array action pool + outputs
+    resident = working_set <= INFINITY_CACHE_BYTES
+    prof = None if args.extras else load_step_profile(n, 'resident')
+    plan = lib.step_plan(n, flags)  # the library's own launch policy (env2048_step_plan), not a copy of its size rule
+    tiling = plan['boards_per_lane']
+    kernel = f'step_kernel<false, false, {tiling}>' if not args.extras else f'step_kernel<true, false, {tiling}>'
+    roofline = {
+        'kernel': kernel,
+        'launch_plan': plan,
+        'avg_launch_us': launch_s * 1e6,
+        'algorithmic_bytes_per_launch': bytes_per_launch,
+        'traffic': None if prof is None else prof.get('fabric_bytes_per_launch'),
+        'traffic_kind': 'fabric bytes per launch (2*FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes): L2 <-> Infinity '
+                        'Cache/HBM requests -- Infinity-Cache hits are counted, so this is HBM traffic only for the cold leg',
+        'traffic_source': None if prof is None else dict(source=prof.get('source'), stale=prof['stale']),
+    }
+    if resident and prof is not None and prof.get('valu_insts_per_launch'):
+        ginstr = prof['valu_insts_per_launch'] / launch_s / 1e9
+        waves_per_simd = max(1, min(8, round(n / (64 * tiling) / 1024)))
+        peak, peak_source = valu_ceiling(4 if waves_per_simd >= 4 else 2 if waves_per_simd >= 2 else 1)
+        per_lane = prof['valu_insts_per_launch'] * 64 / n  # wave64 instructions x 64 lanes / boards
+        roofline.update({
+            'bound': 'valu',
+            'achieved': ginstr,
+            'peak': peak,
+            'peak_source': peak_source,
+            'unit': 'G wave-instr/s',
+            'frac': ginstr / peak,
+            'why': f'working set {working_set / 2**20:.0f} MiB is Infinity-Cache resident at this size, so no HBM fraction can be quoted '
+                   f'for this leg; of the on-chip limits VALU issue is the nearest: {per_lane:.0f} VALU instructions per board-step '
+                   f'(SQ_INSTS_VALU {prof["valu_insts_per_launch"]:.0f} wave64 instructions per launch = {prof["valu_insts_per_launch"] / n:.2f} per board, '
+                   f'x 64 lanes / board), against the MEASURED issue ceiling of this opcode mix at {waves_per_simd} waves per SIMD.  '
+                   f'The launch is 15-20 % above its memory-only floor (tools/microbench, DESIGN 6.1); the HBM fraction of this '
+                   f'kernel is roofline.hbm_cold',
+            'hbm_resident_equiv': {'achieved': algo_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': algo_gbs / HBM_PEAK_GBS,
+                                   'note': 'algorithmic bytes / launch time; NOT an HBM fraction while the working set is cache-resident'},
+        })
+    else:
+        roofline.update({'bound': 'hbm', 'achieved': algo_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': algo_gbs / HBM_PEAK_GBS})
+        if resident:
+            roofline['why'] = ('working set is Infinity-Cache resident and no fresh VALU counter profile is committed for this size: '
+                               'algorithmic bytes / launch time is given, see hbm_cold for the HBM fraction')
+    return roofline
+
+
 def workload_text(n: int) -> str:
     which = {1 << 16: 'BASELINE configs[1]', 1 << 20: 'BASELINE configs[2]'}.get(n, 'BASELINE configs[2] workload at a non-default size')
     count = f'{n:,}'.replace(',', ' ')
@@ -326,189 +395,170 @@ def run_rank(args) -> None:
         dist.all_gather(out, t)
         return [o.cpu().tolist() for o in out]
 
-    n = args.boards
-    K, W = args.steps, args.warmup
-    obs_bytes = 4 if args.obs_dtype == 'f32' else 2
-    obs_dtype = {'f32': torch.float32, 'f16': torch.float16, 'bf16': torch.bfloat16}[args.obs_dtype]
-    env_base = rank * n
-    env = BatchedEnv2048(n, SEED, device=device, env_base=env_base, auto_reset=True, with_legal=args.extras,
-                         with_obs=args.extras, obs_dtype=obs_dtype)
-    env.reset()
-    for _ in range(64):  # bring the boards to mid-game
-        env.step(None)
-    torch.cuda.synchronize()
-    midgame = env.boards.clone()
-    boards_midgame = midgame.cpu().numpy() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+    def teardown():
+        if dist is not None:
+            try:
+                dist.barrier()
+            finally:
+                dist.destroy_process_group()
 
-    # host-provided actions: a small pool of uint8 arrays, cycled
-    gen = torch.Generator(device='cpu').manual_seed(1 + rank)
-    pool = [torch.randint(0, 4, (n,), generator=gen, dtype=torch.uint8).to(device) for _ in range(8)]
+    def body():
+        n = args.boards
+        K, W = args.steps, args.warmup
+        obs_bytes = 4 if args.obs_dtype == 'f32' else 2
+        obs_dtype = {'f32': torch.float32, 'f16': torch.float16, 'bf16': torch.bfloat16}[args.obs_dtype]
+        env_base = rank * n
+        env = BatchedEnv2048(n, SEED, device=device, env_base=env_base, auto_reset=True, with_legal=args.extras,
+                             with_obs=args.extras, obs_dtype=obs_dtype)
+        env.reset()
+        for _ in range(64):  # bring the boards to mid-game
+            env.step(None)
+        torch.cuda.synchronize()
+        midgame = env.boards.clone()
+        boards_midgame = midgame.cpu().numpy() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
 
-    lib = capi.library()
-    stream = torch.cuda.current_stream(device)
-    h = stream.cuda_stream
-    p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
-    flags = env.flags
+        # host-provided actions: a small pool of uint8 arrays, cycled
+        gen = torch.Generator(device='cpu').manual_seed(1 + rank)
+        pool = [torch.randint(0, 4, (n,), generator=gen, dtype=torch.uint8).to(device) for _ in range(8)]
 
-    tables = {}
+        lib = capi.library()
+        stream = torch.cuda.current_stream(device)
+        h = stream.cuda_stream
+        p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+        flags = env.flags
 
-    def action_table(count: int, first: int):
-        """Host array of `count` device pointers cycling through the action pool (built once per (count, phase): the timed
-        region then holds the C call and nothing else)."""
-        key = (count, first & 7)
-        if key not in tables:
-            tables[key] = (ctypes.c_void_p * count)(*[pool[(first + t) & 7].data_ptr() for t in range(count)])
-        return tables[key]
+        tables = {}
 
-    step_index = env.step_index
-    fixed = (p(env.boards), p(env.reward), p(env.done), p(env.legal), p(env.obs))
-    step_sequence = lib._dll.env2048_step_sequence  # the raw entry point: argument conversion is all the Python left per block
+        def action_table(count: int, first: int):
+            """Host array of `count` device pointers cycling through the action pool (built once per (count, phase): the timed
+            region then holds the C call and nothing else)."""
+            key = (count, first & 7)
+            if key not in tables:
+                tables[key] = (ctypes.c_void_p * count)(*[pool[(first + t) & 7].data_ptr() for t in range(count)])
+            return tables[key]
 
-    def run_steps(count: int) -> None:
-        """`count` dependent step launches, enqueued from C by one call."""
-        nonlocal step_index
-        if count <= 0:
+        step_index = env.step_index
+        fixed = (p(env.boards), p(env.reward), p(env.done), p(env.legal), p(env.obs))
+        step_sequence = lib._dll.env2048_step_sequence  # the raw entry point: argument conversion is all the Python left per block
+
+        def run_steps(count: int) -> None:
+            """`count` dependent step launches, enqueued from C by one call."""
+            nonlocal step_index
+            if count <= 0:
+                return
+            rc = step_sequence(device_index, h, n, env_base, fixed[0], action_table(count, step_index), fixed[1], fixed[2], fixed[3], fixed[4],
+                               0, SEED, step_index, count, flags)
+            if rc != 0:
+                raise capi.Env2048Error(rc, lib.last_error())
+            step_index += count
+
+        for phase in range(8):
+            action_table(K, phase)
+        enqueue_times = []
+
+        def timed_block(count: int):
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ev0.record(stream)
+            run_steps(count)
+            enqueued = time.perf_counter() - t0
+            ev1.record(stream)
+            torch.cuda.synchronize()
+            wall = time.perf_counter() - t0
+            enqueue_times.append(enqueued / max(count, 1))
+            return wall, ev0.elapsed_time(ev1) * 1e-3
+
+        if args.only_cold:
+            cold = cold_leg(args, torch, lib, capi, device, device_index, h, stream, n, env_base, world, midgame, pool, flags, 8e-6)
+            if rank == 0:
+                emit(json.dumps({'hbm_cold': cold}))
             return
-        rc = step_sequence(device_index, h, n, env_base, fixed[0], action_table(count, step_index), fixed[1], fixed[2], fixed[3], fixed[4],
-                           0, SEED, step_index, count, flags)
-        if rc != 0:
-            raise capi.Env2048Error(rc, lib.last_error())
-        step_index += count
-
-    for phase in range(8):
-        action_table(K, phase)
-    enqueue_times = []
-
-    def timed_block(count: int):
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        run_steps(W)
+        torch.cuda.synchronize()
+        # how many blocks: cover --min-ms of GPU time (the same count on every rank: calibrate on the max over ranks)
+        calib = reduce_max([timed_block(K)[1]])[0]
+        blocks = int(min(args.max_blocks, max(3, math.ceil(args.min_ms * 1e-3 / max(calib, 1e-7)))))
+        walls, events = [], []
+        for _ in range(blocks):
+            wall, ev = timed_block(K)
+            walls.append(wall)
+            events.append(ev)
         barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        ev0.record(stream)
-        run_steps(count)
-        enqueued = time.perf_counter() - t0
-        ev1.record(stream)
-        torch.cuda.synchronize()
-        wall = time.perf_counter() - t0
-        enqueue_times.append(enqueued / max(count, 1))
-        return wall, ev0.elapsed_time(ev1) * 1e-3
+        walls_max = reduce_max(walls)      # per block: the slowest rank
+        events_max = reduce_max(events)
+        per_rank = gather([statistics.median(events) / K * 1e6, statistics.median(walls) / K * 1e6])
+        wall = statistics.median(walls_max)
+        launch_s = statistics.median(events_max) / K
 
-    if args.only_cold:
-        launch_s = 8e-6
-        cold = cold_leg(args, torch, lib, capi, device, device_index, h, stream, n, env_base, world, midgame, pool, flags, launch_s)
+        # ---- HBM-cold leg: same launch size, round-robin over disjoint buffer sets that exceed the Infinity Cache -------
+        cold = None
+        if not args.no_cold and not args.extras:
+            cold = cold_leg(args, torch, lib, capi, device, device_index, h, stream, n, env_base, world, midgame, pool, flags, launch_s)
+
+        # ---- BASELINE configs[1] and configs[4], single GPU only (reported next to the headline, not as `value`) ---------
+        other = None
+        if not args.no_other_configs and world == 1 and not args.extras:
+            other = other_configs(torch, lib, device, device_index, h)
+
         if rank == 0:
-            emit(json.dumps({'hbm_cold': cold}))
-        return
-    run_steps(W)
-    torch.cuda.synchronize()
-    # how many blocks: cover --min-ms of GPU time (the same count on every rank: calibrate on the max over ranks)
-    calib = reduce_max([timed_block(K)[1]])[0]
-    blocks = int(min(args.max_blocks, max(3, math.ceil(args.min_ms * 1e-3 / max(calib, 1e-7)))))
-    walls, events = [], []
-    for _ in range(blocks):
-        wall, ev = timed_block(K)
-        walls.append(wall)
-        events.append(ev)
-    barrier()
-    walls_max = reduce_max(walls)      # per block: the slowest rank
-    events_max = reduce_max(events)
-    per_rank = gather([statistics.median(events) / K * 1e6, statistics.median(walls) / K * 1e6])
-    wall = statistics.median(walls_max)
-    launch_s = statistics.median(events_max) / K
+            total_steps = float(n) * K * world
+            value = total_steps / wall
+            roofline = build_roofline(args, lib, n, flags, launch_s, obs_bytes)
+            if cold is not None:
+                roofline['hbm_cold'] = cold
+            out = {
+                'metric': 'env_board_steps_per_sec',
+                'value': value,
+                'unit': 'board-steps/s',
+                'n_gpus': world,
+                'steps': K,
+                'warmup': W,
+                'ms_per_step': wall * 1e3 / K,
+                'higher_is_better': True,
+                'scaling': 'weak',
+                'vs_baseline': None,
+                'dtype': 'u8',
+                'data': 'synthetic',
+                'config': {
+                    'workload': workload_text(n),
+                    'boards_per_gpu': n,
+                    'global_boards': n * world,
+                    'launch_mode': 'env2048_step_sequence: K launches enqueued from C by one call',
+                    'sharding': 'contiguous env-index slices, one process per GPU, no collective on the hot path',
+                    'outputs': 'board,reward,done' + (f',legal,obs({args.obs_dtype})' if args.extras else ''),
+                },
+                'timing': {
+                    'blocks': blocks,
+                    'block_steps': K,
+                    'wall_us_per_step': {'median': wall / K * 1e6, 'min': min(walls_max) / K * 1e6, 'max': max(walls_max) / K * 1e6},
+                    'event_us_per_step': {'median': launch_s * 1e6, 'min': min(events_max) / K * 1e6, 'max': max(events_max) / K * 1e6},
+                    'per_rank_us_per_step': [{'rank': r, 'event': v[0], 'wall': v[1]} for r, v in enumerate(per_rank)],
+                    'host_enqueue_us_per_launch': statistics.median(enqueue_times) * 1e6,  # rank 0; meaningful while the launch queue has room (small K)
+                    'note': 'value = boards x K x ranks / median over blocks of (max over ranks of the block wall time)',
+                },
+                'roofline': roofline,
+            }
+            if rehearsal:
+                out['config']['rehearsal'] = (f'{world} gloo ranks SHARING one GPU: exercises the multi-rank code path only; '
+                                              f'not a scaling measurement')
+            if other is not None:
+                out['other_configs'] = other
+            if boards_midgame is not None:
+                out['cpu_baseline'] = cpu_baseline(boards_midgame, args.cpu_seconds)
+            elif world > 1:
+                out['cpu_baseline'] = None
+                out['cpu_baseline_note'] = 'timed on rank 0 of the N = 1 run only (the contract); run bench.py --gpus 1 for it'
+            elif args.no_cpu_baseline:
+                out['cpu_baseline'] = None
+                out['cpu_baseline_note'] = 'skipped by --no-cpu-baseline'
+            emit(json.dumps(out))
 
-    # ---- HBM-cold leg: same launch size, round-robin over disjoint buffer sets that exceed the Infinity Cache -------
-    cold = None
-    if not args.no_cold and not args.extras:
-        cold = cold_leg(args, torch, lib, capi, device, device_index, h, stream, n, env_base, world, midgame, pool, flags, launch_s)
-
-    # ---- BASELINE configs[1] and configs[4], single GPU only (reported next to the headline, not as `value`) ---------
-    other = None
-    if not args.no_other_configs and world == 1 and not args.extras:
-        other = other_configs(torch, lib, device, device_index, h)
-
-    if rank == 0:
-        total_steps = float(n) * K * world
-        value = total_steps / wall
-        bytes_per_launch = ALGO_BYTES_PER_STEP * n + (n * (1 + 16 * obs_bytes) if args.extras else 0)
-        algo_gbs = bytes_per_launch / launch_s / 1e9
-        working_set = n * (16 + 8 + 4 + 1) + (n * (1 + 16 * obs_bytes) if args.extras else 0)  # boards + 8-array action pool + outputs
-        resident = working_set <= INFINITY_CACHE_BYTES
-        prof = None if args.extras else load_step_profile(n, 'resident')
-        tiling = 1 if n <= (1 << 18) else 4  # the launch-size rule of env2048_step (one / four boards per lane)
-        kernel = f'step_kernel<false, false, {tiling}>' if not args.extras else f'step_kernel<true, false, {tiling}>'
-        roofline = {
-            'kernel': kernel,
-            'avg_launch_us': launch_s * 1e6,
-            'algorithmic_bytes_per_launch': bytes_per_launch,
-            'traffic': None if prof is None else prof.get('fabric_bytes_per_launch'),
-            'traffic_kind': 'fabric bytes per launch (2*FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes): L2 <-> Infinity '
-                            'Cache/HBM requests -- Infinity-Cache hits are counted, so this is HBM traffic only for the cold leg',
-            'traffic_source': None if prof is None else dict(source=prof.get('source'), stale=prof['stale']),
-        }
-        if resident and prof is not None and prof.get('valu_insts_per_launch'):
-            ginstr = prof['valu_insts_per_launch'] / launch_s / 1e9
-            roofline.update({
-                'bound': 'valu',
-                'achieved': ginstr,
-                'peak': VALU_PEAK_GINSTR,
-                'unit': 'G wave-instr/s',
-                'frac': ginstr / VALU_PEAK_GINSTR,
-                'why': f'working set {working_set / 2**20:.0f} MiB is Infinity-Cache resident at this size: the limiter is VALU issue '
-                       f'({prof["valu_insts_per_launch"] / n:.0f} VALU instructions per board-step, SQ_INSTS_VALU), peak = 1024 SIMDs x '
-                       f'2.4 GHz / 4 cycles per wave64 instruction; the HBM fraction of this kernel is roofline.hbm_cold',
-                'hbm_resident_equiv': {'achieved': algo_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': algo_gbs / HBM_PEAK_GBS,
-                                       'note': 'algorithmic bytes / launch time; NOT an HBM fraction while the working set is cache-resident'},
-            })
-        else:
-            roofline.update({'bound': 'hbm', 'achieved': algo_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': algo_gbs / HBM_PEAK_GBS})
-            if resident:
-                roofline['why'] = ('working set is Infinity-Cache resident and no fresh VALU counter profile is committed for this size: '
-                                   'algorithmic bytes / launch time is given, see hbm_cold for the HBM fraction')
-        if cold is not None:
-            roofline['hbm_cold'] = cold
-        out = {
-            'metric': 'env_board_steps_per_sec',
-            'value': value,
-            'unit': 'board-steps/s',
-            'n_gpus': world,
-            'steps': K,
-            'warmup': W,
-            'ms_per_step': wall * 1e3 / K,
-            'higher_is_better': True,
-            'scaling': 'weak',
-            'vs_baseline': None,
-            'dtype': 'u8',
-            'data': 'synthetic',
-            'config': {
-                'workload': workload_text(n),
-                'boards_per_gpu': n,
-                'global_boards': n * world,
-                'launch_mode': 'env2048_step_sequence: K launches enqueued from C by one call',
-                'sharding': 'contiguous env-index slices, one process per GPU, no collective on the hot path',
-                'outputs': 'board,reward,done' + (f',legal,obs({args.obs_dtype})' if args.extras else ''),
-            },
-            'timing': {
-                'blocks': blocks,
-                'block_steps': K,
-                'wall_us_per_step': {'median': wall / K * 1e6, 'min': min(walls_max) / K * 1e6, 'max': max(walls_max) / K * 1e6},
-                'event_us_per_step': {'median': launch_s * 1e6, 'min': min(events_max) / K * 1e6, 'max': max(events_max) / K * 1e6},
-                'per_rank_us_per_step': [{'rank': r, 'event': v[0], 'wall': v[1]} for r, v in enumerate(per_rank)],
-                'host_enqueue_us_per_launch': statistics.median(enqueue_times) * 1e6,  # rank 0; meaningful while the launch queue has room (small K)
-                'note': 'value = boards x K x ranks / median over blocks of (max over ranks of the block wall time)',
-            },
-            'roofline': roofline,
-        }
-        if rehearsal:
-            out['config']['rehearsal'] = (f'{world} gloo ranks SHARING one GPU: exercises the multi-rank code path only; '
-                                          f'not a scaling measurement')
-        if other is not None:
-            out['other_configs'] = other
-        if boards_midgame is not None:
-            out['cpu_baseline'] = cpu_baseline(boards_midgame, args.cpu_seconds)
-        emit(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    try:
+        body()
+    finally:
+        teardown()  # also on the --only-cold path and when a leg raises (ADVICE r2)
 
 
 def cold_leg(args, torch, lib, capi, device, device_index, h, stream, n, env_base, world, midgame, pool, flags, launch_s) -> dict:
@@ -525,102 +575,73 @@ def cold_leg(args, torch, lib, capi, device, device_index, h, stream, n, env_bas
     cold_step = 1 << 32
     hint = {'auto': 0, 'through': capi.FLAG_STORES_WRITE_THROUGH, 'back': capi.FLAG_STORES_WRITE_BACK}[args.cold_stores]
     hint |= {'auto': 0, 'small': capi.FLAG_TILE_SMALL, 'large': capi.FLAG_TILE_LARGE}[args.cold_tile]
-    extra_hint = 0
-
     def cold_pass() -> None:
         nonlocal cold_step
         for s in range(sets):
             records[s] = capi.StepArgs(n, (world + s) * n + env_base, cb[s].data_ptr(), ca[s].data_ptr(), cr[s].data_ptr(),
-                                       cd[s].data_ptr(), None, None, SEED, cold_step, flags | hint | extra_hint, 0)
+                                       cd[s].data_ptr(), None, None, SEED, cold_step, flags | hint, 0)
         lib.step_many(device_index, h, records)
         cold_step += 1
 
     for _ in range(3):
         cold_pass()
     torch.cuda.synchronize()
+    plan = lib.step_many_plan(records)
     passes = max(4, min(64, math.ceil(25e-3 / max(launch_s * sets, 1e-7))))
-    cold_times = []
-    for _ in range(3):
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record(stream)
-        for _ in range(passes):
-            cold_pass()
-        ev1.record(stream)
-        torch.cuda.synchronize()
-        cold_times.append(ev0.elapsed_time(ev1) * 1e-3 / (passes * sets))
-    cold_s = statistics.median(cold_times)
-    # the same launches with the one-board-per-lane tiling requested (ENV2048_FLAG_TILE_SMALL): four times as many, shorter
-    # workgroups run in two generations, so loads of later workgroups overlap the arithmetic of earlier ones -- slower on
-    # cache-resident data (where the default large tiling is chosen by size), faster on cold data
-    small_hint = None
-    if args.cold_tile == 'auto' and n > (1 << 18):
-        extra_hint = capi.FLAG_TILE_SMALL
-        cold_pass()
-        small_times = []
+
+    def time_passes(one_pass) -> float:
+        times = []
         for _ in range(3):
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record(stream)
             for _ in range(passes):
-                cold_pass()
+                one_pass()
             ev1.record(stream)
             torch.cuda.synchronize()
-            small_times.append(ev0.elapsed_time(ev1) * 1e-3 / (passes * sets))
-        extra_hint = 0
-        sm = statistics.median(small_times)
-        small_hint = {'us_per_launch': sm * 1e6, 'achieved': ALGO_BYTES_PER_STEP * n / sm / 1e9,
-                      'frac': ALGO_BYTES_PER_STEP * n / sm / 1e9 / HBM_PEAK_GBS,
-                      'note': 'same launches with ENV2048_FLAG_TILE_SMALL (caller-side hint for cold batches; not the default at this size)'}
-    # the same sets, but even / odd sets on two streams: consecutive launches are independent batches, so the tail of one
-    # launch may overlap the head of the next (what a caller with several independent cold batches would do)
-    side = torch.cuda.Stream(device)
-    even = (capi.StepArgs * ((sets + 1) // 2))()
-    odd = (capi.StepArgs * (sets // 2))()
+            times.append(ev0.elapsed_time(ev1) * 1e-3 / (passes * sets))
+        return statistics.median(times)
 
-    def cold_pass_two_streams() -> None:
+    cold_s = time_passes(cold_pass)
+    # the same records one env2048_step launch each (what round 2 measured, and what a DEPENDENT chain of cold launches pays):
+    # every launch is load-everything -> compute -> store-everything -> kernel boundary
+    single = (capi.StepArgs * 1)()
+
+    def separate_pass() -> None:
         nonlocal cold_step
         for s in range(sets):
-            rec = capi.StepArgs(n, (world + s) * n + env_base, cb[s].data_ptr(), ca[s].data_ptr(), cr[s].data_ptr(), cd[s].data_ptr(),
-                                None, None, SEED, cold_step, flags | hint | extra_hint, 0)
-            (odd if s & 1 else even)[s >> 1] = rec
-        lib.step_many(device_index, h, even)
-        lib.step_many(device_index, side.cuda_stream, odd)
+            single[0] = capi.StepArgs(n, (world + s) * n + env_base, cb[s].data_ptr(), ca[s].data_ptr(), cr[s].data_ptr(), cd[s].data_ptr(),
+                                      None, None, SEED, cold_step, flags | hint, 0)
+            lib.step_many(device_index, h, single)
         cold_step += 1
 
-    two_times = []
-    for _ in range(3):
-        ev0, ev1, evb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event()
-        ev0.record(stream)
-        side.wait_event(ev0)
-        for _ in range(passes):
-            cold_pass_two_streams()
-        evb.record(side)
-        stream.wait_event(evb)
-        ev1.record(stream)
-        torch.cuda.synchronize()
-        two_times.append(ev0.elapsed_time(ev1) * 1e-3 / (passes * sets))
-    two_s = statistics.median(two_times)
+    separate_pass()
+    separate_s = time_passes(separate_pass)
     prof = load_step_profile(n, 'cold')
+    gbs = lambda t: ALGO_BYTES_PER_STEP * n / t / 1e9
     return {
         'bound': 'hbm',
-        'achieved': ALGO_BYTES_PER_STEP * n / cold_s / 1e9,
+        'achieved': gbs(cold_s),
         'peak': HBM_PEAK_GBS,
         'unit': 'GB/s',
-        'frac': ALGO_BYTES_PER_STEP * n / cold_s / 1e9 / HBM_PEAK_GBS,
+        'frac': gbs(cold_s) / HBM_PEAK_GBS,
         'avg_launch_us': cold_s * 1e6,
+        'avg_launch_us_means': f'time per {n}-board record; the {sets} records of a call share {plan["launches"]} kernel launch(es)',
+        'kernel': f'step_many_kernel<false, false, {plan["boards_per_lane"][0]}>' if plan['launches'] < sets else f'step_kernel<false, false, {plan["boards_per_lane"][0]}>',
+        'launch_plan': {'records_per_call': sets, 'kernel_launches_per_call': plan['launches'], 'boards_per_lane': plan['boards_per_lane'][0],
+                        'write_through': plan['write_through'][0],
+                        'policy': 'env2048_step_many: consecutive records that touch disjoint memory share one launch (no caller hint)'},
         'buffer_sets': sets,
         'footprint_bytes': sets * set_bytes,
-        'launches_timed': passes * sets,
+        'records_timed': passes * sets,
         'stores': args.cold_stores,
         'tile': args.cold_tile,
-        'tile_small_hint': small_hint,
-        'two_streams': {'achieved': ALGO_BYTES_PER_STEP * n / two_s / 1e9, 'frac': ALGO_BYTES_PER_STEP * n / two_s / 1e9 / HBM_PEAK_GBS,
-                        'us_per_launch': two_s * 1e6,
-                        'note': 'even / odd sets on two streams (independent batches may overlap): aggregate bytes / time, not a '
-                                'single-launch duration'},
+        'separate_launches': {'us_per_launch': separate_s * 1e6, 'achieved': gbs(separate_s), 'frac': gbs(separate_s) / HBM_PEAK_GBS,
+                              'note': 'the same records as one kernel launch each (round 2\'s figure; what a dependent chain of cold '
+                                      'launches pays: a pipeline fill and drain per launch)'},
         'traffic': None if prof is None else prof.get('fabric_bytes_per_launch'),
         'traffic_source': None if prof is None else dict(source=prof.get('source'), stale=prof['stale']),
         'how': f'{sets} disjoint sets of (boards, actions, reward, done) = {sets * set_bytes / 2**20:.0f} MiB > 2 x Infinity Cache, '
-               f'stepped round-robin by env2048_step_many, so every launch reads and writes lines last touched {sets} launches ago',
+               f'stepped round-robin by env2048_step_many, so every record reads and writes lines last touched {sets} records ago',
     }
 
 
@@ -707,6 +728,27 @@ def other_configs(torch, lib, device, device_index, h) -> dict:
         graph_times.append((time.perf_counter() - t0, ev0.elapsed_time(ev1) * 1e-3))
     gwall, gev = sorted(graph_times)[len(graph_times) // 2]
     replayed = genv.step_index - 10_000
+    # the same workload with the moves STAGED ([200, N] uint8 rows): BatchedEnv2048.step_many picks env2048_replay at this size --
+    # one launch per 200 moves, boards in registers, 6 B per board-step, no per-move launch at all
+    renv = BatchedEnv2048(n1, SEED, device=device, auto_reset=True)
+    renv.boards.copy_(env.boards)
+    renv.step_index = 20_000
+    staged = torch.stack([pool[t & 7] for t in range(captured)]).contiguous()
+    rr = torch.zeros((captured, n1), dtype=torch.int32, device=device)
+    dd = torch.zeros((captured, n1), dtype=torch.uint8, device=device)
+    renv.step_many(staged, out_reward=rr, out_done=dd)
+    replay_times = []
+    for rep in range(4):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        for _ in range(10):
+            renv.step_many(staged, out_reward=rr, out_done=dd)
+        ev1.record(stream)
+        torch.cuda.synchronize()
+        replay_times.append((time.perf_counter() - t0, ev0.elapsed_time(ev1) * 1e-3))
+    rwall, rev = sorted(replay_times)[len(replay_times) // 2]
     out['configs[1]'] = {
         'workload': '65 536 parallel boards, uint8 log2-packed, uniform random host actions, auto-reset, 1 GPU',
         'value': n1 * count / wall, 'unit': 'board-steps/s', 'us_per_step_wall': wall / count * 1e6, 'us_per_step_event': ev / count * 1e6,
@@ -716,8 +758,13 @@ def other_configs(torch, lib, device, device_index, h) -> dict:
                                  'us_per_step_event': gev / (captured * 10) * 1e6, 'steps_replayed_check': replayed == captured * 41,
                                  'note': f'{captured} step launches + one counter-advance node captured once (device-side step counter), graph replayed: '
                                          f'no per-step host cost'},
+        'as_staged_moves_one_replay_launch': {'value': n1 * captured * 10 / rwall, 'unit': 'board-steps/s',
+                                              'us_per_step_wall': rwall / (captured * 10) * 1e6, 'us_per_step_event': rev / (captured * 10) * 1e6,
+                                              'speedup_vs_launches': (wall / count) / (rwall / (captured * 10)),
+                                              'note': f'BatchedEnv2048.step_many(actions[{captured}, N]) -> ONE env2048_replay launch per {captured} moves '
+                                                      f'(reward / done rows written per move); the small-batch answer when the moves are known up front'},
     }
-    del env, pool, genv, graph
+    del env, pool, genv, graph, renv, staged, rr, dd
 
     # configs[4]
     n4, T = 1 << 20, 512
@@ -795,8 +842,84 @@ def other_configs(torch, lib, device, device_index, h) -> dict:
     return out
 
 
+def run_single_process(args) -> None:
+    """--single-process: the whole node from ONE process (ShardedEnv2048: contiguous slices, one worker thread and one stream
+    per device, no collective, no torch.distributed).  A timed block = synchronise all devices | every shard's K launches
+    enqueued by its own thread through one env2048_step_sequence call | synchronise all devices."""
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+    import torch
+
+    from simulate_2048_amd import capi
+    from simulate_2048_amd.sharded import ShardedEnv2048
+
+    if not torch.cuda.is_available():
+        sys.exit('bench.py needs a HIP device: the product path has no CPU fallback')
+    G, n, K, W = args.gpus, args.boards, args.steps, args.warmup
+    rehearsal = args.shards_on_device_0
+    if not rehearsal and G > torch.cuda.device_count():
+        sys.exit(f'--gpus {G} but only {torch.cuda.device_count()} visible device(s); --shards-on-device-0 rehearses the fan-out on one')
+    devices = [torch.device('cuda', 0 if rehearsal else g) for g in range(G)]
+    env = ShardedEnv2048(n * G, SEED, devices=devices, auto_reset=True)
+    lib = capi.library()
+    env.reset()
+    env.step_sequence(64)  # mid-game boards (on-device random actions)
+    gen = torch.Generator(device='cpu').manual_seed(1)
+    pools = [[torch.randint(0, 4, (c,), generator=gen, dtype=torch.uint8).to(d) for _ in range(8)] for (_, c), d in zip(env.ranges, devices)]
+    tables = {}
+
+    def tables_for(count: int, first: int):
+        key = (count, first & 7)
+        if key not in tables:
+            tables[key] = [(ctypes.c_void_p * count)(*[pool[(first + t) & 7].data_ptr() for t in range(count)]) for pool in pools]
+        return tables[key]
+
+    for phase in range(8):
+        tables_for(K, phase)
+    env.step_sequence(W, tables_for(W, 0)) if W else None
+    env.synchronize()
+
+    def timed_block():
+        env.synchronize()
+        t0 = time.perf_counter()
+        env.step_sequence(K, tables_for(K, env.step_index))
+        env.synchronize()
+        return time.perf_counter() - t0
+
+    calib = timed_block()
+    blocks = int(min(args.max_blocks, max(3, math.ceil(args.min_ms * 1e-3 / max(calib, 1e-7)))))
+    walls = [timed_block() for _ in range(blocks)]
+    per_device_ms = env.timed(lambda g: env.shards[g].lib.step_sequence(
+        g if not rehearsal else 0, torch.cuda.current_stream(devices[g]).cuda_stream, env.shards[g].num_envs, env.shards[g].env_base,
+        env.shards[g].boards.data_ptr(), tables_for(K, 0)[g], env.shards[g].reward.data_ptr(), env.shards[g].done.data_ptr(), None, None, 0,
+        SEED, 10_000_000, K, env.shards[g].flags))
+    wall = statistics.median(walls)
+    launch_s = statistics.median(per_device_ms) * 1e-3 / K
+    out = {
+        'metric': 'env_board_steps_per_sec', 'value': float(n) * G * K / wall, 'unit': 'board-steps/s', 'n_gpus': G, 'steps': K, 'warmup': W,
+        'ms_per_step': wall * 1e3 / K, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u8', 'data': 'synthetic',
+        'config': {'workload': workload_text(n), 'boards_per_gpu': n, 'global_boards': n * G,
+                   'launch_mode': 'single process: ShardedEnv2048, one worker thread + one stream per device, each enqueuing its K launches '
+                                  'through one env2048_step_sequence call',
+                   'sharding': 'contiguous env-index slices, no collective, no torch.distributed', 'outputs': 'board,reward,done'},
+        'timing': {'blocks': blocks, 'block_steps': K,
+                   'wall_us_per_step': {'median': wall / K * 1e6, 'min': min(walls) / K * 1e6, 'max': max(walls) / K * 1e6},
+                   'per_device_event_us_per_step': [m * 1e3 / K for m in per_device_ms]},
+        'roofline': build_roofline(args, lib, n, env.shards[0].flags, launch_s, 4),
+        'cpu_baseline': None, 'cpu_baseline_note': 'timed by the default (rank-per-GPU, N = 1) run only',
+    }
+    if rehearsal:
+        out['config']['rehearsal'] = f'{G} shards SHARING device 0: exercises the single-process fan-out only; not a scaling measurement'
+    env.close()
+    os.write(result_fd, (json.dumps(out) + '\n').encode())
+
+
 def main():
     args = parse_args()
+    if args.single_process:
+        run_single_process(args)
+        return
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         # no torchrun environment: start one worker per GPU ourselves (children; this process never touches a GPU)
         sys.exit(spawn_ranks(args.gpus, [sys.executable, str(Path(__file__).resolve())] + sys.argv[1:]))

@@ -407,6 +407,15 @@ ENV2048_EXPORT int env2048_spawn_random(int device, void *stream, uint64_t n, ui
                                         uint64_t seed, uint64_t step_index, uint32_t count);
 
 /*
+ * The actions ENV2048_FLAG_RANDOM_ACTIONS makes env2048_step / env2048_rollout take at (seed, step_index), written out:
+ * actions[i] = low two bits of the step word of environment env_base + i.  A step played with this array as `actions`
+ * (without the flag) is bit for bit the step played with the flag -- recorders use it so that the action row of a
+ * random-play step says what was played (Trajectory.actions, reinforce/training/self_play.py:361).
+ */
+ENV2048_EXPORT int env2048_random_actions(int device, void *stream, uint64_t n, uint64_t env_base, uint64_t seed, uint64_t step_index,
+                                          uint8_t *actions);
+
+/*
  * All chance outcomes of an afterstate: for every board the 32 slots s = 2*k + v (k = rank of an
  * empty cell in row-major order, v = 0 for tile 2, 1 for tile 4) hold the board with that tile
  * placed and its probability P(tile) / n_empty (0.9 / 0.1); slots with k >= n_empty hold a zero

@@ -125,9 +125,14 @@ class BatchedEnv2048:
     def commit_steps(self) -> None:
         """``device_step_counter`` only: advance the device counter by the steps enqueued since the last commit (one
         one-thread kernel on the current stream).  Call it at the END of a region captured into a graph, so that every
-        replay of the graph plays the NEXT steps; in eager use it is optional (offsets simply keep growing)."""
+        replay of the graph plays the NEXT steps.  Eager steps commit by themselves; a capture that ends without it is reported
+        by the next step() / commit_steps()."""
         if self.step_counter is None or self._pending == 0:
             return
+        if self._in_capture and not (self.device.type == 'cuda' and torch.cuda.is_current_stream_capturing()):
+            pending, self._pending, self._in_capture = self._pending, 0, False  # (committing after the capture block: too late)
+            raise RuntimeError(f'commit_steps() must be called INSIDE the captured region ({pending} captured step(s) were left '
+                               'uncommitted: replays of that graph repeat the same step indices)')
         dev, stream = _stream_handle(self.device)
         self.lib.advance_counter(dev, stream, _p(self.step_counter), self._pending)
         self._pending = 0
@@ -144,9 +149,19 @@ class BatchedEnv2048:
         self.lib.reset(dev, stream, self.num_envs, self.env_base, _p(self.boards), _p(self.done), self.seed,
                        self.step_index)
         self.reward.zero_()
+        self.reset_episode_carry()  # every environment starts a new game: nothing is "in progress" any more
         if self.legal is not None or self.obs is not None:
             self.describe(self.legal, self.obs)
         return self.boards
+
+    def reset_episode_carry(self) -> None:
+        """Forget the game every environment is IN for ``rollout_episodes`` (running length / return, and the "this game was
+        already counted" marks of non-auto-reset runs).  ``reset()`` and ``set_boards()`` call it; call it yourself after
+        advancing the boards by other means (``step`` / ``rollout`` / ``replay`` do not see the carry) if the next
+        ``rollout_episodes`` should count games from the current boards on."""
+        if getattr(self, '_ep_length', None) is not None:
+            self._ep_length.zero_()
+            self._ep_return.zero_()
 
     def describe(self, legal: torch.Tensor | None, obs: torch.Tensor | None) -> None:
         """Legal mask / observation of the CURRENT boards into the given tensors (obs of this env's obs_dtype;
@@ -213,12 +228,15 @@ class BatchedEnv2048:
         return self.boards, reward, done
 
     def _step_with_counter(self, dev, stream, actions, flags, out_reward, out_done, out_legal, out_obs, out_max_exp, normalized_reward):
-        if self.device.type == 'cuda':
-            capturing = torch.cuda.is_current_stream_capturing()
-            if capturing and not self._in_capture and self._pending:
-                raise RuntimeError('call commit_steps() before capturing a graph: the captured launches must start at offset 0 of '
-                                   'the device step counter, or every replay would skip steps')
-            self._in_capture = capturing
+        capturing = self.device.type == 'cuda' and torch.cuda.is_current_stream_capturing()
+        if self._in_capture and not capturing and self._pending:
+            pending, self._pending, self._in_capture = self._pending, 0, False
+            raise RuntimeError(f'the captured region ended with {pending} step(s) not committed: call commit_steps() as the LAST '
+                               'thing inside the capture, or every replay of the graph repeats the same step indices')
+        if capturing and not self._in_capture and self._pending:
+            raise RuntimeError('call commit_steps() before capturing a graph: the captured launches must start at offset 0 of '
+                               'the device step counter, or every replay would skip steps')
+        self._in_capture = capturing
         if normalized_reward:
             if out_reward is None:
                 raise ValueError('normalized_reward=True needs a float32 out_reward tensor (the persistent reward buffer is int32)')
@@ -234,6 +252,11 @@ class BatchedEnv2048:
                                                    _p(legal), _p(obs), self.seed, self._pending, flags, 0, _p(max_exp), _p(self.step_counter)))
         self.lib.step_many(dev, stream, record)
         self._pending += 1
+        if not capturing:
+            # eager step: advance the device counter NOW (one 1-thread launch), so that a graph replayed afterwards continues
+            # behind this step instead of reusing its index; inside a capture the offsets accumulate until
+            # commit_steps() closes the region
+            self.commit_steps()
         return self.boards, reward, done
 
     def _check_out(self, t: torch.Tensor, dtype, shape) -> torch.Tensor:
@@ -241,6 +264,62 @@ class BatchedEnv2048:
             raise ValueError(f'output buffer must be a contiguous {dtype} tensor of shape {tuple(shape)} on {self.boards.device}, '
                              f'got {t.dtype} {tuple(t.shape)} on {t.device}')
         return t
+
+    def random_actions(self, out: torch.Tensor, step_index: int | None = None) -> torch.Tensor:
+        """Write into ``out`` (uint8, (N,)) the actions ``step(None)`` WOULD take at ``step_index`` (default: the next step):
+        the low two bits of every environment's step word (env2048_random_actions).  ``step(out)`` then plays exactly the step
+        ``step(None)`` would have played -- and the caller knows the moves (recorders need that)."""
+        if self.step_counter is not None and step_index is None:
+            raise RuntimeError('random_actions() needs an explicit step_index when the step counter lives on the device')
+        out = self._check_out(out, torch.uint8, (self.num_envs,))
+        dev, stream = _stream_handle(self.device)
+        self.lib.random_actions(dev, stream, self.num_envs, self.env_base, self.seed,
+                                self._step_index if step_index is None else int(step_index), _p(out))
+        return out
+
+    # launches up to this size are bound by the launch rate (3-4 us each), not by the kernel: K staged moves then go through ONE
+    # env2048_replay launch (boards in registers, 6 B per board-step) -- measured crossover in profiles/r02_p_rollout_sizes.json
+    REPLAY_MAX_ENVS = 1 << 18
+
+    def step_many(self, actions: torch.Tensor, *, out_reward: torch.Tensor | None = None, out_done: torch.Tensor | None = None,
+                  mode: str = 'auto'):
+        """K staged moves: ``actions`` (K, N) uint8 -> the boards / rewards / done flags of K ``step(actions[k])`` calls.
+        ``out_reward`` (K, N) int32 / ``out_done`` (K, N) uint8 receive the per-step rows (allocated when omitted).
+        ``mode``: 'replay' = one env2048_replay launch (no per-step launch: the small-batch answer), 'launches' = K step
+        launches enqueued by one env2048_step_sequence call, 'auto' = replay up to ``REPLAY_MAX_ENVS`` environments when only
+        reward / done rows are wanted (the env was built without legal / obs outputs), launches otherwise.
+        Returns ``(boards, reward_rows, done_rows)``."""
+        if actions.dtype != torch.uint8 or actions.dim() != 2 or actions.shape[1] != self.num_envs or not actions.is_contiguous() \
+                or actions.device != self.boards.device:
+            raise ValueError(f'actions must be a contiguous uint8 (K, {self.num_envs}) tensor on {self.boards.device}')
+        if self.step_counter is not None:
+            raise RuntimeError('step_many() keeps the step index on the host: build the env without device_step_counter')
+        K, n = int(actions.shape[0]), self.num_envs
+        reward = torch.empty((K, n), dtype=torch.int32, device=self.device) if out_reward is None else self._check_out(out_reward, torch.int32, (K, n))
+        done = torch.empty((K, n), dtype=torch.uint8, device=self.device) if out_done is None else self._check_out(out_done, torch.uint8, (K, n))
+        if mode not in ('auto', 'replay', 'launches'):
+            raise ValueError("mode must be 'auto', 'replay' or 'launches'")
+        plain = self.legal is None and self.obs is None
+        use_replay = mode == 'replay' or (mode == 'auto' and plain and n <= self.REPLAY_MAX_ENVS)
+        if use_replay and not plain:
+            raise ValueError("mode='replay' writes reward / done rows only: this env also emits legal / obs per step")
+        if K == 0:
+            return self.boards, reward, done
+        dev, stream = _stream_handle(self.device)
+        if use_replay:
+            self.lib.replay(dev, stream, n, self.env_base, self._ptr_boards, _p(actions), _p(reward), _p(done), n, self.seed,
+                            self._step_index, K, capi.FLAG_AUTO_RESET if self.auto_reset else 0, None, None, None)
+        else:
+            import ctypes
+
+            base = actions.data_ptr()
+            table = (ctypes.c_void_p * K)(*[base + k * n for k in range(K)])
+            self.lib.step_sequence(dev, stream, n, self.env_base, self._ptr_boards, table, _p(reward), _p(done), None, None, n,
+                                   self.seed, self._step_index, K, self.flags)
+            if self.legal is not None or self.obs is not None:  # the persistent legal / obs describe the LAST boards
+                self.describe(self.legal, self.obs)
+        self._step_index += K
+        return self.boards, reward, done
 
     def rollout(self, num_steps: int):
         """``num_steps`` transitions with on-device random actions in ONE kernel (boards stay in
@@ -279,10 +358,13 @@ class BatchedEnv2048:
     def rollout_episodes(self, num_steps: int, stats: torch.Tensor | None = None) -> torch.Tensor:
         """``num_steps`` random-action transitions in one kernel, with per-EPISODE statistics accumulated on device
         (env2048_rollout_episodes): returns the 40-word uint64 block as an int64 tensor (see ``episode_statistics``).
-        The game every environment is in is carried across calls, so games spanning calls are counted whole.  Pass the
-        tensor of a previous call as ``stats`` to keep accumulating."""
+        The game every environment is in is carried across CONSECUTIVE ``rollout_episodes`` calls, so games spanning calls are
+        counted whole; ``reset()`` / ``set_boards()`` clear that carry (``reset_episode_carry``).  ``step`` / ``rollout`` /
+        ``replay`` advance the boards without updating it: a game they end or begin in between is reported with the length
+        and return accumulated by ``rollout_episodes`` calls only -- do not interleave them within one statistics run, or
+        call ``reset_episode_carry()`` when you do.  Pass the tensor of a previous call as ``stats`` to keep accumulating."""
         n = self.num_envs
-        if not hasattr(self, '_ep_length'):
+        if getattr(self, '_ep_length', None) is None:
             self._ep_length = torch.zeros((n,), dtype=torch.int32, device=self.device)
             self._ep_return = torch.zeros((n,), dtype=torch.int64, device=self.device)
         if stats is None:
@@ -339,3 +421,4 @@ class BatchedEnv2048:
         """Overwrite the state with packed boards (anything convertible to an (N,16) uint8 tensor)."""
         b = torch.as_tensor(boards, dtype=torch.uint8).reshape(self.num_envs, 16)
         self.boards.copy_(b)
+        self.reset_episode_carry()

@@ -92,6 +92,7 @@ PROTOTYPES = {
     'env2048_afterstates4': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr]),
     'env2048_spawn': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr]),
     'env2048_spawn_random': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _u64, _u64, _u32]),
+    'env2048_random_actions': (_c_int, [_c_int, _ptr, _u64, _u64, _u64, _u64, _ptr]),
     'env2048_chance_outcomes': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr]),
     'env2048_expectimax_ply': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
     'env2048_status': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
@@ -216,6 +217,9 @@ class Library:
 
     def reset_keyed_i32_status(self, device, stream, n, keys, boards, obs, legal4) -> None:
         self._check(self._dll.env2048_reset_keyed_i32_status(device, stream, n, keys, boards, obs, legal4))
+
+    def random_actions(self, device, stream, n, env_base, seed, step_index, actions) -> None:
+        self._check(self._dll.env2048_random_actions(device, stream, n, env_base, seed, step_index, actions))
 
     def status_i32(self, device, stream, n, boards, obs, legal4, done) -> None:
         self._check(self._dll.env2048_status_i32(device, stream, n, boards, obs, legal4, done))

@@ -1307,6 +1307,23 @@ __global__ __launch_bounds__(BLOCK) void spawn_random_kernel(uint64_t n, uint64_
     store_board(boards, i, bd);
 }
 
+// The actions ENV2048_FLAG_RANDOM_ACTIONS makes a step take, materialised: action of environment env at (seed, step) = low two
+// bits of its step word.  For recorders: a step played with these actions read from memory is the same step (same words for
+// the spawn), and the action row then says what was played (recorded random steps had all-zero action rows).
+__global__ __launch_bounds__(BLOCK) void random_actions_kernel(uint64_t n, uint64_t env_base, uint32_t seed_lo, uint32_t seed_hi,
+                                                               uint64_t step_index, uint8_t *actions)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t env = env_base + i;
+    const RngKey key{seed_lo, seed_hi, (uint32_t)step_index, (uint32_t)(step_index >> 32)};
+    uint32_t w[4];
+    env_block(key, env >> 2, STREAM_STEP, w[0], w[1], w[2], w[3]);
+    const uint32_t sel = (uint32_t)env & 3u;
+    const uint32_t word = sel == 0u ? w[0] : sel == 1u ? w[1] : sel == 2u ? w[2] : w[3];
+    actions[i] = (uint8_t)(word & 3u);
+}
+
 // one thread per (board, outcome slot): 32 consecutive lanes write the 512 B of one board's outcomes
 __global__ __launch_bounds__(BLOCK) void chance_outcomes_kernel(uint64_t n, const uint8_t *boards, uint8_t *out_boards,
                                                                 float *out_prob, uint8_t *out_count)
@@ -2291,6 +2308,19 @@ int env2048_spawn_random(int device, void *stream, uint64_t n, uint64_t env_base
     hipLaunchKernelGGL(spawn_random_kernel, grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, n, env_base, boards,
                        (uint32_t)seed, (uint32_t)(seed >> 32), step_index, count);
     return launched("env2048_spawn_random launch");
+}
+
+int env2048_random_actions(int device, void *stream, uint64_t n, uint64_t env_base, uint64_t seed, uint64_t step_index, uint8_t *actions)
+{
+    if (n == 0) return ENV2048_OK;
+    if (!actions) return fail(ENV2048_ERR_INVALID_ARG, "env2048_random_actions: actions is NULL");
+    if (int rc = check_range(n, env_base)) return rc;
+    if (int rc = check_count(n)) return rc;
+    DeviceScope scope(device);
+    if (scope.rc) return scope.rc;
+    hipLaunchKernelGGL(random_actions_kernel, grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, n, env_base, (uint32_t)seed,
+                       (uint32_t)(seed >> 32), step_index, actions);
+    return launched("env2048_random_actions launch");
 }
 
 int env2048_chance_outcomes(int device, void *stream, uint64_t n, const uint8_t *boards, uint8_t *out_boards, float *out_prob,

@@ -78,6 +78,7 @@ class TrajectoryBuffer:
         self.obs = torch.zeros((C + extra, n, 16), dtype=env.obs_dtype, device=dev) if record_obs else None
         self.boards = torch.zeros((C + extra, n, 16), dtype=torch.uint8, device=dev) if record_boards else None
         self.t = 0  # steps recorded since begin()
+        self._unrecorded_random = False
 
     # -- bookkeeping --------------------------------------------------------------------------------------------
     @property
@@ -99,6 +100,7 @@ class TrajectoryBuffer:
     def begin(self) -> None:
         """Describe the CURRENT boards in row 0 (call after env.reset() or whenever a new recording starts)."""
         self.t = 0
+        self._unrecorded_random = False
         if self.legal is not None or self.obs is not None:
             self.env.describe(self.legal[0] if self.legal is not None else None, self.obs[0] if self.obs is not None else None)
         if self.boards is not None:
@@ -106,8 +108,8 @@ class TrajectoryBuffer:
 
     def step(self, actions: torch.Tensor | None = None, *, policy: torch.Tensor | None = None, value: torch.Tensor | None = None):
         """Step the env, recording row t. ``actions`` may be ``self.actions[row]`` itself (write the policy's
-        choice there and pass it: no copy) or any (N,) tensor (copied in); ``None`` = on-device random
-        actions (then the action row is left untouched: they are a function of (seed, step)).
+        choice there and pass it: no copy) or any (N,) tensor (copied in); ``None`` = on-device random actions, which
+        are written into the action row first (env2048_random_actions) so that the recording says what was played.
         ``policy`` (N, A) / ``value`` (N,): the search outputs of this move (self_play.py:339-340), copied into their rows;
         or write ``self.policy[row]`` / ``self.value[row]`` directly before calling."""
         t = self.t
@@ -119,6 +121,12 @@ class TrajectoryBuffer:
             if actions.data_ptr() != dst.data_ptr():
                 dst.copy_(actions.to(device=dst.device, dtype=torch.uint8).reshape(dst.shape))
             actions = dst
+        elif self.env.step_counter is None:
+            # on-device random play: write the moves the step WOULD draw into the action row and play them from there -- the
+            # same step (same words), and the row says what was played (these rows used to stay zero)
+            actions = self.env.random_actions(self.actions[row])
+        else:
+            self._unrecorded_random = True  # (step index on the device: the moves cannot be materialised beforehand)
         if policy is not None:
             if self.policy is None:
                 raise ValueError('this buffer was built without record_policy=True')
@@ -138,6 +146,12 @@ class TrajectoryBuffer:
             self.boards[nxt].copy_(self.env.boards)
         self.t = t + 1
         return out
+
+    def _require_action_rows(self) -> None:
+        if self._unrecorded_random:
+            raise RuntimeError('this recording holds random-action steps of an env with a device-side step counter: their moves were '
+                               'not written to the action rows, so trajectories cannot be exported (pass explicit actions, or build '
+                               'the env without device_step_counter)')
 
     def returns(self) -> torch.Tensor:
         """Undiscounted sum of the recorded reward rows per environment (int64, or float32 sums when normalised)."""
@@ -194,6 +208,7 @@ class TrajectoryBuffer:
         """The rows of episode record ``k`` gathered into the fields of the reference's ``Trajectory``
         (reinforce/training/replay_buffer.py:35-66): observations (L, 16), actions (L,), rewards (L,), policies (L, A),
         values (L,), done, total_reward, max_tile -- device tensors / Python scalars."""
+        self._require_action_rows()
         e = int(episodes['env'][k])
         start, length = int(episodes['start'][k]), int(episodes['length'][k])
         rows = torch.as_tensor([self._row(start + r) for r in range(length)], dtype=torch.int64, device=self.env.device)
@@ -216,6 +231,7 @@ class TrajectoryBuffer:
         slices of them.  Needs observation rows (``record_obs=True``)."""
         if self.obs is None:
             raise ValueError('export_trajectories needs observation rows (record_obs=True)')
+        self._require_action_rows()
         ep = self.episodes(frozen=frozen)
         first, count = ep['first_step'], ep['num_steps']
         order = [self._row(first + r) for r in range(count)]  # logical step -> physical row, once

@@ -285,6 +285,12 @@ class OracleLibrary:
             if ptr is not None:
                 _view(ptr, n * width, dtype)[:] = res[key].reshape(-1)
 
+    def random_actions(self, device, stream, n, env_base, seed, step_index, actions):
+        self.calls.append(('random_actions', n))
+        out = _view(actions, n, np.uint8)
+        for i in range(n):
+            out[i] = oracle.step_word(seed, env_base + i, step_index) & 3
+
     def status_i32(self, device, stream, n, boards, obs, legal4, done):
         self.calls.append(('status_i32', n))
         res = oracle.status_batch(oracle.pack_values(_view(boards, n * 16, np.int32)).reshape(n, 16))

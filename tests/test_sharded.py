@@ -1,0 +1,82 @@
+"""
+``ShardedEnv2048``: one process, G contiguous slices of one global batch, one worker thread + stream per shard, no collective
+(VERDICT r2 missing #3).  The sharded run must equal the unsharded batch byte for byte -- on the oracle-backed
+stand-in with three "devices" (host logic, CPU) and on the GPU with two shards on device 0.
+Partitioning rule restated from SURVEY 8(e): slice g = global indices [g * ceil(N / G), ...), Philox counters carry the GLOBAL index.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle_backend import OracleLibrary
+from simulate_2048_amd import BatchedEnv2048
+from simulate_2048_amd.sharded import ShardedEnv2048
+
+
+@pytest.fixture(params=['host-logic', pytest.param('hip', marks=pytest.mark.gpu)])
+def backend(request):
+    if request.param == 'hip':
+        return dict(devices=['cuda:0', 'cuda:0'], lib=None, one='cuda:0')
+    return dict(devices=['cpu', 'cpu', 'cpu'], lib=OracleLibrary(), one='cpu')
+
+
+def test_sharded_equals_unsharded(backend):
+    n, seed, base = 10_007, 13, 3  # odd size: the last shard is shorter; odd base: shard boundaries straddle Philox blocks
+    whole = BatchedEnv2048(n, seed, device=backend['one'], env_base=base, auto_reset=True, with_legal=True, lib=backend['lib'])
+    sharded = ShardedEnv2048(n, seed, devices=backend['devices'], env_base=base, auto_reset=True, with_legal=True, lib=backend['lib'])
+    try:
+        assert sharded.num_shards == len(backend['devices']) and sum(c for _, c in sharded.ranges) == n
+        assert [e.env_base for e in sharded.shards] == [base + lo for lo, _ in sharded.ranges]
+        whole.reset()
+        sharded.reset()
+        assert torch.equal(sharded.gather('boards'), whole.boards.cpu())
+        rng = np.random.default_rng(2)
+        for t in range(6):
+            if t % 2:
+                acts = torch.from_numpy(rng.integers(0, 4, size=n).astype(np.uint8))
+                whole.step(acts.to(whole.device))
+                sharded.step(sharded.split(acts))  # per-shard tensors on their devices
+            else:
+                whole.step(None)
+                sharded.step(None)
+            for name in ('boards', 'reward', 'done', 'legal'):
+                assert torch.equal(sharded.gather(name), getattr(whole, name).cpu()), (t, name)
+        assert sharded.step_index == whole.step_index == 6
+        # K dependent steps enqueued per shard by one C call from its own thread
+        sharded.step_sequence(5)
+        for _ in range(5):
+            whole.step(None)
+        assert torch.equal(sharded.gather('boards'), whole.boards.cpu()) and sharded.step_index == whole.step_index
+        staged = torch.from_numpy(rng.integers(0, 4, size=(4, n)).astype(np.uint8))
+        sharded.step_sequence(4, [staged[:, lo:lo + c].contiguous().to(d) for (lo, c), d in zip(sharded.ranges, sharded.devices)])
+        for k in range(4):
+            whole.step(staged[k].to(whole.device))
+        assert torch.equal(sharded.gather('boards'), whole.boards.cpu()) and torch.equal(sharded.gather('reward'), whole.reward.cpu())
+        # fused rollout + statistics reduced on the host
+        a = whole.rollout(40)
+        b = sharded.rollout(40)
+        assert torch.equal(torch.cat([x.cpu() for x in b['return_sum']]), a['return_sum'].cpu())
+        assert torch.equal(sharded.gather('boards'), whole.boards.cpu())
+        st_whole = BatchedEnv2048.episode_statistics(whole.rollout_episodes(300))
+        st_sharded = sharded.episode_statistics(sharded.rollout_episodes(300))
+        assert st_sharded == st_whole and st_whole['games'] > 0
+        ms = sharded.timed(lambda g: sharded.shards[g].step(None))
+        assert len(ms) == sharded.num_shards and all(m >= 0 for m in ms)
+        with pytest.raises(ValueError):
+            sharded.step([torch.zeros(3, dtype=torch.uint8)])
+    finally:
+        sharded.close()
+
+
+def test_worker_errors_reach_the_caller(backend):
+    sharded = ShardedEnv2048(64, 1, devices=backend['devices'], lib=backend['lib'])
+    try:
+        with pytest.raises(ValueError, match='actions'):
+            sharded.step([torch.zeros(5, dtype=torch.uint8, device=d) for d in sharded.devices])  # wrong per-shard length
+        sharded.reset()  # the workers are still alive afterwards
+        sharded.step(None)
+    finally:
+        sharded.close()
+    with pytest.raises(ValueError):
+        ShardedEnv2048(64, 1, devices=backend['devices'], lib=backend['lib'], device_step_counter=True)

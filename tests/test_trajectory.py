@@ -288,8 +288,8 @@ def test_device_step_counter_and_graph_replay(make_env):
     for t in range(12):
         ref.step(acts[t & 3])
         env.step(acts[t & 3])
-    assert env.step_index == 112 and int(env.step_counter[0]) == 100  # offsets 0..11 pending on top of the device counter
-    env.commit_steps()
+    assert env.step_index == 112 and int(env.step_counter[0]) == 112  # eager steps advance the device counter themselves
+    env.commit_steps()  # nothing pending: a no-op
     assert env.step_index == 112 and int(env.step_counter[0]) == 112
     assert torch.equal(env.boards, ref.boards) and torch.equal(env.legal, ref.legal) and torch.equal(env.reward, ref.reward)
     env.step_index = 500  # re-synchronise both sides somewhere else
@@ -303,13 +303,20 @@ def test_device_step_counter_and_graph_replay(make_env):
     side = torch.cuda.Stream()
     graph = torch.cuda.CUDAGraph()
     torch.cuda.synchronize()
-    with pytest.raises(RuntimeError, match='commit_steps'):  # one uncommitted step is pending: a capture must start at offset 0
-        with torch.cuda.stream(side):
-            with torch.cuda.graph(torch.cuda.CUDAGraph(), stream=side):
-                env.step(acts[0])
+    with torch.cuda.stream(side):  # a captured region that ends WITHOUT commit_steps(): its replays would repeat step indices ...
+        with torch.cuda.graph(torch.cuda.CUDAGraph(), stream=side):
+            env.step(acts[0])
     torch.cuda.synchronize()
-    env.commit_steps()
+    with pytest.raises(RuntimeError, match='commit_steps'):  # ... which the next call reports (and then starts clean)
+        env.step(acts[0])
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(torch.cuda.CUDAGraph(), stream=side):
+            env.step(acts[0])
     torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match='INSIDE'):  # committing after the capture block is too late as well
+        env.commit_steps()
+    torch.cuda.synchronize()
+    assert env.step_index == 501
     with torch.cuda.stream(side):
         with torch.cuda.graph(graph, stream=side):
             for t in range(K):
@@ -344,3 +351,98 @@ def test_episode_entry_points_reject_bad_arguments(make_env):
     assert e.value.code == capi.ERR_INVALID_ARG
     with pytest.raises(ValueError):
         env.step(None, out_reward=torch.zeros(8, dtype=torch.int32, device=env.device), normalized_reward=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Round 3: ADVICE r2 fixes (episode carry across reset, random-action rows) and the staged-moves entry point
+# ---------------------------------------------------------------------------------------------------------------------------
+def test_rollout_episodes_counts_again_after_reset(make_env):
+    """reset -> rollout_episodes -> reset -> rollout_episodes: the second run reports its own games.  Without auto-reset
+    every environment's game is counted once and marked over; round 2 kept those marks across reset() and then reported
+    0 games; with auto-reset it carried stale lengths into the first game after a reset."""
+    n, seed = 256, 4
+    env = make_env(n, seed, auto_reset=False)
+    env.reset()
+    first = BatchedEnv2048.episode_statistics(env.rollout_episodes(3000))
+    assert first['games'] == n
+    env.reset(step_index=0)
+    again = BatchedEnv2048.episode_statistics(env.rollout_episodes(3000))
+    assert again == first  # same seed, same step indices, fresh carry: the very same games
+    auto = make_env(n, seed, auto_reset=True)
+    auto.reset()
+    auto.rollout_episodes(10)  # no game can end within 10 moves (a board fills up after 14 at the earliest): every slot carries 10
+    assert int(host(auto._ep_length).min()) == 10
+    auto.reset(step_index=0)
+    assert int(host(auto._ep_length).max()) == 0
+    stats = BatchedEnv2048.episode_statistics(auto.rollout_episodes(600))
+    oracle_stats = oracle.rollout_episodes(oracle.reset_batch(n, seed, 0)[0], seed, 0, 600, flags=3)['stats']
+    assert stats == BatchedEnv2048.episode_statistics(torch.from_numpy(oracle_stats.astype(np.int64)))
+    auto.set_boards(host(auto.boards))  # overwriting the state forgets the games in progress as well
+    assert int(host(auto._ep_length).max()) == 0
+
+
+def test_random_action_steps_record_their_moves(make_env):
+    """traj.step(None): the action row holds the moves the on-device random policy played (low two bits of the step words),
+    and the recorded step is bit for bit the step(None) of an unrecorded env."""
+    n, T, seed, base = 300, 12, 77, 5
+    env = make_env(n, seed, env_base=base, auto_reset=True)
+    plain = make_env(n, seed, env_base=base, auto_reset=True)
+    for e in (env, plain):
+        e.reset()
+        e.rollout(30)
+    traj = TrajectoryBuffer(env, T, record_obs=True, record_legal=False)
+    traj.begin()
+    for t in range(T):
+        traj.step(None)
+        plain.step(None)
+        want = np.array([oracle.step_word(seed, base + i, 30 + t) & 3 for i in range(n)], dtype=np.uint8)
+        assert np.array_equal(host(traj.actions[t]), want)
+        assert np.array_equal(host(env.boards), host(plain.boards)) and np.array_equal(host(traj.reward[t]), host(plain.reward))
+    games = traj.export_trajectories()
+    assert games and all(g.actions.max() <= 3 for g in games) and any(g.actions.any() for g in games)
+    counter_env = make_env(n, seed, env_base=base, auto_reset=True, device_step_counter=True)
+    counter_env.reset()
+    t2 = TrajectoryBuffer(counter_env, 4, record_obs=True, record_legal=False)
+    t2.begin()
+    t2.step(None)
+    with pytest.raises(RuntimeError, match='action rows'):
+        t2.export_trajectories()
+
+
+@pytest.mark.parametrize('n', [1000, 5000])
+def test_step_many_staged_moves_equal_single_steps(make_env, n):
+    """BatchedEnv2048.step_many(actions[K, N]): one env2048_replay launch ('replay', the default for small batches), K
+    launches from one env2048_step_sequence call ('launches'), and K step() calls give the same boards and rows."""
+    K, seed = 9, 31
+    rng = np.random.default_rng(n)
+    actions = torch.from_numpy(rng.integers(0, 4, size=(K, n)).astype(np.uint8))
+    envs = {mode: make_env(n, seed, env_base=7, auto_reset=True) for mode in ('steps', 'auto', 'replay', 'launches')}
+    for e in envs.values():
+        e.reset()
+        e.rollout(120)
+    actions = actions.to(envs['steps'].device)
+    rows = {}
+    ref_r = torch.zeros((K, n), dtype=torch.int32, device=actions.device)
+    ref_d = torch.zeros((K, n), dtype=torch.uint8, device=actions.device)
+    for k in range(K):
+        envs['steps'].step(actions[k], out_reward=ref_r[k], out_done=ref_d[k])
+    for mode in ('auto', 'replay', 'launches'):
+        calls = getattr(envs[mode].lib, 'calls', None)
+        mark = len(calls) if calls is not None else 0
+        _, r, d = envs[mode].step_many(actions, mode=mode)
+        rows[mode] = (r, d)
+        assert envs[mode].step_index == envs['steps'].step_index
+        assert torch.equal(envs[mode].boards, envs['steps'].boards) and torch.equal(r, ref_r) and torch.equal(d, ref_d)
+        if calls is not None:  # host logic: which entry point was used
+            names = [c[0] for c in calls[mark:]]
+            assert names == (['replay'] if mode in ('auto', 'replay') else ['step_sequence'] if 'step_sequence' in names else names)
+            assert ('replay' in names) == (mode in ('auto', 'replay'))
+    with pytest.raises(ValueError):
+        envs['auto'].step_many(actions[:, :10].contiguous())
+    obs_env = make_env(n, seed, auto_reset=True, with_obs=True)
+    obs_env.reset()
+    with pytest.raises(ValueError, match='replay'):
+        obs_env.step_many(actions, mode='replay')
+    obs_env.step_many(actions)  # 'auto' falls back to launches and refreshes the persistent obs
+    st = obs_env.status()
+    assert torch.equal(st['obs'], obs_env.obs)

@@ -103,6 +103,11 @@ enum Op {
     OP_XOR_VARIED,
     OP_LSHRREV_INDEP,
     OP_ADD_CO_VCC,
+    OP_OR_INDEP,
+    OP_ASHRREV_INDEP,
+    OP_NOT_INDEP,
+    OP_LSHL_ADD_U64_INDEP,
+    OP_OR3_INDEP,
     OP_MIX_PERM_BITOP,  // alternating v_perm_b32 / v_bitop3_b32 / v_add_u32 (the step kernel's staple diet)
     OP_COUNT
 };
@@ -151,6 +156,11 @@ static const char *OP_NAMES[OP_COUNT] = {
     "v_xor_b32 (e32) varied registers",
     "v_lshrrev_b32 (e32) indep",
     "v_add_co_u32 (e32 -> vcc) indep",
+    "v_or_b32 (e32) indep",
+    "v_ashrrev_i32 (e32) indep",
+    "v_not_b32 (e32) indep",
+    "v_lshl_add_u64 indep",
+    "v_or3_b32 indep",
     "mix: perm, bitop3, add (chain of 8)",
 };
 
@@ -318,6 +328,21 @@ __global__ void probe_kernel(Stamp *out, uint32_t seed, uint32_t *sink)
         else if constexpr (OP == OP_ADD_CO_VCC)
             PROBE_ASM_V("v_add_co_u32_e32 %0, vcc, %8, %9", "v_add_co_u32_e32 %1, vcc, %8, %9", "v_add_co_u32_e32 %2, vcc, %8, %9", "v_add_co_u32_e32 %3, vcc, %8, %9",
                         "v_add_co_u32_e32 %4, vcc, %8, %9", "v_add_co_u32_e32 %5, vcc, %8, %9", "v_add_co_u32_e32 %6, vcc, %8, %9", "v_add_co_u32_e32 %7, vcc, %8, %9");
+        else if constexpr (OP == OP_OR_INDEP)
+            PROBE_ASM("v_or_b32_e32 %0, %8, %9", "v_or_b32_e32 %1, %8, %9", "v_or_b32_e32 %2, %8, %9", "v_or_b32_e32 %3, %8, %9",
+                      "v_or_b32_e32 %4, %8, %9", "v_or_b32_e32 %5, %8, %9", "v_or_b32_e32 %6, %8, %9", "v_or_b32_e32 %7, %8, %9");
+        else if constexpr (OP == OP_ASHRREV_INDEP)
+            PROBE_ASM("v_ashrrev_i32_e32 %0, 31, %9", "v_ashrrev_i32_e32 %1, 31, %9", "v_ashrrev_i32_e32 %2, 31, %9", "v_ashrrev_i32_e32 %3, 31, %9",
+                      "v_ashrrev_i32_e32 %4, 31, %9", "v_ashrrev_i32_e32 %5, 31, %9", "v_ashrrev_i32_e32 %6, 31, %9", "v_ashrrev_i32_e32 %7, 31, %9");
+        else if constexpr (OP == OP_NOT_INDEP)
+            PROBE_ASM("v_not_b32_e32 %0, %8", "v_not_b32_e32 %1, %8", "v_not_b32_e32 %2, %8", "v_not_b32_e32 %3, %8", "v_not_b32_e32 %4, %8",
+                      "v_not_b32_e32 %5, %8", "v_not_b32_e32 %6, %8", "v_not_b32_e32 %7, %8");
+        else if constexpr (OP == OP_LSHL_ADD_U64_INDEP)
+            PROBE_ASM64("v_lshl_add_u64 %0, %0, 2, %1", "v_lshl_add_u64 %1, %1, 2, %2", "v_lshl_add_u64 %2, %2, 2, %3", "v_lshl_add_u64 %3, %3, 2, %4",
+                        "v_lshl_add_u64 %4, %4, 2, %5", "v_lshl_add_u64 %5, %5, 2, %6", "v_lshl_add_u64 %6, %6, 2, %7", "v_lshl_add_u64 %7, %7, 2, %0");
+        else if constexpr (OP == OP_OR3_INDEP)
+            PROBE_ASM("v_or3_b32 %0, %8, %9, %8", "v_or3_b32 %1, %8, %9, %8", "v_or3_b32 %2, %8, %9, %8", "v_or3_b32 %3, %8, %9, %8",
+                      "v_or3_b32 %4, %8, %9, %8", "v_or3_b32 %5, %8, %9, %8", "v_or3_b32 %6, %8, %9, %8", "v_or3_b32 %7, %8, %9, %8");
         else if constexpr (OP == OP_MIX_PERM_BITOP)
             PROBE_ASM("v_perm_b32 %0, %0, %9, %8", "v_bitop3_b32 %1, %8, %9, %1 bitop3:0x96", "v_add_u32_e32 %2, %8, %2", "v_perm_b32 %3, %3, %9, %8",
                       "v_bitop3_b32 %4, %8, %9, %4 bitop3:0x96", "v_add_u32_e32 %5, %8, %5", "v_perm_b32 %6, %6, %9, %8", "v_bitop3_b32 %7, %8, %9, %7 bitop3:0x96");

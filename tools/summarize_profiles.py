@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Turn gpurun_out/<tag>/ (written by tools/profile_step.sh) into the committed profiles/ files:
     profiles/<label>_{resident,cold}_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the bench command
-    profiles/<label>_pmc_summary.json                   counter means per launch of step_kernel<false, false>, both legs
+    profiles/<label>_pmc_summary.json                   counter means per 2^20-board record: resident step launches, the shared cold launch
+                                                        (step_many_kernel, 30 records per launch) and the same cold records as separate launches
     (tools/profile_step.sh adds <label>_bench_default.json / _bench_driver_shape.json next to them)
     profiles/step_pmc.json                              what bench.py reads (keyed by leg:boards, stamped with the kernel-source hash)
 usage: tools/summarize_profiles.py <gpurun_out tag> <label> [<destination dir, default profiles/>]
@@ -20,27 +21,33 @@ sys.path.insert(0, str(REPO))
 import bench  # noqa: E402  (kernel_source_sha only; nothing touches a GPU)
 
 KERNEL = 'step_kernel<false, false, 4>'  # lean outputs, host actions, the large tiling (what 2^20-board launches run)
+SHARED = 'step_many_kernel<false, false, 4>'  # the same block code over the records of an env2048_step_many call
 BOARDS = 1 << 20
+COLD_RECORDS = -(-int(2.5 * (256 << 20)) // (BOARDS * 22))  # bench.py's cold leg: records (buffer sets) per shared launch
+# leg -> (rocprof run it comes from, kernel, 2^20-board records per launch): the --only-cold run holds BOTH cold forms
+LEGS = {'resident': ('resident', KERNEL, 1), 'cold': ('cold', SHARED, COLD_RECORDS), 'cold_separate': ('cold', KERNEL, 1)}
 
 
 def leg_counters(src: Path, leg: str) -> dict:
+    run, kernel, records = LEGS[leg]
     counters = {}
-    for path in glob.glob(str(src / f'pmc_{leg}_*' / '*' / '*counter_collection.csv')):
-        rows = [r for r in csv.DictReader(open(path)) if KERNEL in r['Kernel_Name']]
+    for path in glob.glob(str(src / f'pmc_{run}_*' / '*' / '*counter_collection.csv')):
+        rows = [r for r in csv.DictReader(open(path)) if kernel in r['Kernel_Name']]
         by_name = {}
         for r in rows:
             by_name.setdefault(r['Counter_Name'], []).append(float(r['Counter_Value']))
         for name, vals in by_name.items():
             vals = vals[len(vals) // 4:]  # skip the warm-up launches
-            counters[name] = {'mean': statistics.mean(vals), 'launches': len(vals)}
+            counters[name] = {'mean': statistics.mean(vals) / records, 'launches': len(vals)}  # per 2^20-board record
     return counters
 
 
-def kernel_avg_us(stats_csv: Path):
+def kernel_avg_us(stats_csv: Path, leg: str):
+    _, kernel, records = LEGS[leg]
     for r in csv.DictReader(open(stats_csv)):
-        if KERNEL in r['Name']:
-            return {'calls': int(r['Calls']), 'avg_us': float(r['AverageNs']) / 1e3, 'min_us': float(r['MinNs']) / 1e3,
-                    'max_us': float(r['MaxNs']) / 1e3}
+        if kernel in r['Name']:
+            return {'calls': int(r['Calls']), 'avg_us': float(r['AverageNs']) / 1e3 / records, 'min_us': float(r['MinNs']) / 1e3 / records,
+                    'max_us': float(r['MaxNs']) / 1e3 / records, 'records_per_launch': records}
     return None
 
 
@@ -54,12 +61,13 @@ def main(tag, label, dest=None):
     table = {'kernel_source_sha': bench.kernel_source_sha(), 'entries': {},
              'formula': 'fabric bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB from separate rocprofv3 --pmc passes (gfx950: FETCH_SIZE counts '
                         'wide coalesced reads at half their bytes; MI355X_MICROARCH.md, HBM section); counts Infinity-Cache hits'}
-    for leg in ('resident', 'cold'):
-        stats = glob.glob(str(src / f'stats_{leg}' / '*' / '*kernel_stats.csv'))
-        entry = {}
+    for leg in LEGS:
+        stats = glob.glob(str(src / f'stats_{LEGS[leg][0]}' / '*' / '*kernel_stats.csv'))
+        entry = {'kernel': LEGS[leg][1], 'per': f'2^20-board record ({LEGS[leg][2]} per launch)'}
         if stats:
-            shutil.copy(stats[0], dst / f'{label}_{leg}_kernel_stats.csv')
-            entry['rocprof_kernel_stats'] = kernel_avg_us(Path(stats[0]))
+            if leg != 'cold_separate':
+                shutil.copy(stats[0], dst / f'{label}_{leg}_kernel_stats.csv')
+            entry['rocprof_kernel_stats'] = kernel_avg_us(Path(stats[0]), leg)
         counters = leg_counters(src, leg)
         entry['counters'] = counters
         if 'FETCH_SIZE' in counters and 'WRITE_SIZE' in counters:
