@@ -448,6 +448,25 @@ ENV2048_EXPORT int env2048_expectimax_ply(int device, void *stream, uint64_t n, 
                                           uint8_t *legal);
 
 /*
+ * Depth-2 expectimax of the true environment -- the whole two-ply tree of every board in one launch, nothing of it in
+ * memory (the search a caller would build from latent_state + after_state + legal_actions, gameboard.py:105-171,
+ * gamemove.py:45-83):
+ *     Q2(s, a) = r(s, a) + sum over chance outcomes o of afterstate(s, a):  P(o) * max over legal a' of r(o, a')
+ *     V2(s)    = max over legal a of Q2(s, a) (0 for a terminal board);  best = the smallest maximising a (255: terminal)
+ * with P(o) = {0.9, 0.1}[tile] / num_empty (after_state) and r the merge score of latent_state; a successor with no legal
+ * move contributes 0.  Outputs (each may be NULL, at least one must not be):
+ *     terms        n x 4 x 4 int32, per (board, action): {r(s,a), S2, S4, num_empty} -- S2 / S4 = the sum over the empty
+ *                  cells of the afterstate of max_a' r(o, a') with a 2 / a 4 spawned there; all 0 for an illegal action.
+ *                  EXACT integers; Q2 = r + (0.9 * S2 + 0.1 * S4) / num_empty = (10 n r + 9 S2 + S4) / (10 n)
+ *     q            n x 4 float32: that fraction as ONE double division, rounded to float32 (-inf for an illegal action);
+ *                  the arg-max compares the fractions exactly (integers), so ties are decided by the action index alone
+ *     best_action  n bytes        value  n float32 (V2)
+ * [no single reference counterpart: composes gameboard.py:105-129 latent_state, :132-171 after_state, gamemove.py:45-83]
+ */
+ENV2048_EXPORT int env2048_expectimax_depth2(int device, void *stream, uint64_t n, const uint8_t *boards, int32_t *terms, float *q,
+                                             uint8_t *best_action, float *value);
+
+/*
  * Read-only board status; every output may be NULL.
  *     done / legal / obs as in env2048_step;  max_exp[i] = log2(max tile);  n_empty[i] = #zeros
  * [replaces: twentyfortyeight/core/gameboard.py:328-348 is_done;

@@ -687,6 +687,59 @@ ORACLE_API int oracle_expectimax_ply(uint64_t n, const uint8_t *boards, uint8_t 
 }
 
 /* [ref: twentyfortyeight/utils/binary.py:11-86 encode_flatten]  eye(width)[log2(cell)], empty -> index 0. */
+/* Depth-2 expectimax composed from the reference's building blocks:
+ *   Q2(s, a) = r(s, a) + sum_o P(o) * max_{legal a'} r(o, a')   with  latent_state [ref: gameboard.py:105-129],
+ *   after_state's outcomes and P(o) = TILE_SPAWN_PROBS[v] / num_empty [ref: gameboard.py:132-171], legality = the move changes
+ *   the board [ref: gamemove.py:45-83, 132-164]; a successor with no legal move contributes 0; V2 = max over legal a, best =
+ *   the smallest maximising action (255 for a terminal board).  terms = {r, S2, S4, num_empty} per (board, action) with
+ *   S2 / S4 the integer sums over the empty cells for a spawned 2 / 4; q = r + (0.9 S2 + 0.1 S4) / num_empty evaluated as the
+ *   exact fraction (10 n r + 9 S2 + S4) / (10 n): one division in double, arg-max by exact integer comparison. */
+ORACLE_API int oracle_expectimax_depth2(uint64_t n, const uint8_t *boards, int32_t *terms, double *q, uint8_t *best_action, double *value)
+{
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint8_t *b = boards + 16 * i;
+        int64_t best_x = 0, best_d = 1; /* Q2 = X / D with X = 10 n r + 9 S2 + S4, D = 10 n: compared exactly */
+        int best_a = 255;
+        for (int a = 0; a < 4; ++a) {
+            uint8_t after[16];
+            int64_t r = oracle_latent_state(b, a, after);
+            int changed = memcmp(after, b, 16) != 0;
+            int32_t *t = terms + (4 * i + (uint64_t)a) * 4;
+            t[0] = t[1] = t[2] = t[3] = 0;
+            q[4 * i + a] = -INFINITY;
+            if (!changed) continue;
+            int n_empty = oracle_count_empty(after);
+            int64_t s[2] = {0, 0};
+            for (int k = 0; k < n_empty; ++k)
+                for (int v = 0; v < 2; ++v) {
+                    uint8_t o[16], tmp[16];
+                    memcpy(o, after, 16);
+                    oracle_fill_cell_kv(o, k, (uint8_t)(v + 1));
+                    int64_t best = 0;
+                    for (int a2 = 0; a2 < 4; ++a2) {
+                        int64_t r2 = oracle_latent_state(o, a2, tmp);
+                        if (memcmp(tmp, o, 16) != 0 && r2 > best) best = r2;
+                    }
+                    s[v] += best;
+                }
+            t[0] = (int32_t)r;
+            t[1] = (int32_t)s[0];
+            t[2] = (int32_t)s[1];
+            t[3] = n_empty;
+            const int64_t d = 10 * (int64_t)n_empty, x = d * r + 9 * s[0] + s[1];
+            q[4 * i + a] = (double)x / (double)d; /* = r + (0.9 S2 + 0.1 S4) / n, one correctly rounded division */
+            if (best_a == 255 || x * best_d > best_x * d) { /* exact comparison of the fractions; a tie keeps the smaller action */
+                best_x = x;
+                best_d = d;
+                best_a = a;
+            }
+        }
+        best_action[i] = (uint8_t)best_a;
+        value[i] = (double)best_x / (double)best_d;
+    }
+    return 0;
+}
+
 ORACLE_API int oracle_encode_onehot(uint64_t n, const uint8_t *boards, uint32_t width, uint8_t *out)
 {
     memset(out, 0, (size_t)n * 16 * width);

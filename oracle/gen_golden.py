@@ -21,6 +21,7 @@ Fixture sets:
   resets.npz        G5  reset boards under the Philox contract (two sequential injected spawns)
   transforms.npz        encode_flatten(...,31) one-hot observations and normalize_reward values
   chance_outcomes.npz   after_state(board): every (empty cell, value) outcome in the reference's order + float64 probabilities
+  expectimax_d2.npz     depth-2 expectimax (Q2, exact integer terms, best action) composed from latent_state / after_state / can_move
   random_play_stats.npz per-game length / total reward / max tile of 3000 uniformly-random games played by the REFERENCE engine
                         with its own NumPy RNG: the distribution the build's Philox-driven play must reproduce
 """
@@ -323,6 +324,50 @@ def gen_chance_outcomes():
     return n, int(count.max()), int((count == 1).sum())
 
 
+def gen_expectimax_d2():
+    """Depth-2 expectimax composed LITERALLY from the reference's functions on the chance_outcomes boards:
+    Q2(s, a) = latent_state reward + sum over after_state(afterstate) outcomes of prob * max over legal a' of the latent_state
+    reward of the outcome (legal = can_move of the rotated board, as next_state decides it, gameboard.py:316-317); float64,
+    summed in after_state's order.  Pins oracle_expectimax_depth2 / env2048_expectimax_depth2 (exact integer terms; q to 1e-12)."""
+    boards = np.load(OUT / 'chance_outcomes.npz')['boards']
+    n = boards.shape[0]
+    q = np.full((n, 4), -np.inf, dtype=np.float64)
+    terms = np.zeros((n, 4, 4), dtype=np.int32)
+    best = np.full(n, 255, dtype=np.uint8)
+    value = np.zeros(n, dtype=np.float64)
+
+    def legal(state, a):
+        return bool(ref_move.can_move(np.rot90(state, k=a)))
+
+    def best_reward(state):
+        rewards = [float(ref_board.latent_state(state, a2)[1]) for a2 in range(4) if legal(state, a2)]
+        return max(rewards) if rewards else 0.0
+
+    for i in range(n):
+        state = to_values(boards[i]).reshape(4, 4)
+        for a in range(4):
+            if not legal(state, a):
+                continue
+            after, r = ref_board.latent_state(state, a)
+            outcomes = ref_board.after_state(after)
+            expect, s2, s4 = 0.0, 0, 0
+            for o, pr in outcomes:
+                v = best_reward(o)
+                expect += pr * v
+                spawned = int((o != after).sum()) and int(o[o != after][0])
+                if spawned == 2:
+                    s2 += int(v)
+                else:
+                    s4 += int(v)
+            q[i, a] = float(r) + expect
+            terms[i, a] = (int(r), s2, s4, int((after == 0).sum()))
+        if np.isfinite(q[i]).any():
+            best[i] = int(np.argmax(q[i]))  # first maximum
+            value[i] = q[i, best[i]]
+    np.savez_compressed(OUT / 'expectimax_d2.npz', boards=boards, q=q, terms=terms, best=best, value=value)
+    return n, int((best == 255).sum()), float(np.nanmax(np.where(np.isfinite(q), q, np.nan)))
+
+
 def gen_random_play_stats(games: int = 3000):
     """Whole games of the reference engine under uniformly random actions with ITS OWN spawn RNG (seeded per step):
     the bitstream cannot be reproduced, the DISTRIBUTION of game length / score / max tile can -- it pins
@@ -361,6 +406,7 @@ def main():
     print('resets', gen_resets())
     print('transforms', gen_transforms(rng))
     print('chance_outcomes', gen_chance_outcomes())
+    print('expectimax_d2', gen_expectimax_d2())
     print('random_play_stats', gen_random_play_stats())
     with open(OUT / 'SHA256SUMS', 'w') as fh:
         for p in sorted(OUT.glob('*.npz')):

@@ -95,6 +95,7 @@ PROTOTYPES = {
     'env2048_random_actions': (_c_int, [_c_int, _ptr, _u64, _u64, _u64, _u64, _ptr]),
     'env2048_chance_outcomes': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr]),
     'env2048_expectimax_ply': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    'env2048_expectimax_depth2': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr, _ptr]),
     'env2048_status': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
     'env2048_encode_onehot': (_c_int, [_c_int, _ptr, _u64, _ptr, _u32, _ptr]),
     'env2048_pack_i32': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr]),
@@ -220,6 +221,9 @@ class Library:
 
     def random_actions(self, device, stream, n, env_base, seed, step_index, actions) -> None:
         self._check(self._dll.env2048_random_actions(device, stream, n, env_base, seed, step_index, actions))
+
+    def expectimax_depth2(self, device, stream, n, boards, terms, q, best_action, value) -> None:
+        self._check(self._dll.env2048_expectimax_depth2(device, stream, n, boards, terms, q, best_action, value))
 
     def status_i32(self, device, stream, n, boards, obs, legal4, done) -> None:
         self._check(self._dll.env2048_status_i32(device, stream, n, boards, obs, legal4, done))

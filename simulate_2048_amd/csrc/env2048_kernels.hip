@@ -1262,6 +1262,172 @@ __global__ __launch_bounds__(PLY_BLOCK) void expectimax_ply_kernel(uint64_t n, c
     }
 }
 
+// Depth-2 expectimax of the TRUE environment, the whole search tree of a board in one launch, nothing of it in HBM
+// (VERDICT r2 "next" #8; the frontier of expectimax_ply_kernel kept on chip):
+//     Q2(s, a) = r(s, a) + sum over chance outcomes o of afterstate(s, a):  P(o) * max over legal a' of r(o, a')        (legal a)
+//     V2(s)    = max over legal a of Q2(s, a)   (0 for a terminal board);  best(s) = the smallest such a
+// with r and the afterstates of latent_state [ref: twentyfortyeight/core/gameboard.py:105-129], the outcomes and
+// P(o) = TILE_SPAWN_PROBS[value] / num_empty of after_state [ref: gameboard.py:132-171] and legality as in
+// legal_actions_mask [ref: twentyfortyeight/core/gamemove.py:45-83] (== "the slide changes the board").  A successor without
+// a legal move (game over) contributes 0.  Up to 4 x 16 x 2 = 128 successors per board, 4 slides each: 512 slide/merge
+// evaluations per board, all in registers.
+// Work split as in the ply kernel: a wave owns 64 boards; phase 1, one board per lane -> its four afterstates into a
+// wave-private LDS strip; phase 2, 128 iterations in which lane l evaluates successor (action 2h + l/32, slot l%32) of
+// board it/2 and the 32 lanes of a half-wave add up their best rewards separately for the tile-2 and the tile-4 outcomes
+// (four xor-shuffles: the sums are INTEGERS, so the result does not depend on the order); phase 3, one board per lane
+// again: Q2 = r + (0.9 * S2 + 0.1 * S4) / n_empty as an exact fraction, arg-max, outputs.  Pure VALU work: 16 B in, 89 B out per board.
+struct D2After {  // one (board, action) entry of the LDS strip: 24 bytes (6 KiB per wave: six workgroups per CU)
+    uint32_t r0, r1, r2, r3;  // the afterstate; once its successors have been evaluated, r0 / r1 are reused for the sums S2 / S4
+    uint32_t empties;         // cell mask of the afterstate's empty cells; 0 = action illegal
+    int32_t reward;
+};
+
+// best reward over the legal moves of one board (0 if it has none): one byte transpose shared by the four slides
+__device__ __forceinline__ int32_t best_move_reward(const Board &bd)
+{
+    uint32_t c0, c1, c2, c3, changed;
+    transpose4x4(bd.r0, bd.r1, bd.r2, bd.r3, c0, c1, c2, c3);
+    int32_t best = 0;
+    {
+        uint32_t a = c0, b = c1, c = c2, d = c3;
+        const int32_t r = (int32_t)slide_merge_planes(a, b, c, d, changed);  // left (a move that changes nothing merges nothing: r = 0)
+        best = max(best, r);
+    }
+    {
+        uint32_t a = bd.r0, b = bd.r1, c = bd.r2, d = bd.r3;
+        best = max(best, (int32_t)slide_merge_planes(a, b, c, d, changed));  // up
+    }
+    {
+        uint32_t a = c3, b = c2, c = c1, d = c0;
+        best = max(best, (int32_t)slide_merge_planes(a, b, c, d, changed));  // right
+    }
+    {
+        uint32_t a = bd.r3, b = bd.r2, c = bd.r1, d = bd.r0;
+        best = max(best, (int32_t)slide_merge_planes(a, b, c, d, changed));  // down
+    }
+    return best;  // illegal moves score 0 and never win against a legal one with a merge; all-zero = no merge anywhere: 0 either way
+}
+
+constexpr int D2_BLOCK = 256;
+
+__global__ __launch_bounds__(D2_BLOCK) void expectimax_depth2_kernel(uint64_t n, const uint8_t *boards, int32_t *terms, float *q,
+                                                                      uint8_t *best_action, float *value)
+{
+    __shared__ __attribute__((aligned(16))) D2After strip_lds[D2_BLOCK / 64][64 * 4];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t board0 = ((uint64_t)blockIdx.x * (D2_BLOCK / 64) + wave) * 64u;
+    if (board0 >= n) return;  // wave-uniform
+    D2After *strip = strip_lds[wave];
+
+    // phase 1: one board per lane -> four afterstates
+    const uint64_t mine = board0 + lane;
+    if (mine < n) {
+        const Board bd = load_board(boards, mine);
+        uint32_t c0, c1, c2, c3;
+        transpose4x4(bd.r0, bd.r1, bd.r2, bd.r3, c0, c1, c2, c3);
+        Board after[4];
+        int32_t rewards[4];
+        uint32_t legal = 0u, changed;
+        {
+            uint32_t a = c0, b = c1, c = c2, d = c3;
+            rewards[0] = (int32_t)slide_merge_planes(a, b, c, d, changed);
+            transpose4x4(a, b, c, d, after[0].r0, after[0].r1, after[0].r2, after[0].r3);
+            legal |= changed != 0u ? 1u : 0u;
+        }
+        {
+            uint32_t a = bd.r0, b = bd.r1, c = bd.r2, d = bd.r3;
+            rewards[1] = (int32_t)slide_merge_planes(a, b, c, d, changed);
+            after[1] = Board{a, b, c, d};
+            legal |= changed != 0u ? 2u : 0u;
+        }
+        {
+            uint32_t a = c3, b = c2, c = c1, d = c0;
+            rewards[2] = (int32_t)slide_merge_planes(a, b, c, d, changed);
+            transpose4x4(d, c, b, a, after[2].r0, after[2].r1, after[2].r2, after[2].r3);
+            legal |= changed != 0u ? 4u : 0u;
+        }
+        {
+            uint32_t a = bd.r3, b = bd.r2, c = bd.r1, d = bd.r0;
+            rewards[3] = (int32_t)slide_merge_planes(a, b, c, d, changed);
+            after[3] = Board{d, c, b, a};
+            legal |= changed != 0u ? 8u : 0u;
+        }
+#pragma unroll
+        for (uint32_t act = 0; act < 4u; ++act) {
+            const bool is_legal = ((legal >> act) & 1u) != 0u;
+            const uint32_t empt = is_legal ? empty_mask(after[act]) : 0u;  // a legal move always leaves an empty cell
+            strip[4u * lane + act] = D2After{after[act].r0, after[act].r1, after[act].r2, after[act].r3, empt, is_legal ? rewards[act] : 0};
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the strip is wave-private: LDS ops of a wave are ordered
+    __builtin_amdgcn_wave_barrier();
+
+    // phase 2: 128 successor slots per board, 64 per iteration
+    const uint32_t boards_here = (uint32_t)min((uint64_t)64, n - board0);
+    const uint32_t slot = lane & 31u, k = slot >> 1;
+    const bool four = (slot & 1u) != 0u;
+    for (uint32_t it = 0; it < 2u * boards_here; ++it) {
+        const uint32_t entry = 4u * (it >> 1) + 2u * (it & 1u) + (lane >> 5);
+        const D2After a = strip[entry];
+        int32_t best = 0;
+        if (k < ENV2048_POPC(a.empties)) {
+            Board bd{a.r0, a.r1, a.r2, a.r3};
+            place_tile(bd, kth_empty(a.empties, k), four);
+            best = best_move_reward(bd);
+        }
+        // sum over the 16 lanes of this half-wave that share the tile value (same parity): offsets 2, 4, 8, 16
+        best += __shfl_xor(best, 2);
+        best += __shfl_xor(best, 4);
+        best += __shfl_xor(best, 8);
+        best += __shfl_xor(best, 16);
+        // slot 0 holds S2 (tile-2 outcomes), slot 1 S4: parked in the entry's r0 / r1 -- every lane of the half-wave has read the
+        // entry above and a wave's LDS operations execute in order, and no later iteration reads this entry's board again
+        if (slot == 0u) strip[entry].r0 = (uint32_t)best;
+        if (slot == 1u) strip[entry].r1 = (uint32_t)best;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // phase 3: one board per lane again
+    if (mine >= n) return;
+    // Q2 = r + (0.9 S2 + 0.1 S4) / n = X / D with the INTEGERS X = 10 n r + 9 S2 + S4 and D = 10 n: the arg-max compares the
+    // fractions exactly (cross-multiplied in 64 bits; a tie keeps the smaller action) and the float outputs are ONE correctly
+    // rounded double division each -- so device and oracle agree bit for bit, independent of fma contraction or summation order
+    int64_t best_x = 0, best_d = 1;
+    uint32_t best_a = 255u;
+    float q4[4];
+    int4 t[4];
+#pragma unroll
+    for (uint32_t act = 0; act < 4u; ++act) {
+        const D2After a = strip[4u * lane + act];
+        const int32_t s2 = (int32_t)a.r0, s4 = (int32_t)a.r1, n_empty = (int32_t)ENV2048_POPC(a.empties);
+        t[act] = make_int4(a.reward, s2, s4, n_empty);
+        if (a.empties != 0u) {
+            const int64_t d = 10 * (int64_t)n_empty, x = d * (int64_t)a.reward + 9 * (int64_t)s2 + (int64_t)s4;
+            q4[act] = (float)((double)x / (double)d);
+            if (best_a == 255u || x * best_d > best_x * d) {
+                best_x = x;
+                best_d = d;
+                best_a = act;
+            }
+        } else {
+            q4[act] = -__builtin_inff();
+        }
+    }
+    const double best_q = (double)best_x / (double)best_d;
+    if (terms) {
+        int4 *out = reinterpret_cast<int4 *>(terms) + 4 * mine;
+        out[0] = t[0];
+        out[1] = t[1];
+        out[2] = t[2];
+        out[3] = t[3];
+    }
+    if (q) reinterpret_cast<float4 *>(q)[mine] = make_float4(q4[0], q4[1], q4[2], q4[3]);
+    if (best_action) best_action[mine] = (uint8_t)best_a;
+    if (value) value[mine] = (float)best_q;
+}
+
 __global__ __launch_bounds__(BLOCK) void spawn_kernel(uint64_t n, uint8_t *boards, const uint8_t *spawn_k,
                                                       const uint8_t *spawn_e, uint8_t *placed)
 {
@@ -2354,6 +2520,22 @@ int env2048_expectimax_ply(int device, void *stream, uint64_t n, const uint8_t *
     hipLaunchKernelGGL(expectimax_ply_kernel, dim3((unsigned)((n + PLY_BLOCK - 1) / PLY_BLOCK)), dim3(PLY_BLOCK), 0, (hipStream_t)stream, n,
                        boards, succ_boards, succ_prob, succ_status, succ_count, after_reward, legal);
     return launched("env2048_expectimax_ply launch");
+}
+
+int env2048_expectimax_depth2(int device, void *stream, uint64_t n, const uint8_t *boards, int32_t *terms, float *q, uint8_t *best_action,
+                              float *value)
+{
+    if (n == 0) return ENV2048_OK;
+    if (!boards) return fail(ENV2048_ERR_INVALID_ARG, "env2048_expectimax_depth2: boards is NULL");
+    if (!terms && !q && !best_action && !value) return fail(ENV2048_ERR_INVALID_ARG, "env2048_expectimax_depth2: no output requested");
+    if (misaligned(boards, 16) || misaligned(terms, 16) || misaligned(q, 16) || misaligned(value, 4))
+        return fail(ENV2048_ERR_ALIGNMENT, "env2048_expectimax_depth2: boards / terms / q must be 16-byte, value 4-byte aligned");
+    if (int rc = check_count(n)) return rc;
+    DeviceScope scope(device);
+    if (scope.rc) return scope.rc;
+    hipLaunchKernelGGL(expectimax_depth2_kernel, dim3((unsigned)((n + D2_BLOCK - 1) / D2_BLOCK)), dim3(D2_BLOCK), 0, (hipStream_t)stream, n,
+                       boards, terms, q, best_action, value);
+    return launched("env2048_expectimax_depth2 launch");
 }
 
 int env2048_encode_onehot(int device, void *stream, uint64_t n, const uint8_t *boards, uint32_t width, uint8_t *out)

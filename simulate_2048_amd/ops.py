@@ -142,6 +142,24 @@ def expectimax_ply(boards: torch.Tensor, *, want_status: bool = True, rt=None) -
     return out
 
 
+def expectimax_depth2(boards: torch.Tensor, *, want_terms: bool = False, rt=None) -> dict:
+    """Depth-2 expectimax of the true environment for every board in ONE launch (env2048_expectimax_depth2): Q2(s, a) = r(s, a) +
+    E over the spawn outcomes of the afterstate of the best immediate reward (the two-ply tree is evaluated on chip).
+    -> dict(q (n,4) f32, -inf for illegal actions; best (n,) u8, 255 = terminal; value (n,) f32[, terms (n,4,4) i32 = {r, S2, S4, num_empty}])."""
+    rt = rt or runtime.current()
+    n = boards.shape[0]
+    out = {
+        'q': torch.empty((n, 4), dtype=torch.float32, device=rt.device),
+        'best': torch.empty((n,), dtype=torch.uint8, device=rt.device),
+        'value': torch.empty((n,), dtype=torch.float32, device=rt.device),
+    }
+    if want_terms:
+        out['terms'] = torch.empty((n, 4, 4), dtype=torch.int32, device=rt.device)
+    dev, stream = rt.handles()
+    rt.lib.expectimax_depth2(dev, stream, n, _p(boards), _p(out.get('terms')), _p(out['q']), _p(out['best']), _p(out['value']))
+    return out
+
+
 def onehot(boards: torch.Tensor, width: int = 31, rt=None) -> torch.Tensor:
     rt = rt or runtime.current()
     n = boards.shape[0]

@@ -291,6 +291,18 @@ class OracleLibrary:
         for i in range(n):
             out[i] = oracle.step_word(seed, env_base + i, step_index) & 3
 
+    def expectimax_depth2(self, device, stream, n, boards, terms, q, best_action, value):
+        self.calls.append(('expectimax_depth2', n))
+        res = oracle.expectimax_depth2(_view(boards, n * 16, np.uint8).reshape(n, 16).copy())
+        if terms is not None:
+            _view(terms, n * 16, np.int32)[:] = res['terms'].reshape(-1)
+        if q is not None:
+            _view(q, n * 4, np.float32)[:] = res['q'].astype(np.float32).reshape(-1)
+        if best_action is not None:
+            _view(best_action, n, np.uint8)[:] = res['best']
+        if value is not None:
+            _view(value, n, np.float32)[:] = res['value'].astype(np.float32)
+
     def status_i32(self, device, stream, n, boards, obs, legal4, done):
         self.calls.append(('status_i32', n))
         res = oracle.status_batch(oracle.pack_values(_view(boards, n * 16, np.int32)).reshape(n, 16))
