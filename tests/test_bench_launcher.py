@@ -96,7 +96,7 @@ def test_profile_table_is_keyed_by_kernel_source():
         assert set(table) >= {'kernel_source_sha', 'entries'}
         for key, entry in table['entries'].items():
             leg, boards = key.split(':')
-            assert leg in ('resident', 'cold') and int(boards) > 0
+            assert leg in ('resident', 'cold', 'cold_separate') and int(boards) > 0
             assert entry['fabric_bytes_per_launch'] > 0 and (REPO / entry['source']).exists()
         prof = bench.load_step_profile(1 << 20, 'resident')
         assert prof is None or prof['stale'] == (table['kernel_source_sha'] != sha)
