@@ -83,6 +83,8 @@ def parse_args(argv=None):
                     'thread + stream per device) instead of one rank per GPU; no torch.distributed at all')
     ap.add_argument('--shards-on-device-0', action='store_true', help='with --single-process: put all --gpus shards on device 0 (REHEARSAL of '
                     'the fan-out on a box with fewer GPUs; not a scaling measurement)')
+    ap.add_argument('--single-chain', action='store_true', help='A/B aid: ENV2048_FLAG_SINGLE_CHAIN on the timed env2048_step_sequence calls '
+                    '(never split the batch into two half-batch chains)')
     ap.add_argument('--dist-backend', default='nccl', help="'nccl' (= RCCL, one GPU per rank); 'gloo' = REHEARSAL of the "
                     'multi-rank logic on a box with fewer GPUs than ranks (all ranks then share device 0; numbers are not a '
                     'scaling measurement and the JSON says so)')
@@ -283,13 +285,20 @@ def build_roofline(args, lib, n: int, flags: int, launch_s: float, obs_bytes: in
     working_set = n * (16 + 8 + 4 + 1) + (n * (1 + 16 * obs_bytes) if args.extras else 0)  # boards + 8-array action pool + outputs
     resident = working_set <= INFINITY_CACHE_BYTES
     prof = None if args.extras else load_step_profile(n, 'resident')
-    plan = lib.step_plan(n, flags)  # the library's own launch policy (env2048_step_plan), not a copy of its size rule
+    # the library's own launch policy (env2048_step_sequence_plan), not a copy of its size rules: the timed region is one
+    # env2048_step_sequence call, which may run the batch as two half-batch chains on two streams
+    plan = lib.step_sequence_plan(n, args.steps, flags)
     tiling = plan['boards_per_lane']
     kernel = f'step_kernel<false, false, {tiling}>' if not args.extras else f'step_kernel<true, false, {tiling}>'
     roofline = {
         'kernel': kernel,
         'launch_plan': plan,
+        'launches_per_step': plan['chains'],
+        'boards_per_kernel_launch': n if plan['chains'] == 1 else n - (n // 2) // 2048 * 2048,
         'avg_launch_us': launch_s * 1e6,
+        'avg_launch_us_means': 'HIP-event time of the K-step region / K = the period of one step over the whole batch' +
+                               ('' if plan['chains'] == 1 else '; the step is two half-batch launches on two streams that overlap each '
+                                'other, each lasting about one period (the rocprofv3 average of the half-batch kernel)'),
         'algorithmic_bytes_per_launch': bytes_per_launch,
         'traffic': None if prof is None else prof.get('fabric_bytes_per_launch'),
         'traffic_kind': 'fabric bytes per launch (2*FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes): L2 <-> Infinity '
@@ -298,7 +307,7 @@ def build_roofline(args, lib, n: int, flags: int, launch_s: float, obs_bytes: in
     }
     if resident and prof is not None and prof.get('valu_insts_per_launch'):
         ginstr = prof['valu_insts_per_launch'] / launch_s / 1e9
-        waves_per_simd = max(1, min(8, round(n / (64 * tiling) / 1024)))
+        waves_per_simd = max(1, min(8, round(n / (64 * tiling) / 1024)))  # both half-batch chains are resident together
         peak, peak_source = valu_ceiling(4 if waves_per_simd >= 4 else 2 if waves_per_simd >= 2 else 1)
         per_lane = prof['valu_insts_per_launch'] * 64 / n  # wave64 instructions x 64 lanes / boards
         roofline.update({
@@ -425,7 +434,7 @@ def run_rank(args) -> None:
         stream = torch.cuda.current_stream(device)
         h = stream.cuda_stream
         p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
-        flags = env.flags
+        flags = env.flags | (capi.FLAG_SINGLE_CHAIN if args.single_chain else 0)
 
         tables = {}
 
@@ -525,7 +534,8 @@ def run_rank(args) -> None:
                     'workload': workload_text(n),
                     'boards_per_gpu': n,
                     'global_boards': n * world,
-                    'launch_mode': 'env2048_step_sequence: K launches enqueued from C by one call',
+                    'launch_mode': 'env2048_step_sequence: the K steps enqueued from C by one call (two half-batch chains of K launches each when the '
+                               'library plans it so: roofline.launch_plan)',
                     'sharding': 'contiguous env-index slices, one process per GPU, no collective on the hot path',
                     'outputs': 'board,reward,done' + (f',legal,obs({args.obs_dtype})' if args.extras else ''),
                 },

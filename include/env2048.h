@@ -83,6 +83,9 @@ extern "C" {
  * replay / rollout_episodes kernels have the same two tilings (switch at 2^18 environments) and accept the same hints. */
 #define ENV2048_FLAG_TILE_SMALL 128u
 #define ENV2048_FLAG_TILE_LARGE 256u
+/* env2048_step_sequence only, a tuning hint that changes no result: never split the batch into two half-batch chains
+ * (see env2048_step_sequence). */
+#define ENV2048_FLAG_SINGLE_CHAIN 512u
 /* env2048_step* only: `reward` is an n-float32 array receiving the LOG-NORMALISED reward log2(score) / 16 (0 for a
  * score of 0) -- normalize_reward of the reference (twentyfortyeight/utils/normalize.py:6-33, the `normalize=True`
  * constructor flag, twentyfortyeight/envs/twentyfortyeight.py:80-81) for a whole batch; within 1 ulp (float32) of the
@@ -189,6 +192,11 @@ ENV2048_EXPORT int env2048_step_many_plan(uint64_t count, const env2048_step_arg
 /* *counter += delta on `stream` (one thread): the node that ends a captured graph of step_counter launches. */
 ENV2048_EXPORT int env2048_advance_counter(int device, void *stream, uint64_t *counter, uint64_t delta);
 
+/* How env2048_step_sequence would run: chains (1 or 2 half-batch chains), and tiling / store policy of its launches (each may be
+ * NULL).  No device is touched. */
+ENV2048_EXPORT int env2048_step_sequence_plan(uint64_t n, uint32_t count, uint32_t flags, int32_t *chains, int32_t *boards_per_lane,
+                                              int32_t *write_through);
+
 /*
  * `count` consecutive transitions of ONE batch: launch t (t = 0 .. count-1) is
  *     env2048_step(device, stream, n, env_base, boards, actions[t], reward + t*row_stride, done + t*row_stride,
@@ -196,6 +204,17 @@ ENV2048_EXPORT int env2048_advance_counter(int device, void *stream, uint64_t *c
  * `actions` is a HOST array of `count` device pointers (NULL with RANDOM_ACTIONS).  row_stride = 0 makes every
  * step overwrite the same output arrays; row_stride >= n records step t in row t of [count, row_stride] arrays
  * (the per-step rows of reinforce/training/self_play.py:359-365 without a host round trip).
+ *
+ * Two chains.  The environments of a batch do not depend on each other, so for 2^20 <= n <= 2^23 and count >= 32 (and unless
+ * `stream` is being captured or ENV2048_FLAG_SINGLE_CHAIN is given) the batch is cut in two halves that are stepped as two
+ * independent chains of `count` launches each: the first on `stream`, enqueued by the calling thread, the second on an internal
+ * stream of the device, enqueued concurrently by a helper thread of the library (one per device, created on first use).  The
+ * second chain starts behind everything already on `stream` and `stream` waits for it before anything enqueued after the call,
+ * so the call keeps the semantics of `count` launches on `stream`; the halves slide against each other on the GPU (one half's
+ * load phase and store drain under the other's arithmetic), which a single chain of single-generation launches cannot do:
+ * 6.5-6.7 us instead of 7.7-7.9 us per 2^20-board step in long sequences (count = 50: -10 %, 20: break-even; smaller batches and
+ * batches beyond the Infinity Cache lose, hence the bounds).  Results are bit-identical.  env2048_step_sequence_plan reports
+ * the decision.
  * [replaces: the env.step calls of the move loop, reinforce/training/self_play.py:314-368]
  */
 ENV2048_EXPORT int env2048_step_sequence(int device, void *stream, uint64_t n, uint64_t env_base, uint8_t *boards,

@@ -36,7 +36,7 @@ def build_library(force: bool = False, verbose: bool = False, extra_flags: list[
     LIB.parent.mkdir(exist_ok=True)
     tmp = LIB.with_suffix('.so.tmp%d' % os.getpid())
     cmd = [hipcc(), f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-shared', '-fPIC', '-fvisibility=hidden',
-           '-DENV2048_BUILDING', f'-I{REPO / "include"}', f'-I{PKG / "csrc"}', '-Wall', '-Wno-unused-function',
+           '-pthread', '-DENV2048_BUILDING', f'-I{REPO / "include"}', f'-I{PKG / "csrc"}', '-Wall', '-Wno-unused-function',
            # leading kernel arguments arrive in SGPRs with the wave instead of through an s_load (gfx950 kernarg
            # preload; the code object keeps the s_load prologue as the fallback for firmware without it)
            '-mllvm', '-amdgpu-kernarg-preload-count=16']

@@ -30,6 +30,7 @@ FLAG_STORES_WRITE_BACK = 32
 FLAG_REWARD_LOG2_F32 = 64
 FLAG_TILE_SMALL = 128
 FLAG_TILE_LARGE = 256
+FLAG_SINGLE_CHAIN = 512
 
 LIB_PATH = Path(__file__).resolve().parent / 'lib' / 'libenv2048.so'
 
@@ -68,6 +69,8 @@ PROTOTYPES = {
     'env2048_step': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _u64, _u64, _u32]),
     'env2048_step_many': (_c_int, [_c_int, _ptr, _u64, ctypes.POINTER(StepArgs)]),
     'env2048_step_plan': (_c_int, [_u64, _u32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
+    'env2048_step_sequence_plan': (_c_int, [_u64, _u32, _u32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32),
+                                            ctypes.POINTER(ctypes.c_int32)]),
     'env2048_step_many_plan': (_c_int, [_u64, ctypes.POINTER(StepArgs), ctypes.POINTER(_u32), ctypes.POINTER(ctypes.c_int32),
                                         ctypes.POINTER(ctypes.c_int32)]),
     'env2048_advance_counter': (_c_int, [_c_int, _ptr, _ptr, _u64]),
@@ -168,6 +171,12 @@ class Library:
         bpl, through = ctypes.c_int32(), ctypes.c_int32()
         self._check(self._dll.env2048_step_plan(n, flags, ctypes.byref(bpl), ctypes.byref(through)))
         return {'boards_per_lane': bpl.value, 'write_through': bool(through.value)}
+
+    def step_sequence_plan(self, n: int, count: int, flags: int = 0) -> dict:
+        """How env2048_step_sequence would run: {'chains': 1 | 2, 'boards_per_lane', 'write_through'}. No device needed."""
+        chains, bpl, through = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        self._check(self._dll.env2048_step_sequence_plan(n, count, flags, ctypes.byref(chains), ctypes.byref(bpl), ctypes.byref(through)))
+        return {'chains': chains.value, 'boards_per_lane': bpl.value, 'write_through': bool(through.value)}
 
     def step_many_plan(self, records) -> dict:
         """How env2048_step_many would run ``records``: {'launches': L, 'launch_of': [...], 'boards_per_lane': [...],

@@ -11,6 +11,13 @@
 #include <stdarg.h>
 #include <stdlib.h>
 
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
+
 #include "env2048.h"
 #include "board_ops.hpp"
 
@@ -1747,7 +1754,7 @@ int launched(const char *what)
 
 constexpr uint32_t STEP_FLAGS = ENV2048_FLAG_AUTO_RESET | ENV2048_FLAG_RANDOM_ACTIONS | ENV2048_FLAG_OBS_F16 | ENV2048_FLAG_OBS_BF16 |
                                 ENV2048_FLAG_STORES_WRITE_THROUGH | ENV2048_FLAG_STORES_WRITE_BACK | ENV2048_FLAG_REWARD_LOG2_F32 |
-                                ENV2048_FLAG_TILE_SMALL | ENV2048_FLAG_TILE_LARGE;
+                                ENV2048_FLAG_TILE_SMALL | ENV2048_FLAG_TILE_LARGE | ENV2048_FLAG_SINGLE_CHAIN;
 // Launches up to this many boards use write-through stores unless a STORES_* flag says otherwise: they win while
 // boards + outputs of one launch stay within the 256 MiB Infinity Cache (measured 2^20..2^23 boards: -5..-13 %)
 // and lose beyond it (2^24: +7 %).
@@ -1782,7 +1789,7 @@ int validate_step(const env2048_step_args &a, const char *who)
 void launch_step(const env2048_step_args &a, hipStream_t stream)
 {
     uint32_t kernel_flags = a.flags & ~(ENV2048_FLAG_STORES_WRITE_THROUGH | ENV2048_FLAG_STORES_WRITE_BACK | ENV2048_FLAG_TILE_SMALL |
-                                        ENV2048_FLAG_TILE_LARGE);
+                                        ENV2048_FLAG_TILE_LARGE | ENV2048_FLAG_SINGLE_CHAIN);
     if (!misaligned(a.reward, 16) && !misaligned(a.done, 4)) kernel_flags |= INTERNAL_FLAG_WIDE_OUTPUTS;
     const bool through = (a.flags & ENV2048_FLAG_STORES_WRITE_THROUGH)  ? true
                          : (a.flags & ENV2048_FLAG_STORES_WRITE_BACK) ? false
@@ -2018,7 +2025,7 @@ void launch_group(const env2048_step_args *args, uint64_t first, uint64_t last, 
         const env2048_step_args &a = args[k];
         if (a.n == 0) continue;
         uint32_t kernel_flags = a.flags & ~(ENV2048_FLAG_STORES_WRITE_THROUGH | ENV2048_FLAG_STORES_WRITE_BACK | ENV2048_FLAG_TILE_SMALL |
-                                            ENV2048_FLAG_TILE_LARGE);
+                                            ENV2048_FLAG_TILE_LARGE | ENV2048_FLAG_SINGLE_CHAIN);
         if (!misaligned(a.reward, 16) && !misaligned(a.done, 4)) kernel_flags |= INTERNAL_FLAG_WIDE_OUTPUTS;
         if (plan_write_through(total, a.flags)) kernel_flags |= INTERNAL_FLAG_WRITE_THROUGH;
         const uint32_t blocks = (uint32_t)((a.n + block_boards(bpl) - 1) / block_boards(bpl));
@@ -2047,6 +2054,85 @@ void launch_group(const env2048_step_args *args, uint64_t first, uint64_t last, 
 #undef ENV2048_LAUNCH_MANY
 }
 // [step-kernel-source-end]
+
+// ---- env2048_step_sequence: two half-batch chains -----------------------------------------------------------------------------
+// K dependent steps of ONE batch are K dependent launches, and a 2^20-board launch is a single generation of workgroups: launch
+// -> load phase -> arithmetic -> store drain -> kernel boundary, none of which overlaps with the next launch of the same chain
+// (20-25 % above the memory floor, whatever the instruction count or occupancy).  But the environments of a batch do
+// not depend on each other: the two HALVES of the batch are two independent chains, and run on two streams they slide against
+// each other -- one half's load phase and store drain under the other half's arithmetic (measured: 6.5-6.7 us per 2^20-board
+// step instead of 7.7-7.9).  One host thread cannot feed two chains (3.5 us per launch against a 6.5 us step), so the second
+// chain is enqueued by a helper thread per device while the caller's thread enqueues the first; both chains are ordered behind
+// everything already on the caller's stream (event fork) and the caller's stream waits for both (event join), so to the caller
+// the call still looks like K launches on `stream`.  Results are those of the unsplit launches bit for bit (global environment
+// indices in the Philox counters).
+constexpr uint64_t SPLIT_MIN_BOARDS = 1ull << 20;  // below: a half (< 2^19 boards) is latency- / launch-bound on its own (2^19: 6.1 vs 5.5 us)
+constexpr uint64_t SPLIT_MAX_BOARDS = 1ull << 23;  // above: one launch already runs at the memory floor (2^23: 43.7 vs 48.4 us, 2^24: 118 vs 98)
+constexpr uint32_t SPLIT_MIN_STEPS = 32;           // two enqueuing threads cost 6-7 us of host time per step while the queues fill: K = 20
+                                                   // blocks are enqueue-bound (+3 % .. -3 %), K = 50: -10 %, 100: -12 %, >= 1000: -15..17 %
+
+struct DeviceLanes {  // per device, created on first use, never destroyed (a helper blocked in wait() must outlive static destructors)
+    hipStream_t side = nullptr;
+    std::mutex call_mutex;  // one split call at a time per device
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool has_job = false, job_done = false;
+    std::atomic<bool> posted{false};  // set with has_job: what the helper polls while it is still warm
+    hipError_t job_error = hipSuccess;
+    hipError_t create_error = hipSuccess;
+};
+
+DeviceLanes *lanes_for(int device)
+{
+    static std::mutex table_mutex;
+    static DeviceLanes *table[64] = {};
+    if (device < 0 || device >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(table_mutex);
+    if (!table[device]) {
+        DeviceLanes *L = new DeviceLanes;
+        L->create_error = hipStreamCreateWithFlags(&L->side, hipStreamNonBlocking);  // (the caller has selected `device`)
+        if (L->create_error == hipSuccess) {
+            std::thread([L, device] {
+                (void)hipSetDevice(device);
+                std::unique_lock<std::mutex> lk(L->m);
+                for (;;) {
+                    if (!L->has_job) {
+                        // calls come in bursts (a stepping loop): after a job keep polling for ~300 us before going to sleep, so
+                        // that the next call's second chain starts within a microsecond instead of a futex wake-up later
+                        lk.unlock();
+                        const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(300);
+                        while (!L->posted.load(std::memory_order_acquire) && std::chrono::steady_clock::now() < until) __builtin_ia32_pause();
+                        lk.lock();
+                    }
+                    L->cv.wait(lk, [L] { return L->has_job; });
+                    L->posted.store(false, std::memory_order_relaxed);
+                    std::function<void()> job = std::move(L->job);
+                    L->has_job = false;
+                    lk.unlock();
+                    job();
+                    const hipError_t e = hipGetLastError();
+                    lk.lock();
+                    L->job_error = e;
+                    L->job_done = true;
+                    L->cv.notify_all();
+                }
+            }).detach();
+        }
+        table[device] = L;
+    }
+    return table[device];
+}
+
+inline bool plan_two_chains(uint64_t n, uint32_t count, uint32_t flags)
+{
+#ifdef ENV2048_EXP_SPLIT_MIN_STEPS
+    static const uint32_t min_steps = getenv("ENV2048_SPLIT_MIN_STEPS") ? (uint32_t)atoi(getenv("ENV2048_SPLIT_MIN_STEPS")) : SPLIT_MIN_STEPS;
+    static const uint64_t max_boards = getenv("ENV2048_SPLIT_MAX_LOG2") ? 1ull << atoi(getenv("ENV2048_SPLIT_MAX_LOG2")) : SPLIT_MAX_BOARDS;
+    return !(flags & ENV2048_FLAG_SINGLE_CHAIN) && n >= SPLIT_MIN_BOARDS && n <= max_boards && count >= min_steps;
+#endif
+    return !(flags & ENV2048_FLAG_SINGLE_CHAIN) && n >= SPLIT_MIN_BOARDS && n <= SPLIT_MAX_BOARDS && count >= SPLIT_MIN_STEPS;
+}
 
 }  // namespace
 
@@ -2184,8 +2270,86 @@ int env2048_step_sequence(int device, void *stream, uint64_t n, uint64_t env_bas
     if (n == 0) return ENV2048_OK;
     DeviceScope scope(device);
     if (scope.rc) return scope.rc;
-    for (uint32_t t = 0; t < count; ++t) launch_step(record(t), (hipStream_t)stream);
-    return launched("env2048_step_sequence launch");
+    hipStream_t main_stream = (hipStream_t)stream;
+    bool two_chains = plan_two_chains(n, count, flags);
+    if (two_chains) {  // a stream that is being captured into a graph takes the plain form (no cross-thread work inside a capture)
+        hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(main_stream, &capture) != hipSuccess || capture != hipStreamCaptureStatusNone) {
+            (void)hipGetLastError();
+            two_chains = false;
+        }
+    }
+    DeviceLanes *L = two_chains ? lanes_for(device) : nullptr;
+    if (!L || L->create_error != hipSuccess) {
+        for (uint32_t t = 0; t < count; ++t) launch_step(record(t), main_stream);
+        return launched("env2048_step_sequence launch");
+    }
+    // the second half starts on a block boundary of the large tiling, so the first half consists of full blocks only
+    const uint64_t h = (n / 2) / block_boards(BOARDS_PER_LANE) * block_boards(BOARDS_PER_LANE);
+    auto half = [&](uint32_t t, int which) {
+        env2048_step_args a = record(t);
+        if (which == 0) {
+            a.n = h;
+        } else {
+            a.n = n - h;
+            a.env_base += h;
+            a.boards += 16 * h;
+            if (a.actions) a.actions += h;
+            if (a.reward) a.reward += h;
+            if (a.done) a.done += h;
+            if (a.legal) a.legal += h;
+            if (a.obs) a.obs = static_cast<uint8_t *>(a.obs) + 16u * obs_bytes * h;
+        }
+        return a;
+    };
+    std::lock_guard<std::mutex> call(L->call_mutex);
+    hipEvent_t fork = nullptr, join = nullptr;
+    hipError_t e = hipEventCreateWithFlags(&fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&join, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(fork, main_stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(L->side, fork, 0);
+    if (e != hipSuccess) {
+        if (fork) (void)hipEventDestroy(fork);
+        if (join) (void)hipEventDestroy(join);
+        return hip_fail(e, "env2048_step_sequence: fork of the second chain");
+    }
+    {
+        std::lock_guard<std::mutex> lk(L->m);
+        L->job = [&] {
+            for (uint32_t t = 0; t < count; ++t) launch_step(half(t, 1), L->side);
+        };
+        L->has_job = true;
+        L->job_done = false;
+        L->posted.store(true, std::memory_order_release);
+    }
+    L->cv.notify_all();
+    for (uint32_t t = 0; t < count; ++t) launch_step(half(t, 0), main_stream);
+    const hipError_t mine = hipGetLastError();
+    hipError_t theirs;
+    {
+        std::unique_lock<std::mutex> lk(L->m);
+        L->cv.wait(lk, [L] { return L->job_done; });
+        theirs = L->job_error;
+    }
+    e = hipEventRecord(join, L->side);
+    if (e == hipSuccess) e = hipStreamWaitEvent(main_stream, join, 0);
+    (void)hipEventDestroy(fork);
+    (void)hipEventDestroy(join);
+    if (mine != hipSuccess) return hip_fail(mine, "env2048_step_sequence launch");
+    if (theirs != hipSuccess) return hip_fail(theirs, "env2048_step_sequence launch (second chain)");
+    if (e != hipSuccess) return hip_fail(e, "env2048_step_sequence: join of the second chain");
+    return ENV2048_OK;
+}
+
+int env2048_step_sequence_plan(uint64_t n, uint32_t count, uint32_t flags, int32_t *chains, int32_t *boards_per_lane, int32_t *write_through)
+{
+    if (flags & ~STEP_FLAGS) return fail(ENV2048_ERR_INVALID_ARG, "env2048_step_sequence_plan: unknown flag bits 0x%x", flags);
+    const bool two = plan_two_chains(n, count, flags);
+    const uint64_t per_launch = two ? n - (n / 2) / block_boards(BOARDS_PER_LANE) * block_boards(BOARDS_PER_LANE) : n;
+    if (chains) *chains = two ? 2 : 1;
+    if (boards_per_lane) *boards_per_lane = plan_small_tiling(per_launch, flags) ? 1 : BOARDS_PER_LANE;
+    if (write_through) *write_through = plan_write_through(per_launch, flags) ? 1 : 0;
+    return ENV2048_OK;
 }
 
 static int step_state_i32_common(const char *who, int device, void *stream, uint64_t n, uint64_t env_base, const uint32_t *keys,

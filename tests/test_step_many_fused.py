@@ -258,3 +258,67 @@ def test_default_store_policy_beyond_2_pow_23_boards_vs_oracle():
         assert int(got.sum(dtype=np.uint64)) == int(ref_boards.sum(dtype=np.uint64))
         assert np.array_equal(got, ref_boards)
         assert np.array_equal(reward.cpu().numpy(), ref['reward']) and np.array_equal(done.cpu().numpy(), ref['done'])
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# env2048_step_sequence: two half-batch chains (the calling thread feeds one, a helper thread of the library the other)
+# ---------------------------------------------------------------------------------------------------------------------------
+def test_step_sequence_plan_two_chains():
+    lib = capi.Library()
+    assert lib.step_sequence_plan(1 << 20, 200) == {'chains': 2, 'boards_per_lane': 4, 'write_through': True}
+    assert lib.step_sequence_plan(1 << 20, 31)['chains'] == 1 and lib.step_sequence_plan(1 << 20, 32)['chains'] == 2  # too few steps to amortise fork / join
+    assert lib.step_sequence_plan((1 << 20) - 1, 200)['chains'] == 1     # a half would be latency-bound on its own
+    assert lib.step_sequence_plan(1 << 20, 200)['chains'] == 2 and lib.step_sequence_plan(1 << 23, 200)['chains'] == 2
+    assert lib.step_sequence_plan((1 << 23) + 1, 200)['chains'] == 1     # one launch already runs several generations
+    assert lib.step_sequence_plan(1 << 20, 200, capi.FLAG_SINGLE_CHAIN)['chains'] == 1
+    with pytest.raises(capi.Env2048Error):
+        lib.step_sequence_plan(1 << 20, 20, 1 << 30)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n', [1 << 20, (1 << 20) + 2049, (1 << 20) + 77])
+def test_step_sequence_two_chains_equal_single_chain_and_single_steps(n):
+    """K dependent steps as two half-batch chains == the same call with ENV2048_FLAG_SINGLE_CHAIN == K env2048_step calls:
+    boards and every recorded row, with host actions and with on-device actions, with the legal mask and observations, followed
+    by work on the caller's stream that must see the results of BOTH chains."""
+    import ctypes
+
+    lib = capi.library()
+    K, base, seed = 32, 12_345, 0xABC
+    rng = np.random.default_rng(n)
+    start = midgame(lib, n, env_base=base, seed=seed)
+    acts = torch.from_numpy(rng.integers(0, 4, size=(K, n)).astype(np.uint8)).cuda()
+    table = (ctypes.c_void_p * K)(*[acts[k].data_ptr() for k in range(K)])
+    for random_actions in (False, True):
+        for extras in (False, True):
+            flags = AUTO | (RANDOM if random_actions else 0) | (capi.FLAG_OBS_F16 if extras else 0)
+            assert lib.step_sequence_plan(n, K, flags)['chains'] == 2
+            results = []
+            for mode in ('two', 'single', 'steps'):
+                b = start.clone()
+                r = torch.full((K, n), -3, dtype=torch.int32, device='cuda')
+                d = torch.full((K, n), 7, dtype=torch.uint8, device='cuda')
+                lg = torch.full((K, n), 99, dtype=torch.uint8, device='cuda') if extras else None
+                ob = torch.full((K, n, 16), -1.0, dtype=torch.float16, device='cuda') if extras else None  # f16 rows: 1 GiB per mode
+                if mode == 'steps':
+                    for k in range(K):
+                        lib.step(DEV, stream(), n, base, p(b), None if random_actions else p(acts[k]), p(r[k]), p(d[k]),
+                                 p(lg[k]) if extras else None, p(ob[k]) if extras else None, seed, 500 + k, flags)
+                else:
+                    lib.step_sequence(DEV, stream(), n, base, p(b), None if random_actions else table, p(r), p(d), p(lg), p(ob), n, seed, 500, K,
+                                      flags | (capi.FLAG_SINGLE_CHAIN if mode == 'single' else 0))
+                checksum = b.sum(dtype=torch.int64) + r.sum(dtype=torch.int64)  # caller-stream work right behind the call
+                torch.cuda.synchronize()
+                results.append((b, r, d, lg, ob, int(checksum)))
+            for other in results[1:]:
+                for x, y in zip(results[0][:5], other[:5]):
+                    assert (x is None and y is None) or torch.equal(x, y)
+                assert results[0][5] == other[5]
+    # row_stride = 0: every step overwrites the same output arrays (what bench.py's timed region does)
+    b1, b2 = start.clone(), start.clone()
+    r1, r2 = (torch.zeros((n,), dtype=torch.int32, device='cuda') for _ in range(2))
+    d1, d2 = (torch.zeros((n,), dtype=torch.uint8, device='cuda') for _ in range(2))
+    lib.step_sequence(DEV, stream(), n, base, p(b1), table, p(r1), p(d1), None, None, 0, seed, 9, K, AUTO)
+    lib.step_sequence(DEV, stream(), n, base, p(b2), table, p(r2), p(d2), None, None, 0, seed, 9, K, AUTO | capi.FLAG_SINGLE_CHAIN)
+    torch.cuda.synchronize()
+    assert torch.equal(b1, b2) and torch.equal(r1, r2) and torch.equal(d1, d2)

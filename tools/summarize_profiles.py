@@ -23,31 +23,36 @@ import bench  # noqa: E402  (kernel_source_sha only; nothing touches a GPU)
 KERNEL = 'step_kernel<false, false, 4>'  # lean outputs, host actions, the large tiling (what 2^20-board launches run)
 SHARED = 'step_many_kernel<false, false, 4>'  # the same block code over the records of an env2048_step_many call
 BOARDS = 1 << 20
-COLD_RECORDS = -(-int(2.5 * (256 << 20)) // (BOARDS * 22))  # bench.py's cold leg: records (buffer sets) per shared launch
-# leg -> (rocprof run it comes from, kernel, 2^20-board records per launch): the --only-cold run holds BOTH cold forms
-LEGS = {'resident': ('resident', KERNEL, 1), 'cold': ('cold', SHARED, COLD_RECORDS), 'cold_separate': ('cold', KERNEL, 1)}
+# leg -> (rocprof run it comes from, kernel): the --only-cold run holds BOTH cold forms.  Every figure is scaled to ONE 2^20-board
+# step (record): a launch's share is boards-per-launch / 2^20, read off its grid size (512-thread blocks of 2048 boards: 4 boards
+# per work-item) -- 1/30 of a shared cold launch, and TWO launches per step where env2048_step_sequence runs two half-batch chains.
+LEGS = {'resident': ('resident', KERNEL), 'cold': ('cold', SHARED), 'cold_separate': ('cold', KERNEL)}
 
 
-def leg_counters(src: Path, leg: str) -> dict:
-    run, kernel, records = LEGS[leg]
-    counters = {}
+def leg_counters(src: Path, leg: str):
+    run, kernel = LEGS[leg]
+    counters, per_launch_boards = {}, []
     for path in glob.glob(str(src / f'pmc_{run}_*' / '*' / '*counter_collection.csv')):
         rows = [r for r in csv.DictReader(open(path)) if kernel in r['Kernel_Name']]
         by_name = {}
         for r in rows:
-            by_name.setdefault(r['Counter_Name'], []).append(float(r['Counter_Value']))
+            boards = float(r['Grid_Size']) * 4.0
+            per_launch_boards.append(boards)
+            by_name.setdefault(r['Counter_Name'], []).append(float(r['Counter_Value']) * BOARDS / boards)
         for name, vals in by_name.items():
             vals = vals[len(vals) // 4:]  # skip the warm-up launches
-            counters[name] = {'mean': statistics.mean(vals) / records, 'launches': len(vals)}  # per 2^20-board record
-    return counters
+            counters[name] = {'mean': statistics.mean(vals), 'launches': len(vals)}  # per 2^20-board step
+    boards = statistics.median(per_launch_boards) if per_launch_boards else float(BOARDS)
+    return counters, boards
 
 
-def kernel_avg_us(stats_csv: Path, leg: str):
-    _, kernel, records = LEGS[leg]
+def kernel_avg_us(stats_csv: Path, leg: str, boards_per_launch: float):
+    _, kernel = LEGS[leg]
     for r in csv.DictReader(open(stats_csv)):
         if kernel in r['Name']:
-            return {'calls': int(r['Calls']), 'avg_us': float(r['AverageNs']) / 1e3 / records, 'min_us': float(r['MinNs']) / 1e3 / records,
-                    'max_us': float(r['MaxNs']) / 1e3 / records, 'records_per_launch': records}
+            return {'calls': int(r['Calls']), 'avg_us': float(r['AverageNs']) / 1e3, 'min_us': float(r['MinNs']) / 1e3,
+                    'max_us': float(r['MaxNs']) / 1e3, 'boards_per_launch': boards_per_launch,
+                    'avg_us_per_2pow20_boards': float(r['AverageNs']) / 1e3 * BOARDS / boards_per_launch}
     return None
 
 
@@ -63,24 +68,26 @@ def main(tag, label, dest=None):
                         'wide coalesced reads at half their bytes; MI355X_MICROARCH.md, HBM section); counts Infinity-Cache hits'}
     for leg in LEGS:
         stats = glob.glob(str(src / f'stats_{LEGS[leg][0]}' / '*' / '*kernel_stats.csv'))
-        entry = {'kernel': LEGS[leg][1], 'per': f'2^20-board record ({LEGS[leg][2]} per launch)'}
+        counters, boards_per_launch = leg_counters(src, leg)
+        entry = {'kernel': LEGS[leg][1], 'boards_per_launch': boards_per_launch, 'launches_per_2pow20_board_step': BOARDS / boards_per_launch,
+                 'per': 'counters are scaled to ONE 2^20-board step (all the launches, or the share of a shared launch, that step it)'}
         if stats:
             if leg != 'cold_separate':
                 shutil.copy(stats[0], dst / f'{label}_{leg}_kernel_stats.csv')
-            entry['rocprof_kernel_stats'] = kernel_avg_us(Path(stats[0]), leg)
-        counters = leg_counters(src, leg)
+            entry['rocprof_kernel_stats'] = kernel_avg_us(Path(stats[0]), leg, boards_per_launch)
         entry['counters'] = counters
         if 'FETCH_SIZE' in counters and 'WRITE_SIZE' in counters:
             fetch = counters['FETCH_SIZE']['mean'] * 1024 * 2
             write = counters['WRITE_SIZE']['mean'] * 1024
             entry.update(fabric_read_bytes=fetch, fabric_write_bytes=write, fabric_bytes_per_launch=fetch + write,
                          traffic_over_algorithmic=(fetch + write) / (38 * BOARDS))
-            row = {'fabric_bytes_per_launch': fetch + write, 'source': f'profiles/{label}_pmc_summary.json'}
+            row = {'fabric_bytes_per_launch': fetch + write, 'source': f'profiles/{label}_pmc_summary.json', 'boards_per_kernel_launch': boards_per_launch,
+                   'per': '2^20-board step'}
             if 'SQ_INSTS_VALU' in counters:
                 row['valu_insts_per_launch'] = counters['SQ_INSTS_VALU']['mean']
             table['entries'][f'{leg}:{BOARDS}'] = row
         if 'SQ_INSTS_VALU' in counters and 'SQ_WAVES' in counters:
-            entry['valu_instructions_per_board'] = counters['SQ_INSTS_VALU']['mean'] / counters['SQ_WAVES']['mean'] / 4
+            entry['valu_instructions_per_board'] = counters['SQ_INSTS_VALU']['mean'] * 64 / BOARDS
         summary['legs'][leg] = entry
     (dst / f'{label}_pmc_summary.json').write_text(json.dumps(summary, indent=1) + '\n')
     if table['entries']:
