@@ -266,16 +266,18 @@ def load_step_profile(boards: int, leg: str):
 
 
 def valu_ceiling(waves_per_simd: int = 4):
-    """(G wave-instructions/s, source text) of the measured VALU ceiling for the step kernel's mix."""
+    """(G wave-instructions/s, source text, sustained rate of the real instruction stream or None) of the measured VALU ceiling
+    for the step kernel's mix."""
     path = REPO / 'profiles' / 'valu_ceiling.json'
     try:
         table = json.loads(path.read_text())
         row = table['ceiling'][str(waves_per_simd)]
+        real = table.get('real_instruction_stream')
         return row['g_wave_instr_per_s'], (f'profiles/valu_ceiling.json: {row["cycles_per_wave_instruction"]} cycles per wave64 instruction for this '
                                            f'kernel\'s opcode mix at {waves_per_simd} waves per SIMD (tools/issue_probe on MI355X: {table["probe"]}), '
-                                           f'1024 SIMDs x 2.4 GHz')
+                                           f'1024 SIMDs x 2.4 GHz'), real
     except Exception:
-        return VALU_PEAK_GINSTR_FALLBACK, 'fallback constant of bench.py (profiles/valu_ceiling.json not readable)'
+        return VALU_PEAK_GINSTR_FALLBACK, 'fallback constant of bench.py (profiles/valu_ceiling.json not readable)', None
 
 
 def build_roofline(args, lib, n: int, flags: int, launch_s: float, obs_bytes: int) -> dict:
@@ -308,7 +310,7 @@ def build_roofline(args, lib, n: int, flags: int, launch_s: float, obs_bytes: in
     if resident and prof is not None and prof.get('valu_insts_per_launch'):
         ginstr = prof['valu_insts_per_launch'] / launch_s / 1e9
         waves_per_simd = max(1, min(8, round(n / (64 * tiling) / 1024)))  # both half-batch chains are resident together
-        peak, peak_source = valu_ceiling(4 if waves_per_simd >= 4 else 2 if waves_per_simd >= 2 else 1)
+        peak, peak_source, real_stream = valu_ceiling(4 if waves_per_simd >= 4 else 2 if waves_per_simd >= 2 else 1)
         per_lane = prof['valu_insts_per_launch'] * 64 / n  # wave64 instructions x 64 lanes / boards
         roofline.update({
             'bound': 'valu',
@@ -323,6 +325,11 @@ def build_roofline(args, lib, n: int, flags: int, launch_s: float, obs_bytes: in
                    f'x 64 lanes / board), against the MEASURED issue ceiling of this opcode mix at {waves_per_simd} waves per SIMD.  '
                    f'The launch is 15-20 % above its memory-only floor (tools/microbench, DESIGN 6.1); the HBM fraction of this '
                    f'kernel is roofline.hbm_cold',
+            'vs_real_instruction_stream': None if not real_stream else {
+                'sustained_g_wave_instr_per_s': real_stream['saturated_g_wave_instr_per_s'],
+                'frac': ginstr / real_stream['saturated_g_wave_instr_per_s'], 'source': real_stream['source'],
+                'note': 'what the SAME instruction stream sustains with the boards in registers (env2048_rollout, any occupancy from 8 waves '
+                        'per SIMD): the practical VALU ceiling of this code; `peak` above is the stricter single-opcode-probe bound'},
             'hbm_resident_equiv': {'achieved': algo_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': algo_gbs / HBM_PEAK_GBS,
                                    'note': 'algorithmic bytes / launch time; NOT an HBM fraction while the working set is cache-resident'},
         })
