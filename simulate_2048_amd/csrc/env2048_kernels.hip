@@ -1283,8 +1283,8 @@ __global__ __launch_bounds__(PLY_BLOCK) void expectimax_ply_kernel(uint64_t n, c
 // board it/2 and the 32 lanes of a half-wave add up their best rewards separately for the tile-2 and the tile-4 outcomes
 // (four xor-shuffles: the sums are INTEGERS, so the result does not depend on the order); phase 3, one board per lane
 // again: Q2 = r + (0.9 * S2 + 0.1 * S4) / n_empty as an exact fraction, arg-max, outputs.  Pure VALU work: 16 B in, 89 B out per board.
-struct D2After {  // one (board, action) entry of the LDS strip: 24 bytes (6 KiB per wave: six workgroups per CU)
-    uint32_t r0, r1, r2, r3;  // the afterstate; once its successors have been evaluated, r0 / r1 are reused for the sums S2 / S4
+struct D2After {  // one (board, action) entry of the LDS strip: 24 bytes
+    uint32_t r0, r1, r2, r3;  // the afterstate
     uint32_t empties;         // cell mask of the afterstate's empty cells; 0 = action illegal
     int32_t reward;
 };
@@ -1321,23 +1321,28 @@ __global__ __launch_bounds__(D2_BLOCK) void expectimax_depth2_kernel(uint64_t n,
                                                                       uint8_t *best_action, float *value)
 {
     __shared__ __attribute__((aligned(16))) D2After strip_lds[D2_BLOCK / 64][64 * 4];
+    __shared__ int32_t sums_lds[D2_BLOCK / 64][64 * 4][2];   // per (board, action): S2, S4
+    __shared__ uint16_t first_lds[D2_BLOCK / 64][64 * 4 + 4];  // exclusive prefix sum of the successor counts (+ the total)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint64_t board0 = ((uint64_t)blockIdx.x * (D2_BLOCK / 64) + wave) * 64u;
     if (board0 >= n) return;  // wave-uniform
     D2After *strip = strip_lds[wave];
+    int32_t(*sums)[2] = sums_lds[wave];
+    uint16_t *first = first_lds[wave];
 
     // phase 1: one board per lane -> four afterstates
     const uint64_t mine = board0 + lane;
+    uint32_t mine_count = 0u, c0 = 0u, c1 = 0u, c2 = 0u;  // successors of my board, and of its first three actions
     if (mine < n) {
         const Board bd = load_board(boards, mine);
-        uint32_t c0, c1, c2, c3;
-        transpose4x4(bd.r0, bd.r1, bd.r2, bd.r3, c0, c1, c2, c3);
+        uint32_t t0, t1, t2, t3;
+        transpose4x4(bd.r0, bd.r1, bd.r2, bd.r3, t0, t1, t2, t3);
         Board after[4];
         int32_t rewards[4];
         uint32_t legal = 0u, changed;
         {
-            uint32_t a = c0, b = c1, c = c2, d = c3;
+            uint32_t a = t0, b = t1, c = t2, d = t3;
             rewards[0] = (int32_t)slide_merge_planes(a, b, c, d, changed);
             transpose4x4(a, b, c, d, after[0].r0, after[0].r1, after[0].r2, after[0].r3);
             legal |= changed != 0u ? 1u : 0u;
@@ -1349,7 +1354,7 @@ __global__ __launch_bounds__(D2_BLOCK) void expectimax_depth2_kernel(uint64_t n,
             legal |= changed != 0u ? 2u : 0u;
         }
         {
-            uint32_t a = c3, b = c2, c = c1, d = c0;
+            uint32_t a = t3, b = t2, c = t1, d = t0;
             rewards[2] = (int32_t)slide_merge_planes(a, b, c, d, changed);
             transpose4x4(d, c, b, a, after[2].r0, after[2].r1, after[2].r2, after[2].r3);
             legal |= changed != 0u ? 4u : 0u;
@@ -1360,38 +1365,58 @@ __global__ __launch_bounds__(D2_BLOCK) void expectimax_depth2_kernel(uint64_t n,
             after[3] = Board{d, c, b, a};
             legal |= changed != 0u ? 8u : 0u;
         }
+        uint32_t count[4];
 #pragma unroll
         for (uint32_t act = 0; act < 4u; ++act) {
             const bool is_legal = ((legal >> act) & 1u) != 0u;
             const uint32_t empt = is_legal ? empty_mask(after[act]) : 0u;  // a legal move always leaves an empty cell
             strip[4u * lane + act] = D2After{after[act].r0, after[act].r1, after[act].r2, after[act].r3, empt, is_legal ? rewards[act] : 0};
+            sums[4u * lane + act][0] = 0;
+            sums[4u * lane + act][1] = 0;
+            count[act] = 2u * ENV2048_POPC(empt);  // successors of this afterstate: a 2 and a 4 in every empty cell
         }
+        mine_count = count[0] + count[1] + count[2] + count[3];
+        c0 = count[0];
+        c1 = count[1];
+        c2 = count[2];
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the strip is wave-private: LDS ops of a wave are ordered
+    // successors are WORK ITEMS numbered densely over the wave's 256 (board, action) entries: entry e owns items
+    // [first[e], first[e + 1]).  On mid-game boards 34 of the 128 slots per board hold a successor, so walking the slots
+    // would leave three quarters of the lanes idle.  Exclusive scan of the per-board counts over the wave (six shuffles).
+    uint32_t scan = mine_count;
+#pragma unroll
+    for (uint32_t d = 1; d < 64u; d <<= 1) {
+        const uint32_t up = __shfl_up(scan, d);
+        scan += lane >= d ? up : 0u;
+    }
+    const uint32_t total = __shfl(scan, 63);
+    const uint32_t before = scan - mine_count;
+    first[4u * lane + 0u] = (uint16_t)before;
+    first[4u * lane + 1u] = (uint16_t)(before + c0);
+    first[4u * lane + 2u] = (uint16_t)(before + c0 + c1);
+    first[4u * lane + 3u] = (uint16_t)(before + c0 + c1 + c2);
+    if (lane == 63u) first[256] = (uint16_t)total;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // strip, sums and first are wave-private: LDS ops of a wave are ordered
     __builtin_amdgcn_wave_barrier();
 
-    // phase 2: 128 successor slots per board, 64 per iteration
-    const uint32_t boards_here = (uint32_t)min((uint64_t)64, n - board0);
-    const uint32_t slot = lane & 31u, k = slot >> 1;
-    const bool four = (slot & 1u) != 0u;
-    for (uint32_t it = 0; it < 2u * boards_here; ++it) {
-        const uint32_t entry = 4u * (it >> 1) + 2u * (it & 1u) + (lane >> 5);
-        const D2After a = strip[entry];
-        int32_t best = 0;
-        if (k < ENV2048_POPC(a.empties)) {
+    // phase 2: 64 successors per iteration
+    for (uint32_t w0 = 0; w0 < total; w0 += 64u) {
+        const uint32_t w = w0 + lane;
+        if (w < total) {
+            uint32_t lo = 0u, hi = 256u;  // the LAST entry whose first item is <= w (entries without successors are skipped by that)
+#pragma unroll
+            for (int step = 0; step < 8; ++step) {
+                const uint32_t mid = (lo + hi) >> 1;
+                const bool right = first[mid] <= w;
+                lo = right ? mid : lo;
+                hi = right ? hi : mid;
+            }
+            const D2After a = strip[lo];
+            const uint32_t slot = w - first[lo];
             Board bd{a.r0, a.r1, a.r2, a.r3};
-            place_tile(bd, kth_empty(a.empties, k), four);
-            best = best_move_reward(bd);
+            place_tile(bd, kth_empty(a.empties, slot >> 1), (slot & 1u) != 0u);
+            atomicAdd(&sums[lo][slot & 1u], best_move_reward(bd));  // integer sums: the order of the adds does not matter
         }
-        // sum over the 16 lanes of this half-wave that share the tile value (same parity): offsets 2, 4, 8, 16
-        best += __shfl_xor(best, 2);
-        best += __shfl_xor(best, 4);
-        best += __shfl_xor(best, 8);
-        best += __shfl_xor(best, 16);
-        // slot 0 holds S2 (tile-2 outcomes), slot 1 S4: parked in the entry's r0 / r1 -- every lane of the half-wave has read the
-        // entry above and a wave's LDS operations execute in order, and no later iteration reads this entry's board again
-        if (slot == 0u) strip[entry].r0 = (uint32_t)best;
-        if (slot == 1u) strip[entry].r1 = (uint32_t)best;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1408,7 +1433,7 @@ __global__ __launch_bounds__(D2_BLOCK) void expectimax_depth2_kernel(uint64_t n,
 #pragma unroll
     for (uint32_t act = 0; act < 4u; ++act) {
         const D2After a = strip[4u * lane + act];
-        const int32_t s2 = (int32_t)a.r0, s4 = (int32_t)a.r1, n_empty = (int32_t)ENV2048_POPC(a.empties);
+        const int32_t s2 = sums[4u * lane + act][0], s4 = sums[4u * lane + act][1], n_empty = (int32_t)ENV2048_POPC(a.empties);
         t[act] = make_int4(a.reward, s2, s4, n_empty);
         if (a.empties != 0u) {
             const int64_t d = 10 * (int64_t)n_empty, x = d * (int64_t)a.reward + 9 * (int64_t)s2 + (int64_t)s4;
