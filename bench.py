@@ -306,6 +306,9 @@ def build_roofline(args, lib, n: int, flags: int, launch_s: float, obs_bytes: in
         'traffic_kind': 'fabric bytes per launch (2*FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes): L2 <-> Infinity '
                         'Cache/HBM requests -- Infinity-Cache hits are counted, so this is HBM traffic only for the cold leg',
         'traffic_source': None if prof is None else dict(source=prof.get('source'), stale=prof['stale']),
+        'rocprof_kernel_stats': ('profiles/r03_t_resident_kernel_stats.csv (two half-batch chains: 16 200 launches of 2^19 boards, average 6.48 us each, two in '
+                                 'flight)' if plan['chains'] == 2 else
+                                 'profiles/r03_k_resident_kernel_stats.csv (one chain: 10 100 launches of 2^20 boards, average 7.81 us, isolated by the profiler)'),
     }
     if resident and prof is not None and prof.get('valu_insts_per_launch'):
         ginstr = prof['valu_insts_per_launch'] / launch_s / 1e9

@@ -10,6 +10,7 @@
 #include <stdio.h>
 #include <stdarg.h>
 #include <stdlib.h>
+#include <unistd.h>
 
 #include <atomic>
 #include <chrono>
@@ -2106,6 +2107,7 @@ struct DeviceLanes {  // per device, created on first use, never destroyed (a he
     std::atomic<bool> posted{false};  // set with has_job: what the helper polls while it is still warm
     hipError_t job_error = hipSuccess;
     hipError_t create_error = hipSuccess;
+    pid_t owner = 0;  // the process that created the helper thread (threads do not survive a fork)
 };
 
 DeviceLanes *lanes_for(int device)
@@ -2114,8 +2116,10 @@ DeviceLanes *lanes_for(int device)
     static DeviceLanes *table[64] = {};
     if (device < 0 || device >= 64) return nullptr;
     std::lock_guard<std::mutex> lock(table_mutex);
+    if (table[device] && table[device]->owner != getpid()) table[device] = nullptr;  // forked child: its helper does not exist
     if (!table[device]) {
         DeviceLanes *L = new DeviceLanes;
+        L->owner = getpid();
         L->create_error = hipStreamCreateWithFlags(&L->side, hipStreamNonBlocking);  // (the caller has selected `device`)
         if (L->create_error == hipSuccess) {
             std::thread([L, device] {
