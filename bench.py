@@ -475,19 +475,27 @@ def run_rank(args) -> None:
             action_table(K, phase)
         enqueue_times = []
 
-        def timed_block(count: int):
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        def timed_block(count: int, with_events: bool = True):
+            """One timed region: barrier + synchronize | K steps | synchronize.  Blocks alternate between two instruments: the
+            host clock alone (what `value` is computed from: nothing but the K steps sits between the two synchronisations) and
+            HIP events on the launch stream (the GPU-side duration, for the roofline); recording the events costs a few
+            microseconds of host time and two marker packets per block, which a 20-step block would otherwise carry as load."""
+            ev0 = ev1 = None
+            if with_events:
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            ev0.record(stream)
+            if with_events:
+                ev0.record(stream)
             run_steps(count)
             enqueued = time.perf_counter() - t0
-            ev1.record(stream)
+            if with_events:
+                ev1.record(stream)
             torch.cuda.synchronize()
             wall = time.perf_counter() - t0
             enqueue_times.append(enqueued / max(count, 1))
-            return wall, ev0.elapsed_time(ev1) * 1e-3
+            return wall, (ev0.elapsed_time(ev1) * 1e-3 if with_events else None)
 
         if args.only_cold:
             cold = cold_leg(args, torch, lib, capi, device, device_index, h, stream, n, env_base, world, midgame, pool, flags, 8e-6)
@@ -501,9 +509,8 @@ def run_rank(args) -> None:
         blocks = int(min(args.max_blocks, max(3, math.ceil(args.min_ms * 1e-3 / max(calib, 1e-7)))))
         walls, events = [], []
         for _ in range(blocks):
-            wall, ev = timed_block(K)
-            walls.append(wall)
-            events.append(ev)
+            walls.append(timed_block(K, with_events=False)[0])
+            events.append(timed_block(K, with_events=True)[1])
         barrier()
         walls_max = reduce_max(walls)      # per block: the slowest rank
         events_max = reduce_max(events)
@@ -556,7 +563,8 @@ def run_rank(args) -> None:
                     'event_us_per_step': {'median': launch_s * 1e6, 'min': min(events_max) / K * 1e6, 'max': max(events_max) / K * 1e6},
                     'per_rank_us_per_step': [{'rank': r, 'event': v[0], 'wall': v[1]} for r, v in enumerate(per_rank)],
                     'host_enqueue_us_per_launch': statistics.median(enqueue_times) * 1e6,  # rank 0; meaningful while the launch queue has room (small K)
-                    'note': 'value = boards x K x ranks / median over blocks of (max over ranks of the block wall time)',
+                    'note': 'value = boards x K x ranks / median over blocks of (max over ranks of the block wall time); wall-clock blocks '
+                        'and HIP-event blocks alternate (an event-timed block is not wall-timed: recording events is itself host work)',
                 },
                 'roofline': roofline,
             }

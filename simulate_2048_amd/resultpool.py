@@ -35,6 +35,7 @@ from .interop import DeviceArray
 _use_count = getattr(torch._C, '_storage_Use_Count', None)  # references to a StorageImpl (tensors, views, wrappers)
 
 MAX_SETS_PER_KEY = 6
+MAX_KEYS = 16  # distinct (n, device) shapes kept; the least recently used shape's sets are dropped beyond that
 STAGE_MAX_BYTES = 16 << 10  # larger host arrays take an ordinary H2D copy (the kernel would read them across the bus)
 
 
@@ -112,9 +113,16 @@ class ResultPool:
     def acquire(self, n: int, device: torch.device) -> ResultSet:
         key = (n, device)
         with self._lock:
-            sets = self._sets.get(key)
+            sets = self._sets.pop(key, None)  # (re-inserted below: dict order = recency of use)
             if sets is None:
-                sets = self._sets[key] = []
+                sets = []
+                while len(self._sets) >= MAX_KEYS:  # a caller cycling through many batch sizes must not pin memory for all of them
+                    _, dropped = next(iter(self._sets.items()))
+                    for old in dropped:
+                        for t in old.tensors:
+                            self.registry.pop(id(t), None)
+                    del self._sets[next(iter(self._sets))]
+            self._sets[key] = sets
             for rs in sets:
                 if rs.idle():
                     return rs

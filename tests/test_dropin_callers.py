@@ -322,3 +322,22 @@ def test_host_stager_ring_wraps_without_losing_data():
         assert np.array_equal(st.host[off:off + a.nbytes].view(np.uint32), a)
         seen.append(off)
     assert min(seen) == 0 and max(seen) >= 128  # both halves were used
+
+
+def test_result_pool_forgets_old_shapes(api_runtime):
+    """A caller that cycles through many batch sizes does not pin a result set per size for ever: beyond MAX_KEYS shapes the
+    least recently used shape's sets (and their registry entries) are dropped; states the caller still holds stay valid."""
+    rng = np.random.default_rng(11)
+    resultpool.pool.clear()
+    kept = batched_reset(_loop_keys(rng, 3))  # shape n = 3, held by the caller for the whole test
+    kept_board = np.array(kept.board).copy()
+    for n in range(4, 4 + resultpool.MAX_KEYS + 5):
+        st = batched_reset(_loop_keys(rng, n))
+        st, *_ = batched_step(st, np.zeros(n, dtype=np.int32), _loop_keys(rng, n))
+    assert len(resultpool.pool._sets) <= resultpool.MAX_KEYS
+    assert len(resultpool.pool.registry) <= resultpool.MAX_KEYS * resultpool.MAX_SETS_PER_KEY * 8
+    assert np.array_equal(np.array(kept.board), kept_board)  # dropped from the pool, never overwritten
+    obs = batched_get_observation(kept)  # no longer a pooled state: answered by a status launch of its own
+    assert np.array_equal(np.array(obs), oracle.status_batch(oracle.pack_values(kept_board.reshape(3, 16)).reshape(3, 16))['obs'])
+    again, *_ = batched_step(kept, np.zeros(3, dtype=np.int32), _loop_keys(rng, 3))
+    assert np.array(again.board).shape == (3, 4, 4)
