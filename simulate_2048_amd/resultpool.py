@@ -18,8 +18,8 @@ counters say neither the board nor the stash was modified in place).
 
 ``HostStager`` -- small host arrays (PRNG keys, actions) reach the kernel through a ring of PINNED host memory, which is
 device-accessible on HIP: one NumPy copy into the ring instead of a pageable H2D copy (8-12 microseconds each at N = 8).  The
-ring has two halves; the half being left gets an event on the launch stream, and that event is waited for before the half
-is written again, so a kernel never reads a slot that is being refilled -- with no per-call synchronisation.
+ring has two halves; the device is synchronised once whenever the writer moves into the other half (every 512 KiB of staged
+inputs), so a kernel never reads a slot that is being refilled -- with no per-call synchronisation.
 """
 
 from __future__ import annotations
@@ -161,19 +161,13 @@ class HostStager:
         self.capacity = capacity
         self.half = capacity // 2
         self.offset = 0
-        self.events = [None, None]  # per half: recorded when the writer LEFT it (every kernel reading it was enqueued before)
 
     def _enter_half(self, h: int) -> None:
-        if not self.gpu:
-            return
-        left = 1 - h
-        ev = self.events[left]
-        if ev is None:
-            ev = self.events[left] = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.device))  # all launches that read the half we are leaving are on the stream by now
-        pending = self.events[h]
-        if pending is not None:
-            pending.synchronize()  # (long done in any real loop: half a MiB of 100-byte inputs ago)
+        """Before half `h` is written again every kernel that read it must be done.  Those kernels were enqueued -- on whatever
+        streams the caller used -- before the writer left the half, i.e. at least half a ring (512 KiB of ~100-byte inputs: thousands
+        of moves) ago; one device synchronisation per half a ring makes that certain at no measurable cost."""
+        if self.gpu:
+            torch.cuda.synchronize(self.device)
 
     def stage(self, array: np.ndarray) -> int:
         """Copy a small contiguous host array into the ring; returns the device-visible address (16-byte aligned)."""
