@@ -2099,6 +2099,7 @@ constexpr uint32_t SPLIT_MIN_STEPS = 32;           // two enqueuing threads cost
 
 struct DeviceLanes {  // per device, created on first use, never destroyed (a helper blocked in wait() must outlive static destructors)
     hipStream_t side = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;  // re-recorded by every call (calls are serialised by call_mutex)
     std::mutex call_mutex;  // one split call at a time per device
     std::mutex m;
     std::condition_variable cv;
@@ -2121,6 +2122,8 @@ DeviceLanes *lanes_for(int device)
         DeviceLanes *L = new DeviceLanes;
         L->owner = getpid();
         L->create_error = hipStreamCreateWithFlags(&L->side, hipStreamNonBlocking);  // (the caller has selected `device`)
+        if (L->create_error == hipSuccess) L->create_error = hipEventCreateWithFlags(&L->fork, hipEventDisableTiming);
+        if (L->create_error == hipSuccess) L->create_error = hipEventCreateWithFlags(&L->join, hipEventDisableTiming);
         if (L->create_error == hipSuccess) {
             std::thread([L, device] {
                 (void)hipSetDevice(device);
@@ -2332,16 +2335,9 @@ int env2048_step_sequence(int device, void *stream, uint64_t n, uint64_t env_bas
         return a;
     };
     std::lock_guard<std::mutex> call(L->call_mutex);
-    hipEvent_t fork = nullptr, join = nullptr;
-    hipError_t e = hipEventCreateWithFlags(&fork, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&join, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventRecord(fork, main_stream);
-    if (e == hipSuccess) e = hipStreamWaitEvent(L->side, fork, 0);
-    if (e != hipSuccess) {
-        if (fork) (void)hipEventDestroy(fork);
-        if (join) (void)hipEventDestroy(join);
-        return hip_fail(e, "env2048_step_sequence: fork of the second chain");
-    }
+    hipError_t e = hipEventRecord(L->fork, main_stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(L->side, L->fork, 0);
+    if (e != hipSuccess) return hip_fail(e, "env2048_step_sequence: fork of the second chain");
     {
         std::lock_guard<std::mutex> lk(L->m);
         L->job = [&] {
@@ -2360,10 +2356,8 @@ int env2048_step_sequence(int device, void *stream, uint64_t n, uint64_t env_bas
         L->cv.wait(lk, [L] { return L->job_done; });
         theirs = L->job_error;
     }
-    e = hipEventRecord(join, L->side);
-    if (e == hipSuccess) e = hipStreamWaitEvent(main_stream, join, 0);
-    (void)hipEventDestroy(fork);
-    (void)hipEventDestroy(join);
+    e = hipEventRecord(L->join, L->side);
+    if (e == hipSuccess) e = hipStreamWaitEvent(main_stream, L->join, 0);
     if (mine != hipSuccess) return hip_fail(mine, "env2048_step_sequence launch");
     if (theirs != hipSuccess) return hip_fail(theirs, "env2048_step_sequence launch (second chain)");
     if (e != hipSuccess) return hip_fail(e, "env2048_step_sequence: join of the second chain");
