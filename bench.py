@@ -265,6 +265,26 @@ def load_step_profile(boards: int, leg: str):
         return None
 
 
+def load_kernel_stats(leg: str):
+    """rocprofv3 --kernel-trace --stats of the step kernel in the committed profile of this leg (profiles/step_pmc.json ->
+    'kernel_stats', written by tools/summarize_profiles.py), with what that average means; None when there is none."""
+    try:
+        table = json.loads((REPO / 'profiles' / 'step_pmc.json').read_text())
+        ks = dict(table['kernel_stats'][leg])
+    except Exception:
+        return None
+    ks['stale'] = table.get('kernel_source_sha') != kernel_source_sha()
+    ks['note'] = ('one chain: the profiler isolates the whole-batch kernels; their average is the launch duration itself and is what '
+                  'roofline.avg_launch_us of a one-chain run (K-step event time / K, which also holds the gaps between launches) has to '
+                  'agree with' if leg != 'resident' else
+                  'two half-batch chains: under the profiler every launch of the two enqueuing threads costs extra host time, the run '
+                  'becomes launch-bound (its own step period: bench_event_us_per_step_in_the_profiled_run) and the half-batch kernels '
+                  'mostly run alone -- their profiled average is the duration of a half-batch kernel with little overlap, NOT the step '
+                  'period of the timed run (avg_launch_us, two kernels in flight).  The like-for-like check of event time against '
+                  'rocprofv3 is the one-chain pair: step_pmc.json kernel_stats.resident_one_chain vs a --single-chain (or K < 32) run')
+    return ks
+
+
 def valu_ceiling(waves_per_simd: int = 4):
     """(G wave-instructions/s, source text, sustained rate of the real instruction stream or None) of the measured VALU ceiling
     for the step kernel's mix."""
@@ -306,9 +326,7 @@ def build_roofline(args, lib, n: int, flags: int, launch_s: float, obs_bytes: in
         'traffic_kind': 'fabric bytes per launch (2*FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes): L2 <-> Infinity '
                         'Cache/HBM requests -- Infinity-Cache hits are counted, so this is HBM traffic only for the cold leg',
         'traffic_source': None if prof is None else dict(source=prof.get('source'), stale=prof['stale']),
-        'rocprof_kernel_stats': ('profiles/r03_t_resident_kernel_stats.csv (two half-batch chains: 16 200 launches of 2^19 boards, average 6.48 us each, two in '
-                                 'flight)' if plan['chains'] == 2 else
-                                 'profiles/r03_k_resident_kernel_stats.csv (one chain: 10 100 launches of 2^20 boards, average 7.81 us, isolated by the profiler)'),
+        'rocprof_kernel_stats': load_kernel_stats('resident' if plan['chains'] == 2 else 'resident_one_chain'),
     }
     if resident and prof is not None and prof.get('valu_insts_per_launch'):
         ginstr = prof['valu_insts_per_launch'] / launch_s / 1e9

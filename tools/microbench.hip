@@ -402,6 +402,20 @@ int main(int argc, char **argv)
                 exit(2);
             }
         });
+        typedef int (*many_fn_t)(int, void *, uint64_t, const env2048_step_args *);
+        many_fn_t many = (many_fn_t)dlsym(h, "env2048_step_many");
+        std::string mname = std::string("EXP step_many ") + argv[ai];
+        if (many && sets > 1)
+            run(mname.c_str(), [=](int t) {  // the experiment build's shared launch over ALL sets, once every `sets` launches
+                if (t % sets) return;
+                std::vector<env2048_step_args> recs(sets);
+                for (int k = 0; k < sets; ++k)
+                    recs[k] = env2048_step_args{n, (uint64_t)k * n, (uint8_t *)B(k), A(k), R(k), D(k), nullptr, nullptr, 0x2048, (uint64_t)t, 1, 0, nullptr, nullptr};
+                if (many(0, s, sets, recs.data())) {
+                    fprintf(stderr, "env2048_step_many failed: %s\n", err());
+                    exit(2);
+                }
+            });
         run(name.c_str(), [=](int t) {
             static const uint32_t exp_flags = getenv("MB_FLAGS") ? (uint32_t)atoi(getenv("MB_FLAGS")) : 1u;  // e.g. 33 = AUTO_RESET | STORES_WRITE_BACK
             int rc = fn(0, s, n, 0, (uint8_t *)B(t), A(t), R(t), D(t), nullptr, nullptr, 0x2048, t, exp_flags);

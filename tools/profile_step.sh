@@ -16,6 +16,8 @@ COLD="python3 $R/bench.py --no-cpu-baseline --only-cold"
 # kernel stats over the SAME step counts as the default bench run, so that the averages are comparable
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_resident -- $RES > $O/stats_resident.json 2> $O/stats_resident.err
 echo "stats resident rc=$?"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_resident_one -- $RES --single-chain > $O/stats_resident_one.json 2> $O/stats_resident_one.err
+echo "stats resident (one chain) rc=$?"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cold -- $COLD > $O/stats_cold.json 2> $O/stats_cold.err
 echo "stats cold rc=$?"
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU" "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE"; do

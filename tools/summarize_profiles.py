@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Turn gpurun_out/<tag>/ (written by tools/profile_step.sh) into the committed profiles/ files:
-    profiles/<label>_{resident,cold}_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the bench command
+    profiles/<label>_{resident,resident_one_chain,cold}_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the bench command
+                                                        (default plan = two half-batch chains; --single-chain; the cold leg)
     profiles/<label>_pmc_summary.json                   counter means per 2^20-board record: resident step launches, the shared cold launch
                                                         (step_many_kernel, 30 records per launch) and the same cold records as separate launches
     (tools/profile_step.sh adds <label>_bench_default.json / _bench_driver_shape.json next to them)
@@ -26,7 +27,8 @@ BOARDS = 1 << 20
 # leg -> (rocprof run it comes from, kernel): the --only-cold run holds BOTH cold forms.  Every figure is scaled to ONE 2^20-board
 # step (record): a launch's share is boards-per-launch / 2^20, read off its grid size (512-thread blocks of 2048 boards: 4 boards
 # per work-item) -- 1/30 of a shared cold launch, and TWO launches per step where env2048_step_sequence runs two half-batch chains.
-LEGS = {'resident': ('resident', KERNEL), 'cold': ('cold', SHARED), 'cold_separate': ('cold', KERNEL)}
+LEGS = {'resident': ('resident', KERNEL), 'resident_one_chain': ('resident_one', KERNEL), 'cold': ('cold', SHARED),
+        'cold_separate': ('cold', KERNEL)}  # resident_one_chain: kernel stats only (bench.py --single-chain: whole-batch launches)
 
 
 def leg_counters(src: Path, leg: str):
@@ -63,7 +65,7 @@ def main(tag, label, dest=None):
     summary = {'kernel': KERNEL, 'boards_per_launch': BOARDS, 'kernel_source_sha': bench.kernel_source_sha(),
                'algorithmic_bytes_per_launch': 38 * BOARDS, 'legs': {}}
     table_path = dst / 'step_pmc.json'
-    table = {'kernel_source_sha': bench.kernel_source_sha(), 'entries': {},
+    table = {'kernel_source_sha': bench.kernel_source_sha(), 'entries': {}, 'kernel_stats': {},
              'formula': 'fabric bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB from separate rocprofv3 --pmc passes (gfx950: FETCH_SIZE counts '
                         'wide coalesced reads at half their bytes; MI355X_MICROARCH.md, HBM section); counts Infinity-Cache hits'}
     for leg in LEGS:
@@ -75,6 +77,15 @@ def main(tag, label, dest=None):
             if leg != 'cold_separate':
                 shutil.copy(stats[0], dst / f'{label}_{leg}_kernel_stats.csv')
             entry['rocprof_kernel_stats'] = kernel_avg_us(Path(stats[0]), leg, boards_per_launch)
+            if entry['rocprof_kernel_stats'] is not None:
+                ks = dict(entry['rocprof_kernel_stats'], source=f'profiles/{label}_{leg}_kernel_stats.csv' if leg != 'cold_separate'
+                          else f'profiles/{label}_cold_kernel_stats.csv')
+                try:  # the step period bench.py itself measured in that PROFILED run (the profiler slows the enqueuing threads down)
+                    line = (src / f'stats_{LEGS[leg][0]}.json').read_text().strip().splitlines()[-1]
+                    ks['bench_event_us_per_step_in_the_profiled_run'] = json.loads(line)['timing']['event_us_per_step']['median']
+                except Exception:
+                    pass
+                table['kernel_stats'][leg] = ks
         entry['counters'] = counters
         if 'FETCH_SIZE' in counters and 'WRITE_SIZE' in counters:
             fetch = counters['FETCH_SIZE']['mean'] * 1024 * 2
