@@ -104,13 +104,16 @@ def batched_reset(keys) -> GameState:
     the legal mask of the fresh boards are written by the same launch and kept with the state (see batched_get_observation)."""
     rt = runtime.current()
     kptr, n, keep = _keys_ptr(keys, rt)
-    rs = pool.acquire(n, rt.device)
     dev, stream = rt.handles()
-    p = rs.ptr
-    rt.lib.reset_keyed_i32_status(dev, stream, n, kptr, p['board'], p['obs'], p['legal'])
-    rs.zero_region.zero_()  # step_count, total_reward, done (adjacent in the set: one fill)
-    rs.versions = tuple(t._version for t in rs.tensors)
-    return GameState(board=rs.board, step_count=rs.step_count, done=rs.done, total_reward=rs.total)
+    rs = pool.acquire(n, rt.device, stream or 0)
+    try:
+        p = rs.ptr
+        rt.lib.reset_keyed_i32_status(dev, stream, n, kptr, p['board'], p['obs'], p['legal'])
+        rs.zero_region.zero_()  # step_count, total_reward, done (adjacent in the set: one fill)
+        rs.mark_written()
+        return GameState(board=rs.board, step_count=rs.step_count, done=rs.done, total_reward=rs.total)
+    finally:
+        rs.leased = False  # (the state being returned holds the tensors by now; after an error nobody does and the set is free)
 
 
 def _dev(x, dtype, n, rt) -> torch.Tensor:
@@ -139,14 +142,18 @@ def batched_step(states: GameState, actions, keys):
     if nk != n:
         raise ValueError(f'batched_step: {n} environments but {nk} keys')
     aptr, keep_actions = _actions_ptr(actions, n, rt)
-    rs = pool.acquire(n, rt.device)  # (never the set the input state lives in: the caller still holds that one)
-    p = rs.ptr
     dev, stream = rt.handles()
-    rt.lib.step_state_i32_keyed_status(dev, stream, n, kptr, b_in, p['board'], aptr, s_in, p['step_count'], d_in, p['done'], t_in,
-                                       p['total'], p['reward'], p['max_tile'], p['obs'], p['legal'])
-    new_state = GameState(board=rs.board, step_count=rs.step_count, done=rs.done, total_reward=rs.total)
-    info = {'max_tile': rs.max_tile, 'step_count': rs.step_count, 'total_reward': rs.total}
-    return new_state, rs.reward, rs.done, info
+    rs = pool.acquire(n, rt.device, stream or 0)  # (never the set the input state lives in: the caller still holds that one)
+    try:
+        p = rs.ptr
+        rt.lib.step_state_i32_keyed_status(dev, stream, n, kptr, b_in, p['board'], aptr, s_in, p['step_count'], d_in, p['done'], t_in,
+                                           p['total'], p['reward'], p['max_tile'], p['obs'], p['legal'])
+        rs.mark_written()
+        new_state = GameState(board=rs.board, step_count=rs.step_count, done=rs.done, total_reward=rs.total)
+        info = {'max_tile': rs.max_tile, 'step_count': rs.step_count, 'total_reward': rs.total}
+        return new_state, rs.reward, rs.done, info
+    finally:
+        rs.leased = False
 
 
 def _stashed(states: GameState, field: str):

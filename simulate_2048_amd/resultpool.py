@@ -35,7 +35,7 @@ from .interop import DeviceArray
 _use_count = getattr(torch._C, '_storage_Use_Count', None)  # references to a StorageImpl (tensors, views, wrappers)
 
 MAX_SETS_PER_KEY = 6
-MAX_KEYS = 16  # distinct (n, device) shapes kept; the least recently used shape's sets are dropped beyond that
+MAX_KEYS = 16  # distinct (n, device, stream) keys kept; the least recently used shape's sets are dropped beyond that
 STAGE_MAX_BYTES = 16 << 10  # larger host arrays take an ordinary H2D copy (the kernel would read them across the bus)
 
 
@@ -45,7 +45,7 @@ def _align(x: int, a: int = 16) -> int:
 
 class ResultSet:
     __slots__ = ('n', 'arena', 'storage', 'cdata', 'board', 'obs', 'step_count', 'max_tile', 'total', 'reward', 'legal', 'done',
-                 'tensors', 'ptr', 'idle_refs', 'idle_use', 'versions', 'zero_region', 'pooled')
+                 'tensors', 'ptr', 'idle_refs', 'idle_use', 'version', 'zero_region', 'pooled', 'leased')
 
     def __init__(self, n: int, device: torch.device):
         self.n = n
@@ -78,16 +78,17 @@ class ResultSet:
         self.zero_region = arena[z0:z1]
         self.tensors = (self.board, self.obs, self.step_count, self.total, self.done, self.max_tile, self.reward, self.legal)
         self.ptr = {name: base + offsets[name] for name, _ in sizes}
-        self.versions = tuple(t._version for t in self.tensors)
+        self.version = arena._version  # ONE counter: the carved tensors are views of the arena and share its version counter
         ts = self.tensors  # (measured exactly the way idle() measures: indexing adds no reference, a loop variable would)
         self.idle_refs = (sys.getrefcount(ts[0]), sys.getrefcount(ts[1]), sys.getrefcount(ts[2]), sys.getrefcount(ts[3]),
                           sys.getrefcount(ts[4]), sys.getrefcount(ts[5]), sys.getrefcount(ts[6]), sys.getrefcount(ts[7]))
         self.idle_use = _use_count(self.cdata) if _use_count else -1
         self.pooled = False
+        self.leased = False  # set by ResultPool.acquire, cleared by the mirror once the caller-facing references exist
 
     def idle(self) -> bool:
-        """Nobody but this set references its tensors or their memory."""
-        if _use_count is None or _use_count(self.cdata) != self.idle_use:
+        """Nobody but this set references its tensors or their memory, and no other thread is between acquire() and its return."""
+        if self.leased or _use_count is None or _use_count(self.cdata) != self.idle_use:
             return False
         refs = self.idle_refs
         ts = self.tensors
@@ -95,14 +96,22 @@ class ResultSet:
                 and sys.getrefcount(ts[3]) == refs[3] and sys.getrefcount(ts[4]) == refs[4] and sys.getrefcount(ts[5]) == refs[5]
                 and sys.getrefcount(ts[6]) == refs[6] and sys.getrefcount(ts[7]) == refs[7])
 
+    def mark_written(self) -> None:
+        """A launch has just been given this set to fill: the stash is valid from the current version on."""
+        self.version = self.arena._version
+
     def stash_valid(self) -> bool:
-        """board, obs and legal are as the kernel wrote them (no in-place torch operation touched them since)."""
-        v = self.versions
-        return self.board._version == v[0] and self.obs._version == v[1] and self.legal._version == v[7]
+        """The set is as the kernel wrote it: no in-place torch operation touched any of its tensors since (they share the
+        arena's version counter, so an edit of ANY field -- say ``state.step_count += 1`` -- drops the stash: conservative).
+        Writes torch cannot see (through a DLPack alias held by another framework) are the caller's responsibility."""
+        return self.arena._version == self.version
 
 
 class ResultPool:
-    """Per (n, device) a few ResultSets; ``acquire`` returns an idle one or a new one."""
+    """Per (n, device, stream) a few ResultSets; ``acquire`` returns an idle one or a new one, LEASED to the calling thread until
+    it clears ``leased`` (another thread's acquire() must not pick the same set before the first caller holds its tensors).
+    The stream is part of the key for the caching allocator's reason: reuse is ordered behind the previous use only on the
+    stream that previous use was enqueued on."""
 
     def __init__(self):
         self._sets: dict = {}
@@ -110,8 +119,8 @@ class ResultPool:
         self.registry: dict = {}  # id(tensor) -> (ResultSet, field name); only tensors of POOLED sets (kept alive by the pool)
         self.created = 0  # sets ever created (tests read it)
 
-    def acquire(self, n: int, device: torch.device) -> ResultSet:
-        key = (n, device)
+    def acquire(self, n: int, device: torch.device, stream: int = 0) -> ResultSet:
+        key = (n, device, stream)
         with self._lock:
             sets = self._sets.pop(key, None)  # (re-inserted below: dict order = recency of use)
             if sets is None:
@@ -125,8 +134,10 @@ class ResultPool:
             self._sets[key] = sets
             for rs in sets:
                 if rs.idle():
+                    rs.leased = True
                     return rs
             rs = ResultSet(n, device)
+            rs.leased = True
             self.created += 1
             if len(sets) < MAX_SETS_PER_KEY and _use_count is not None:
                 sets.append(rs)

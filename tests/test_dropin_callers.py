@@ -341,3 +341,57 @@ def test_result_pool_forgets_old_shapes(api_runtime):
     assert np.array_equal(np.array(obs), oracle.status_batch(oracle.pack_values(kept_board.reshape(3, 16)).reshape(3, 16))['obs'])
     again, *_ = batched_step(kept, np.zeros(3, dtype=np.int32), _loop_keys(rng, 3))
     assert np.array(again.board).shape == (3, 4, 4)
+
+
+def test_stash_comes_back_when_an_edited_set_is_reused(api_runtime):
+    """An in-place edit drops the stash of THAT state only: once the set is handed out again its launch re-validates it
+    (a set whose stash stayed invalid for ever would cost two status launches per move from then on)."""
+    n = 4
+    rng = np.random.default_rng(21)
+    resultpool.pool.clear()
+    states = batched_reset(_loop_keys(rng, n))
+    states.step_count.add_(0)  # a caller's own bookkeeping on a field: the whole set shares one version counter
+    assert resultpool.pool.lookup(states.board)[0].stash_valid() is False
+    calls = getattr(api_runtime.lib, 'calls', None)
+    for move in range(12):
+        states, *_ = batched_step(states, np.full(n, move & 3, dtype=np.int32), _loop_keys(rng, n))
+    mark = len(calls) if calls is not None else 0
+    for move in range(12):  # every set of the pool has been rewritten by now, the edited one included
+        assert resultpool.pool.lookup(states.board)[0].stash_valid()
+        batched_get_observation(states), batched_get_legal_actions(states)
+        states, *_ = batched_step(states, np.full(n, move & 3, dtype=np.int32), _loop_keys(rng, n))
+    if calls is not None:
+        assert [c[0] for c in calls[mark:]].count('status_i32') == 0
+
+
+def test_acquire_leases_a_set_to_one_thread_at_a_time():
+    """Two threads calling the mirrors concurrently never get the same idle set: a set is leased from acquire() until the
+    mirror has built the state it returns; and sets are kept per stream (reuse is only ordered on the stream of the last use)."""
+    p = resultpool.ResultPool()
+    dev = torch.device('cpu')
+    a = p.acquire(5, dev, 0)
+    b = p.acquire(5, dev, 0)  # `a` is idle by reference counts (nobody holds its tensors yet) but leased
+    assert a is not b and a.leased and b.leased and not a.idle()
+    a.leased = False
+    assert p.acquire(5, dev, 0) is a  # released without anybody holding it: free again
+    a.leased = False
+    other_stream = p.acquire(5, dev, 1234)
+    assert other_stream is not a and other_stream is not b
+    import threading
+
+    got, barrier = [], threading.Barrier(4)
+
+    def worker():
+        barrier.wait()
+        for _ in range(200):
+            rs = p.acquire(7, dev, 0)
+            got.append(id(rs))
+            held = rs.board  # what the mirror does: take a reference, then end the lease
+            assert rs.leased
+            rs.leased = False
+            del held
+
+    threads = [threading.Thread(target=worker) for _ in range(4)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert len(got) == 800
