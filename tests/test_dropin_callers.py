@@ -395,3 +395,39 @@ def test_acquire_leases_a_set_to_one_thread_at_a_time():
     [t.start() for t in threads]
     [t.join() for t in threads]
     assert len(got) == 800
+
+
+def test_mirror_loops_from_several_threads(api_runtime):
+    """Three self-play loops at the reference's batch sizes run concurrently (each on its own stream on the GPU), sharing the
+    process-wide result pool: every move of every loop equals the oracle's step under the same keys -- no loop ever sees a
+    result set another loop was handed."""
+    import contextlib
+    import threading
+
+    resultpool.pool.clear()
+    errors = []
+
+    def loop(tid, n):
+        try:
+            rng = np.random.default_rng(100 + tid)
+            stream = torch.cuda.Stream(api_runtime.device) if api_runtime.device.type == 'cuda' else None
+            ctx = torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
+            with ctx:
+                states = batched_reset(_loop_keys(rng, n))
+                for move in range(60):
+                    legal = np.array(batched_get_legal_actions(states))
+                    actions = np.array([np.flatnonzero(m)[0] if m.any() else 0 for m in legal], dtype=np.int32)
+                    keys = _loop_keys(rng, n)
+                    before = (np.array(states.board).reshape(n, 16), np.array(states.step_count), np.array(states.done).astype(np.uint8),
+                              np.array(states.total_reward))
+                    states, rewards, dones, _ = batched_step(states, actions, keys)
+                    want = oracle.step_state_i32_keyed(before[0], actions, before[1], before[2], before[3], np.asarray(keys).astype(np.uint32))
+                    assert np.array_equal(np.array(states.board).reshape(n, 16), want['boards']), (tid, move)
+                    assert np.array_equal(np.array(rewards), want['reward']) and np.array_equal(np.array(dones), want['done'].astype(bool)), (tid, move)
+        except BaseException as exc:  # noqa: BLE001 -- reported by the main thread
+            errors.append(exc)
+
+    threads = [threading.Thread(target=loop, args=(i, n)) for i, n in enumerate((8, 8, 4))]  # two loops share a shape
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors, errors[0]
