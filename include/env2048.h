@@ -290,6 +290,30 @@ ENV2048_EXPORT int env2048_reset_keyed_i32_status(int device, void *stream, uint
                                                   uint8_t *legal4);
 
 /*
+ * The same two calls with a HOST MIRROR of the results, for callers that read every state back (the reference's loop does:
+ * np.array(observations), np.array(legal_masks), np.array(rewards), np.array(dones), reinforce/training/self_play.py:346-356).
+ * The caller keeps ALL output arrays of a call in one block of device memory and owns a block of pinned, device-accessible
+ * host memory of the same layout; host_mirror_delta = (host block address) - (device block address), a multiple of 16.
+ * Every output element the kernel writes at address p it also writes at p + host_mirror_delta, so once the launch has
+ * completed (one stream synchronisation) the host block holds the results: no device-to-host copy, no second
+ * synchronisation per array.  A few hundred bytes cross the bus at the reference's batch sizes (N = 2 ... 8); meant for
+ * small batches.  host_mirror_delta = 0: no mirror (then identical to the _status forms).
+ * env2048_reset_state_i32_keyed also writes the bookkeeping fields of a fresh GameState (step_count 0, done 0,
+ * total_reward 0.0; each pointer may be NULL) so that a reset is ONE launch and lands in the mirror whole.
+ * env2048_step_state_i32_keyed_mirrored requires the out-of-place form (boards_in != boards_out).
+ * [replaces: batched_reset / batched_step + the caller's np.array(...) read-backs, reinforce/game/env.py:176-211,
+ *  reinforce/training/self_play.py:298-300,346-356]
+ */
+ENV2048_EXPORT int env2048_reset_state_i32_keyed(int device, void *stream, uint64_t n, const uint32_t *keys, int32_t *boards,
+                                                 int32_t *step_count, uint8_t *done, float *total_reward, float *obs, uint8_t *legal4,
+                                                 int64_t host_mirror_delta);
+ENV2048_EXPORT int env2048_step_state_i32_keyed_mirrored(int device, void *stream, uint64_t n, const uint32_t *keys, const int32_t *boards_in,
+                                                         int32_t *boards_out, const int32_t *actions, const int32_t *step_count_in,
+                                                         int32_t *step_count_out, const uint8_t *done_in, uint8_t *done_out,
+                                                         const float *total_reward_in, float *total_reward_out, float *reward,
+                                                         int32_t *max_tile, float *obs, uint8_t *legal4, int64_t host_mirror_delta);
+
+/*
  * Per-move queries of the reinforce/game callers on int32 tile VALUE boards (n x 16), one launch, each
  * output optional:
  *     obs[16*i..]    float32 log2(tile)/16, 0 for empty      (encode_observation, core.py:346-377)

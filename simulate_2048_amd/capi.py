@@ -85,6 +85,9 @@ PROTOTYPES = {
     'env2048_step_state_i32_keyed_status': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
                                                       _ptr, _ptr, _ptr, _ptr]),
     'env2048_reset_keyed_i32_status': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr]),
+    'env2048_reset_state_i32_keyed': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, ctypes.c_int64]),
+    'env2048_step_state_i32_keyed_mirrored': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
+                                                        _ptr, _ptr, _ptr, _ptr, ctypes.c_int64]),
     'env2048_status_i32': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr]),
     'env2048_rollout': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _u64, _u64, _u32, _ptr, _ptr, _ptr, _u32]),
     'env2048_replay': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _ptr, _ptr, _ptr, _u64, _u64, _u64, _u32, _u32, _ptr, _ptr, _ptr]),
@@ -227,6 +230,16 @@ class Library:
 
     def reset_keyed_i32_status(self, device, stream, n, keys, boards, obs, legal4) -> None:
         self._check(self._dll.env2048_reset_keyed_i32_status(device, stream, n, keys, boards, obs, legal4))
+
+    def reset_state_i32_keyed(self, device, stream, n, keys, boards, step_count, done, total, obs, legal4, host_mirror_delta=0) -> None:
+        self._check(self._dll.env2048_reset_state_i32_keyed(device, stream, n, keys, boards, step_count, done, total, obs, legal4,
+                                                            host_mirror_delta))
+
+    def step_state_i32_keyed_mirrored(self, device, stream, n, keys, boards_in, boards_out, actions, step_count_in, step_count_out,
+                                      done_in, done_out, total_in, total_out, reward, max_tile, obs, legal4, host_mirror_delta=0) -> None:
+        self._check(self._dll.env2048_step_state_i32_keyed_mirrored(device, stream, n, keys, boards_in, boards_out, actions,
+                                                                    step_count_in, step_count_out, done_in, done_out, total_in,
+                                                                    total_out, reward, max_tile, obs, legal4, host_mirror_delta))
 
     def random_actions(self, device, stream, n, env_base, seed, step_index, actions) -> None:
         self._check(self._dll.env2048_random_actions(device, stream, n, env_base, seed, step_index, actions))

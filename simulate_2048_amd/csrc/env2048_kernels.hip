@@ -970,10 +970,16 @@ __global__ __launch_bounds__(BLOCK) void step_state_i32_kernel(uint64_t n, uint6
                                                                const uint8_t *done_in, uint8_t *done_out,
                                                                const float *total_in, float *total_out, float *reward_out,
                                                                int32_t *max_tile, RngKey key, const uint2 *keys, float *obs_out,
-                                                               uint32_t *legal4_out)
+                                                               uint32_t *legal4_out, int64_t mirror)
 {
     const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
+    // `mirror` != 0: every output element is ALSO written `mirror` bytes further on -- the caller's pinned-host copy of its
+    // result block (a few hundred bytes at the reference's batch sizes), so that reading the results back needs no copy
+    auto put = [mirror](auto *p, auto v) {
+        *p = v;
+        if (mirror) *reinterpret_cast<decltype(p)>(reinterpret_cast<char *>(p) + mirror) = v;
+    };
     const int4 *rows_in = reinterpret_cast<const int4 *>(boards_in) + 4 * i;
     int4 *rows_out = reinterpret_cast<int4 *>(boards_out) + 4 * i;
     const int4 v0 = rows_in[0], v1 = rows_in[1], v2 = rows_in[2], v3 = rows_in[3];
@@ -1002,10 +1008,10 @@ __global__ __launch_bounds__(BLOCK) void step_state_i32_kernel(uint64_t n, uint6
         afterstate(bd, (uint32_t)actions[i] & 3u, score, changed);
         spawn_tile_word(bd, word, changed);
         reward = (float)score;  // exact: a step's score is < 2^24
-        rows_out[0] = unpack4(bd.r0);
-        rows_out[1] = unpack4(bd.r1);
-        rows_out[2] = unpack4(bd.r2);
-        rows_out[3] = unpack4(bd.r3);
+        put(rows_out + 0, unpack4(bd.r0));
+        put(rows_out + 1, unpack4(bd.r1));
+        put(rows_out + 2, unpack4(bd.r2));
+        put(rows_out + 3, unpack4(bd.r3));
         legal_bits = legal_mask(bd);
         done = legal_bits == 0u ? 1 : 0;
         steps += 1;
@@ -1015,20 +1021,23 @@ __global__ __launch_bounds__(BLOCK) void step_state_i32_kernel(uint64_t n, uint6
     }
     // what the caller asks about the NEW state right after a move (reinforce/training/self_play.py:316-317), in the same
     // launch: observation and (N, 4) legal bytes of the board this step leaves behind -- a finished game's unchanged board
-    if (obs_out) store_obs(obs_out, i, bd);
-    if (legal4_out) legal4_out[i] = (legal_bits & 1u) | ((legal_bits & 2u) << 7) | ((legal_bits & 4u) << 14) | ((legal_bits & 8u) << 21);
+    if (obs_out) {
+        store_obs(obs_out, i, bd);
+        if (mirror) store_obs(reinterpret_cast<float *>(reinterpret_cast<char *>(obs_out) + mirror), i, bd);
+    }
+    if (legal4_out) put(legal4_out + i, (legal_bits & 1u) | ((legal_bits & 2u) << 7) | ((legal_bits & 4u) << 14) | ((legal_bits & 8u) << 21));
     if (was_done && !in_place) {  // the values as they came in (not re-derived from the packed form)
-        rows_out[0] = v0;
-        rows_out[1] = v1;
-        rows_out[2] = v2;
-        rows_out[3] = v3;
+        put(rows_out + 0, v0);
+        put(rows_out + 1, v1);
+        put(rows_out + 2, v2);
+        put(rows_out + 3, v3);
     }
     if (!was_done || !in_place) {
-        done_out[i] = done;
-        if (step_count_out) step_count_out[i] = steps;
-        if (total_out) total_out[i] = total;
+        put(done_out + i, done);
+        if (step_count_out) put(step_count_out + i, steps);
+        if (total_out) put(total_out + i, total);
     }
-    reward_out[i] = reward;
+    put(reward_out + i, reward);
     if (max_tile) {
         const uint32_t rws[4] = {bd.r0, bd.r1, bd.r2, bd.r3};
         uint32_t m = 0;
@@ -1039,31 +1048,43 @@ __global__ __launch_bounds__(BLOCK) void step_state_i32_kernel(uint64_t n, uint6
             m = max(m, (rws[r] >> 16) & 0xFFu);
             m = max(m, rws[r] >> 24);
         }
-        max_tile[i] = m ? (int32_t)(1u << (m & 31u)) : 0;
+        put(max_tile + i, m ? (int32_t)(1u << (m & 31u)) : 0);
     }
 }
 
 // batched_reset with one PRNG key per environment, straight to int32 value boards: board i = the fresh board of
 // environment 0 at step 0 of the stream seeded with keys[i] (= create_initial_board(keys[i])).
+// step_count / done / total (each may be NULL): the bookkeeping fields of a fresh GameState, written as zeros.
 __global__ __launch_bounds__(BLOCK) void reset_keyed_i32_kernel(uint64_t n, const uint2 *keys, int32_t *boards, float *obs_out,
-                                                                uint32_t *legal4_out)
+                                                                uint32_t *legal4_out, int32_t *step_count, uint8_t *done, float *total,
+                                                                int64_t mirror)
 {
     const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
+    auto put = [mirror](auto *p, auto v) {  // (see step_state_i32_kernel)
+        *p = v;
+        if (mirror) *reinterpret_cast<decltype(p)>(reinterpret_cast<char *>(p) + mirror) = v;
+    };
     const uint2 k = keys[i];
     uint32_t w0, w1, w2, w3;
     env_block(RngKey{k.y, k.x, 0u, 0u}, 0u, STREAM_RESET, w0, w1, w2, w3);
     const Board bd = fresh_board(w0, w1, w2, w3);
     int4 *rows = reinterpret_cast<int4 *>(boards) + 4 * i;
-    rows[0] = unpack4(bd.r0);
-    rows[1] = unpack4(bd.r1);
-    rows[2] = unpack4(bd.r2);
-    rows[3] = unpack4(bd.r3);
-    if (obs_out) store_obs(obs_out, i, bd);
+    put(rows + 0, unpack4(bd.r0));
+    put(rows + 1, unpack4(bd.r1));
+    put(rows + 2, unpack4(bd.r2));
+    put(rows + 3, unpack4(bd.r3));
+    if (obs_out) {
+        store_obs(obs_out, i, bd);
+        if (mirror) store_obs(reinterpret_cast<float *>(reinterpret_cast<char *>(obs_out) + mirror), i, bd);
+    }
     if (legal4_out) {
         const uint32_t bits = legal_mask(bd);
-        legal4_out[i] = (bits & 1u) | ((bits & 2u) << 7) | ((bits & 4u) << 14) | ((bits & 8u) << 21);
+        put(legal4_out + i, (bits & 1u) | ((bits & 2u) << 7) | ((bits & 4u) << 14) | ((bits & 8u) << 21));
     }
+    if (step_count) put(step_count + i, (int32_t)0);
+    if (done) put(done + i, (uint8_t)0);
+    if (total) put(total + i, 0.0f);
 }
 
 // What the reinforce/game callers ask about a batch of int32 value boards, in one launch: the f32
@@ -2379,10 +2400,13 @@ static int step_state_i32_common(const char *who, int device, void *stream, uint
                                  const int32_t *boards_in, int32_t *boards_out, const int32_t *actions, const int32_t *step_count_in,
                                  int32_t *step_count_out, const uint8_t *done_in, uint8_t *done_out, const float *total_reward_in,
                                  float *total_reward_out, float *reward, int32_t *max_tile, uint64_t seed, uint64_t step_index,
-                                 float *obs_out = nullptr, uint8_t *legal4_out = nullptr)
+                                 float *obs_out = nullptr, uint8_t *legal4_out = nullptr, int64_t host_mirror_delta = 0)
 {
     if (n == 0) return ENV2048_OK;
     if (misaligned(obs_out, 16) || misaligned(legal4_out, 4)) return fail(ENV2048_ERR_ALIGNMENT, "%s: obs must be 16-byte, legal4 4-byte aligned", who);
+    if (host_mirror_delta & 15) return fail(ENV2048_ERR_ALIGNMENT, "%s: host_mirror_delta must be a multiple of 16 bytes", who);
+    if (host_mirror_delta && boards_in == boards_out)
+        return fail(ENV2048_ERR_INVALID_ARG, "%s: a host mirror goes with the out-of-place form (outputs in one block of their own)", who);
     if (!boards_in || !boards_out || !actions || !done_in || !done_out || !reward)
         return fail(ENV2048_ERR_INVALID_ARG, "%s: boards, actions, done and reward are required", who);
     if ((step_count_in == nullptr) != (step_count_out == nullptr) || (total_reward_in == nullptr) != (total_reward_out == nullptr))
@@ -2399,7 +2423,8 @@ static int step_state_i32_common(const char *who, int device, void *stream, uint
     const RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)step_index, (uint32_t)(step_index >> 32)};
     hipLaunchKernelGGL(step_state_i32_kernel, grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, n, env_base, boards_in, boards_out,
                        actions, step_count_in, step_count_out, done_in, done_out, total_reward_in, total_reward_out, reward,
-                       max_tile, key, reinterpret_cast<const uint2 *>(keys), obs_out, reinterpret_cast<uint32_t *>(legal4_out));
+                       max_tile, key, reinterpret_cast<const uint2 *>(keys), obs_out, reinterpret_cast<uint32_t *>(legal4_out),
+                       host_mirror_delta);
     return launched(who);
 }
 
@@ -2424,19 +2449,27 @@ int env2048_step_state_i32_keyed(int device, void *stream, uint64_t n, const uin
                                  0, 0);
 }
 
-int env2048_reset_keyed_i32_status(int device, void *stream, uint64_t n, const uint32_t *keys, int32_t *boards, float *obs,
-                                   uint8_t *legal4)
+int env2048_reset_state_i32_keyed(int device, void *stream, uint64_t n, const uint32_t *keys, int32_t *boards, int32_t *step_count,
+                                  uint8_t *done, float *total_reward, float *obs, uint8_t *legal4, int64_t host_mirror_delta)
 {
     if (n == 0) return ENV2048_OK;
     if (!keys || !boards) return fail(ENV2048_ERR_INVALID_ARG, "env2048_reset_keyed_i32: keys and boards are required");
-    if (misaligned(keys, 8) || misaligned(boards, 16) || misaligned(obs, 16) || misaligned(legal4, 4))
-        return fail(ENV2048_ERR_ALIGNMENT, "env2048_reset_keyed_i32: keys must be 8-byte, boards / obs 16-byte, legal4 4-byte aligned");
+    if (misaligned(keys, 8) || misaligned(boards, 16) || misaligned(obs, 16) || misaligned(legal4, 4) || misaligned(step_count, 4) ||
+        misaligned(total_reward, 4))
+        return fail(ENV2048_ERR_ALIGNMENT, "env2048_reset_keyed_i32: keys must be 8-byte, boards / obs 16-byte, the other arrays 4-byte aligned");
+    if (host_mirror_delta & 15) return fail(ENV2048_ERR_ALIGNMENT, "env2048_reset_state_i32_keyed: host_mirror_delta must be a multiple of 16 bytes");
     if (int rc = check_count(n)) return rc;
     DeviceScope scope(device);
     if (scope.rc) return scope.rc;
     hipLaunchKernelGGL(reset_keyed_i32_kernel, grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, n, reinterpret_cast<const uint2 *>(keys),
-                       boards, obs, reinterpret_cast<uint32_t *>(legal4));
+                       boards, obs, reinterpret_cast<uint32_t *>(legal4), step_count, done, total_reward, host_mirror_delta);
     return launched("env2048_reset_keyed_i32 launch");
+}
+
+int env2048_reset_keyed_i32_status(int device, void *stream, uint64_t n, const uint32_t *keys, int32_t *boards, float *obs,
+                                   uint8_t *legal4)
+{
+    return env2048_reset_state_i32_keyed(device, stream, n, keys, boards, nullptr, nullptr, nullptr, obs, legal4, 0);
 }
 
 int env2048_reset_keyed_i32(int device, void *stream, uint64_t n, const uint32_t *keys, int32_t *boards)
@@ -2453,6 +2486,18 @@ int env2048_step_state_i32_keyed_status(int device, void *stream, uint64_t n, co
     return step_state_i32_common("env2048_step_state_i32_keyed_status", device, stream, n, 0, keys, boards_in, boards_out, actions,
                                  step_count_in, step_count_out, done_in, done_out, total_reward_in, total_reward_out, reward, max_tile,
                                  0, 0, obs, legal4);
+}
+
+int env2048_step_state_i32_keyed_mirrored(int device, void *stream, uint64_t n, const uint32_t *keys, const int32_t *boards_in,
+                                          int32_t *boards_out, const int32_t *actions, const int32_t *step_count_in,
+                                          int32_t *step_count_out, const uint8_t *done_in, uint8_t *done_out, const float *total_reward_in,
+                                          float *total_reward_out, float *reward, int32_t *max_tile, float *obs, uint8_t *legal4,
+                                          int64_t host_mirror_delta)
+{
+    if (n && !keys) return fail(ENV2048_ERR_INVALID_ARG, "env2048_step_state_i32_keyed_mirrored: keys is NULL");
+    return step_state_i32_common("env2048_step_state_i32_keyed_mirrored", device, stream, n, 0, keys, boards_in, boards_out, actions,
+                                 step_count_in, step_count_out, done_in, done_out, total_reward_in, total_reward_out, reward, max_tile,
+                                 0, 0, obs, legal4, host_mirror_delta);
 }
 
 int env2048_step_state_i32(int device, void *stream, uint64_t n, uint64_t env_base, int32_t *boards, const int32_t *actions,

@@ -19,6 +19,18 @@ import numpy as np
 import torch
 
 
+_pool = None
+
+
+def _result_pool():
+    global _pool
+    if _pool is None:
+        from . import resultpool  # (imports this module for DeviceArray: resolved lazily)
+
+        _pool = resultpool.pool
+    return _pool
+
+
 class DeviceArray(torch.Tensor):
     """A torch tensor (usually on the GPU) that converts to NumPy on demand -- see the module docstring."""
 
@@ -33,6 +45,12 @@ class DeviceArray(torch.Tensor):
         return t if isinstance(t, DeviceArray) else t.as_subclass(DeviceArray)
 
     def __array__(self, dtype=None, copy=None):
+        if self.is_cuda:  # a field of a pooled result set of the reinforce.game mirrors: one copy per LAUNCH, not per array
+            hit = _result_pool().lookup(self)
+            if hit is not None:
+                host = hit[0].host_array(hit[1])
+                if host is not None:
+                    return host.astype(dtype) if dtype is not None and dtype != host.dtype else host.copy()
         plain = self.as_subclass(torch.Tensor).detach()
         if plain.dtype == torch.bfloat16:  # NumPy has no bfloat16: widen (exact)
             plain = plain.to(torch.float32)

@@ -100,7 +100,7 @@ def _state_ptrs(states: GameState, rt):
 
 def batched_reset(keys) -> GameState:
     """[ref env.py:176-190] fresh games, one per key row: keys (N, 2) -> GameState with leading N.
-    One launch (env2048_reset_keyed_i32_status); board i depends on keys[i] only (= reset(keys[i])).  The observation and
+    One launch (env2048_reset_state_i32_keyed); board i depends on keys[i] only (= reset(keys[i])).  The observation and
     the legal mask of the fresh boards are written by the same launch and kept with the state (see batched_get_observation)."""
     rt = runtime.current()
     kptr, n, keep = _keys_ptr(keys, rt)
@@ -108,9 +108,9 @@ def batched_reset(keys) -> GameState:
     rs = pool.acquire(n, rt.device, stream or 0)
     try:
         p = rs.ptr
-        rt.lib.reset_keyed_i32_status(dev, stream, n, kptr, p['board'], p['obs'], p['legal'])
-        rs.zero_region.zero_()  # step_count, total_reward, done (adjacent in the set: one fill)
-        rs.mark_written()
+        rt.lib.reset_state_i32_keyed(dev, stream, n, kptr, p['board'], p['step_count'], p['done'], p['total'], p['obs'], p['legal'],
+                                     rs.mirror_delta)
+        rs.mark_written(rs.mirror_delta != 0)
         return GameState(board=rs.board, step_count=rs.step_count, done=rs.done, total_reward=rs.total)
     finally:
         rs.leased = False  # (the state being returned holds the tensors by now; after an error nobody does and the set is free)
@@ -129,7 +129,7 @@ def _dev(x, dtype, n, rt) -> torch.Tensor:
 def batched_step(states: GameState, actions, keys):
     """[ref env.py:193-211] one move per environment -> (GameState, reward (N,) f32, done (N,) bool, info).
 
-    ONE fused, out-of-place kernel (env2048_step_state_i32_keyed_status): the input state is only read (functional API), the
+    ONE fused, out-of-place kernel (env2048_step_state_i32_keyed_mirrored): the input state is only read (functional API), the
     new state, reward, done, max_tile AND the observation / legal mask of the new state are written by the same launch into a
     result set that is reused once the caller has let go of it (``resultpool``) -- a move of the reference's self-play loop
     (self_play.py:316-317,354: observation, legal mask, step) is one launch and creates no tensor.  Finished games are frozen
@@ -146,9 +146,9 @@ def batched_step(states: GameState, actions, keys):
     rs = pool.acquire(n, rt.device, stream or 0)  # (never the set the input state lives in: the caller still holds that one)
     try:
         p = rs.ptr
-        rt.lib.step_state_i32_keyed_status(dev, stream, n, kptr, b_in, p['board'], aptr, s_in, p['step_count'], d_in, p['done'], t_in,
-                                           p['total'], p['reward'], p['max_tile'], p['obs'], p['legal'])
-        rs.mark_written()
+        rt.lib.step_state_i32_keyed_mirrored(dev, stream, n, kptr, b_in, p['board'], aptr, s_in, p['step_count'], d_in, p['done'], t_in,
+                                             p['total'], p['reward'], p['max_tile'], p['obs'], p['legal'], rs.mirror_delta)
+        rs.mark_written(rs.mirror_delta != 0)
         new_state = GameState(board=rs.board, step_count=rs.step_count, done=rs.done, total_reward=rs.total)
         info = {'max_tile': rs.max_tile, 'step_count': rs.step_count, 'total_reward': rs.total}
         return new_state, rs.reward, rs.done, info

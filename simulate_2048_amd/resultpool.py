@@ -37,6 +37,7 @@ _use_count = getattr(torch._C, '_storage_Use_Count', None)  # references to a St
 MAX_SETS_PER_KEY = 6
 MAX_KEYS = 16  # distinct (n, device, stream) keys kept; the least recently used shape's sets are dropped beyond that
 STAGE_MAX_BYTES = 16 << 10  # larger host arrays take an ordinary H2D copy (the kernel would read them across the bus)
+MIRROR_MAX_BYTES = 64 << 10  # result sets up to this size (N <= ~430) are read back through one pinned host mirror per launch
 
 
 def _align(x: int, a: int = 16) -> int:
@@ -45,7 +46,8 @@ def _align(x: int, a: int = 16) -> int:
 
 class ResultSet:
     __slots__ = ('n', 'arena', 'storage', 'cdata', 'board', 'obs', 'step_count', 'max_tile', 'total', 'reward', 'legal', 'done',
-                 'tensors', 'ptr', 'idle_refs', 'idle_use', 'version', 'zero_region', 'pooled', 'leased')
+                 'tensors', 'ptr', 'idle_refs', 'idle_use', 'version', 'pooled', 'leased', 'layout', 'serial',
+                 'mirror', 'mirror_fields', 'mirror_key', 'mirror_copies', 'mirror_delta', 'direct_serial')
 
     def __init__(self, n: int, device: torch.device):
         self.n = n
@@ -73,9 +75,6 @@ class ResultSet:
         self.max_tile = carve('max_tile', 4 * n, torch.int32, (n,))
         self.reward = carve('reward', 4 * n, torch.float32, (n,))
         self.legal = carve('legal', 4 * n, torch.bool, (n, 4))
-        # step_count | total | done are adjacent: batched_reset clears them with ONE fill
-        z0, z1 = offsets['step_count'], offsets['done'] + n
-        self.zero_region = arena[z0:z1]
         self.tensors = (self.board, self.obs, self.step_count, self.total, self.done, self.max_tile, self.reward, self.legal)
         self.ptr = {name: base + offsets[name] for name, _ in sizes}
         self.version = arena._version  # ONE counter: the carved tensors are views of the arena and share its version counter
@@ -85,6 +84,24 @@ class ResultSet:
         self.idle_use = _use_count(self.cdata) if _use_count else -1
         self.pooled = False
         self.leased = False  # set by ResultPool.acquire, cleared by the mirror once the caller-facing references exist
+        # host mirror (see host_array): field -> (offset, bytes, NumPy dtype, shape); created on the first NumPy read
+        self.layout = {'board': (offsets['board'], 64 * n, np.int32, (n, 4, 4)), 'obs': (offsets['obs'], 64 * n, np.float32, (n, 16)),
+                       'step_count': (offsets['step_count'], 4 * n, np.int32, (n,)), 'total': (offsets['total'], 4 * n, np.float32, (n,)),
+                       'done': (offsets['done'], n, np.bool_, (n,)), 'max_tile': (offsets['max_tile'], 4 * n, np.int32, (n,)),
+                       'reward': (offsets['reward'], 4 * n, np.float32, (n,)), 'legal': (offsets['legal'], 4 * n, np.bool_, (n, 4))}
+        self.serial = 0  # launches that have written this set (kernel writes do not move torch's version counter)
+        self.mirror = None
+        self.mirror_fields = None
+        self.mirror_key = None
+        self.mirror_delta = 0  # (mirror address) - (arena address): what the mirrored entry points of the C-ABI take
+        self.direct_serial = -1  # the launch (serial) whose kernel wrote the mirror itself
+        if arena.is_cuda and arena.numel() <= MIRROR_MAX_BYTES:
+            self.mirror = torch.empty((arena.numel(),), dtype=torch.uint8, pin_memory=True)
+            host = self.mirror.numpy()
+            self.mirror_fields = {k: host[o:o + b].view(dt).reshape(shape) for k, (o, b, dt, shape) in self.layout.items()}
+            delta = self.mirror.data_ptr() - base
+            self.mirror_delta = delta if delta % 16 == 0 else 0
+        self.mirror_copies = 0  # device-to-host copies made for NumPy reads (tests / tools read it)
 
     def idle(self) -> bool:
         """Nobody but this set references its tensors or their memory, and no other thread is between acquire() and its return."""
@@ -96,9 +113,36 @@ class ResultSet:
                 and sys.getrefcount(ts[3]) == refs[3] and sys.getrefcount(ts[4]) == refs[4] and sys.getrefcount(ts[5]) == refs[5]
                 and sys.getrefcount(ts[6]) == refs[6] and sys.getrefcount(ts[7]) == refs[7])
 
-    def mark_written(self) -> None:
-        """A launch has just been given this set to fill: the stash is valid from the current version on."""
+    def mark_written(self, mirrored: bool = False) -> None:
+        """A launch has just been given this set to fill: the stash is valid from the current version on.  ``mirrored``: the
+        launch writes the host mirror too (it was given ``mirror_delta``)."""
         self.version = self.arena._version
+        self.serial += 1
+        if mirrored:
+            self.direct_serial = self.serial
+
+    def host_array(self, name: str):
+        """Field `name` of this set as a NumPy array backed by the set's PINNED HOST MIRROR, or None when the set is not
+        mirrored (host tensors; arenas above MIRROR_MAX_BYTES).  The reference's loop reads four arrays of every state back
+        (``np.array(observations)``, ``np.array(legal_masks)``, ``np.array(rewards)``, ``np.array(dones)``,
+        self_play.py:346-356): as four device-to-host copies that is four synchronisations (~18 us each).  Here the kernel
+        that fills the set writes every result into the mirror as well (``mirror_delta``, env2048_*_mirrored), so the FIRST read
+        after a launch is one stream synchronisation and every further read of that state is a host-side copy.  The mirror is
+        current for one (launch serial, torch version) pair: after an in-place torch edit of any field it is refreshed with
+        one asynchronous copy of the set.  The caller gets a COPY (what np.array means); the mirror itself is never handed out."""
+        if self.mirror is None:
+            return None
+        arena = self.arena
+        key = (self.serial, arena._version)
+        if self.mirror_key != key:
+            if self.direct_serial == self.serial and arena._version == self.version:
+                torch.cuda.current_stream(arena.device).synchronize()  # the launch has written the mirror itself: wait for it
+            else:
+                self.mirror.copy_(arena, non_blocking=True)
+                torch.cuda.current_stream(arena.device).synchronize()
+                self.mirror_copies += 1
+            self.mirror_key = key
+        return self.mirror_fields[name]
 
     def stash_valid(self) -> bool:
         """The set is as the kernel wrote it: no in-place torch operation touched any of its tensors since (they share the

@@ -162,6 +162,22 @@ class OracleLibrary:
             self.status_i32(device, stream, n, boards, obs, legal4, None)
             self.calls.pop()
 
+    def step_state_i32_keyed_mirrored(self, device, stream, n, keys, boards_in, boards_out, actions, step_count_in, step_count_out,
+                                      done_in, done_out, total_in, total_out, reward, max_tile, obs, legal4, host_mirror_delta=0):
+        assert host_mirror_delta == 0, 'the stand-in works on host memory: nothing to mirror'
+        self.step_state_i32_keyed_status(device, stream, n, keys, boards_in, boards_out, actions, step_count_in, step_count_out,
+                                         done_in, done_out, total_in, total_out, reward, max_tile, obs, legal4)
+
+    def reset_state_i32_keyed(self, device, stream, n, keys, boards, step_count, done, total, obs, legal4, host_mirror_delta=0):
+        assert host_mirror_delta == 0, 'the stand-in works on host memory: nothing to mirror'
+        self.reset_keyed_i32_status(device, stream, n, keys, boards, obs, legal4)
+        if step_count is not None:
+            _view(step_count, n, np.int32)[:] = 0
+        if done is not None:
+            _view(done, n, np.uint8)[:] = 0
+        if total is not None:
+            _view(total, n, np.float32)[:] = 0.0
+
     def rollout(self, device, stream, n, env_base, boards, seed, step0, T, return_sum, episodes, valid_moves, flags):
         self.calls.append(('rollout', n))
         b = _view(boards, n * 16, np.uint8)

@@ -431,3 +431,40 @@ def test_mirror_loops_from_several_threads(api_runtime):
     [t.start() for t in threads]
     [t.join() for t in threads]
     assert not errors, errors[0]
+
+
+@pytest.mark.gpu
+def test_numpy_reads_of_a_state_come_from_the_host_mirror():
+    """The np.array(...) conversions the reference's loop makes per move (self_play.py:346-356) cost NO device-to-host copy:
+    the launch wrote the set's pinned host mirror itself.  Values equal the plain per-array copies; what the caller gets is
+    its own copy; an in-place torch edit is seen by the next read (one refresh copy); views take the general path."""
+    n = 8
+    rng = np.random.default_rng(31)
+    resultpool.pool.clear()
+    states = batched_reset(_loop_keys(rng, n))
+    rs0 = resultpool.pool.lookup(states.board)[0]
+    assert rs0.mirror_delta != 0 and rs0.mirror_delta % 16 == 0
+    fresh = [np.array(states.step_count), np.array(states.done), np.array(states.total_reward), np.array(states.board)]
+    assert not fresh[0].any() and not fresh[1].any() and not fresh[2].any() and (fresh[3] != 0).sum() == 2 * n and rs0.mirror_copies == 0
+    for move in range(12):
+        states, rewards, dones, info = batched_step(states, np.full(n, move & 3, dtype=np.int32), _loop_keys(rng, n))
+        rs = resultpool.pool.lookup(states.board)[0]
+        before = rs.mirror_copies
+        fields = (rewards, dones, batched_get_observation(states), batched_get_legal_actions(states), states.board, info['max_tile'],
+                  states.step_count, states.total_reward)
+        got = [np.array(t) for t in fields]
+        assert rs.mirror_copies == before, 'reads of a freshly written state need no copy'
+        plain = [t.as_subclass(torch.Tensor).cpu().numpy() for t in fields]
+        for a, b in zip(got, plain):
+            assert a.dtype == b.dtype and a.shape == b.shape and np.array_equal(a, b)
+        got[0][:] = -1.0  # the caller's array is its own
+        assert np.array_equal(np.array(rewards), plain[0])
+    states.board[0, 0, 0] = 64  # an in-place edit is seen by the next read (one refresh copy of the set)
+    assert np.array(states.board)[0, 0, 0] == 64 and rs.mirror_copies == before + 1
+    assert np.array(states.board)[0, 0, 0] == 64 and rs.mirror_copies == before + 1
+    view = states.board[1]  # a view is not a pooled tensor: the general path, same values
+    assert np.array_equal(np.array(view), np.array(states.board)[1])
+    assert np.array(states.board, dtype=np.int64).dtype == np.int64
+    # a large batch is not mirrored (its arrays are read one by one as before)
+    big = batched_reset(_loop_keys(rng, 4096))
+    assert resultpool.pool.lookup(big.board)[0].mirror_delta == 0 and np.array(big.board).shape == (4096, 4, 4)

@@ -740,6 +740,87 @@ def test_keyed_step_and_reset_with_fused_status_match_oracle(lib):
     assert e.value.code == capi.ERR_ALIGNMENT
 
 
+def test_mirrored_step_and_reset_write_the_host_block_too(lib):
+    """env2048_step_state_i32_keyed_mirrored / env2048_reset_state_i32_keyed: all outputs of a call live in ONE device block;
+    with host_mirror_delta = (pinned host block) - (device block) every output is also written to the host block, which
+    after one synchronisation equals the device block byte for byte -- and both equal the oracle (frozen games included).
+    delta = 0: no mirror; a misaligned delta and the in-place form are refused."""
+    rng = np.random.default_rng(77)
+    for n in (4, 8, 333):
+        keys = rng.integers(0, 1 << 32, size=(n, 2), dtype=np.uint64).astype(np.uint32)
+        values = oracle.unpack_values(random_boards(rng, n)).astype(np.int32)
+        actions = rng.integers(0, 4, size=n).astype(np.int32)
+        step_count = rng.integers(0, 500, size=n).astype(np.int32)
+        done = (rng.random(n) < 0.3).astype(np.uint8)
+        total = rng.integers(0, 5000, size=n).astype(np.float32)
+        ref = oracle.step_state_i32_keyed(values, actions, step_count, done, total, keys)
+        status = oracle.status_batch(oracle.pack_values(ref['boards']).reshape(n, 16))
+        # one block: board | obs | step_count | total | done | max_tile | reward | legal4, each 16-byte aligned
+        sizes = [('board', 64 * n), ('obs', 64 * n), ('step_count', 4 * n), ('total', 4 * n), ('done', n), ('max_tile', 4 * n), ('reward', 4 * n),
+                 ('legal', 4 * n)]
+        off, at = {}, 0
+        for name, size in sizes:
+            off[name] = at
+            at = (at + size + 15) // 16 * 16
+        block = torch.full((at,), 0xEE, dtype=torch.uint8, device='cuda')
+        host = torch.full((at,), 0xDD, dtype=torch.uint8).pin_memory()
+        delta = host.data_ptr() - block.data_ptr()
+        assert delta % 16 == 0
+        q = {name: block.data_ptr() + o for name, o in off.items()}
+        k, a = cu(keys.view(np.int32)), cu(actions)
+        b_in, sc_in, d_in, tr_in = cu(values), cu(step_count), cu(done), cu(total)
+        lib.step_state_i32_keyed_mirrored(DEV, stream(), n, p(k), p(b_in), q['board'], p(a), p(sc_in), q['step_count'], p(d_in), q['done'],
+                                          p(tr_in), q['total'], q['reward'], q['max_tile'], q['obs'], q['legal'], delta)
+        torch.cuda.synchronize()
+        dev_bytes, host_bytes = block.cpu().numpy(), host.numpy()
+
+        def field(buf, name, dtype, shape):
+            return buf[off[name]:off[name] + dict(sizes)[name]].view(dtype).reshape(shape)
+
+        for buf, where in ((dev_bytes, 'device'), (host_bytes, 'host mirror')):
+            np.testing.assert_array_equal(field(buf, 'board', np.int32, (n, 16)), ref['boards'], err_msg=where)
+            np.testing.assert_array_equal(field(buf, 'step_count', np.int32, (n,)), ref['step_count'], err_msg=where)
+            np.testing.assert_array_equal(field(buf, 'done', np.uint8, (n,)), ref['done'], err_msg=where)
+            np.testing.assert_array_equal(field(buf, 'total', np.float32, (n,)), ref['total_reward'], err_msg=where)
+            np.testing.assert_array_equal(field(buf, 'reward', np.float32, (n,)), ref['reward'], err_msg=where)
+            np.testing.assert_array_equal(field(buf, 'max_tile', np.int32, (n,)), ref['max_tile'], err_msg=where)
+            np.testing.assert_array_equal(field(buf, 'obs', np.float32, (n, 16)), status['obs'], err_msg=where)
+            np.testing.assert_array_equal(field(buf, 'legal', np.uint8, (n, 4)), ((status['legal'][:, None] >> np.arange(4)) & 1).astype(np.uint8),
+                                          err_msg=where)
+        # bytes the call does not own (padding between the arrays) are untouched on both sides
+        owned = np.zeros(at, dtype=bool)
+        for name, size in sizes:
+            owned[off[name]:off[name] + size] = True
+        assert (dev_bytes[~owned] == 0xEE).all() and (host_bytes[~owned] == 0xDD).all()
+        # reset: board + bookkeeping zeros + status, mirrored
+        block.fill_(0xEE)
+        host.fill_(0xDD)
+        lib.reset_state_i32_keyed(DEV, stream(), n, p(k), q['board'], q['step_count'], q['done'], q['total'], q['obs'], q['legal'], delta)
+        torch.cuda.synchronize()
+        want = oracle.reset_keyed_i32(keys)
+        st0 = oracle.status_batch(oracle.pack_values(want).reshape(n, 16))
+        for buf, where in ((block.cpu().numpy(), 'device'), (host.numpy(), 'host mirror')):
+            np.testing.assert_array_equal(field(buf, 'board', np.int32, (n, 16)), want, err_msg=where)
+            assert not field(buf, 'step_count', np.int32, (n,)).any() and not field(buf, 'done', np.uint8, (n,)).any(), where
+            assert not field(buf, 'total', np.float32, (n,)).any(), where
+            np.testing.assert_array_equal(field(buf, 'obs', np.float32, (n, 16)), st0['obs'], err_msg=where)
+        # no mirror: the host block stays as it was
+        host.fill_(0xDD)
+        lib.step_state_i32_keyed_mirrored(DEV, stream(), n, p(k), p(b_in), q['board'], p(a), p(sc_in), q['step_count'], p(d_in), q['done'],
+                                          p(tr_in), q['total'], q['reward'], q['max_tile'], q['obs'], q['legal'], 0)
+        torch.cuda.synchronize()
+        assert (host.numpy() == 0xDD).all()
+        np.testing.assert_array_equal(field(block.cpu().numpy(), 'board', np.int32, (n, 16)), ref['boards'])
+    with pytest.raises(capi.Env2048Error) as e:
+        lib.step_state_i32_keyed_mirrored(DEV, stream(), n, p(k), p(b_in), q['board'], p(a), p(sc_in), q['step_count'], p(d_in), q['done'],
+                                          p(tr_in), q['total'], q['reward'], q['max_tile'], q['obs'], q['legal'], delta + 4)
+    assert e.value.code == capi.ERR_ALIGNMENT
+    with pytest.raises(capi.Env2048Error) as e:  # in place + mirror: refused
+        lib.step_state_i32_keyed_mirrored(DEV, stream(), n, p(k), p(b_in), p(b_in), p(a), p(sc_in), p(sc_in), p(d_in), p(d_in),
+                                          p(tr_in), p(tr_in), q['reward'], q['max_tile'], None, None, delta)
+    assert e.value.code == capi.ERR_INVALID_ARG
+
+
 def test_step_state_i32_matches_oracle(lib):
     """Fused reinforce/game step on int32 value boards: done-guard, bookkeeping, JAX is_done."""
     rng = np.random.default_rng(11)

@@ -55,6 +55,10 @@ def main():
             'env_work_us_device_inputs': round(run(n, moves, True, False), 2),
             'move_with_readback_us_numpy_inputs': round(run(n, moves, False, True), 2),
         }
+    out['readback'] = ('np.array(...) of a pooled result reads the set\'s pinned host mirror, which the launch itself wrote '
+                       '(env2048_step_state_i32_keyed_mirrored): the first read after a launch is one stream synchronisation, further reads '
+                       f'of that state are host copies (resultpool.ResultSet.host_array; sets above {resultpool.MIRROR_MAX_BYTES >> 10} KiB are '
+                       'read array by array, one device-to-host copy each)')
     out['result_sets_created'] = resultpool.pool.created
     print(json.dumps(out, indent=1))
 
