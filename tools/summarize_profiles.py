@@ -83,6 +83,11 @@ def main(tag, label, dest=None):
                 try:  # the step period bench.py itself measured in that PROFILED run (the profiler slows the enqueuing threads down)
                     line = (src / f'stats_{LEGS[leg][0]}.json').read_text().strip().splitlines()[-1]
                     ks['bench_event_us_per_step_in_the_profiled_run'] = json.loads(line)['timing']['event_us_per_step']['median']
+                    # the profiler adds host time to every launch; when the run's own step period is far above the kernel time the
+                    # profiled run was LAUNCH-BOUND: the GPU idled between kernels (clocks sag, kernels of two chains stop overlapping)
+                    # and the average below is not the duration the kernel has in the timed, unprofiled run
+                    per_step = ks['avg_us'] * (1 if leg != 'resident' else 1)
+                    ks['launch_bound_in_the_profiled_run'] = ks['bench_event_us_per_step_in_the_profiled_run'] > 1.15 * per_step
                 except Exception:
                     pass
                 table['kernel_stats'][leg] = ks
