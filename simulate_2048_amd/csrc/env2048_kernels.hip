@@ -224,6 +224,9 @@ constexpr int word_strip_words(int bpl) { return word_strip(bpl) < 256 ? 256 : w
 constexpr uint64_t SMALL_TILING_MAX_BOARDS = 1ull << 18;  // launches up to this size use the BPL = 1 tiling
 
 __constant__ uint32_t DIR_TABLE[32] = {ENV2048_DIR_SELECTOR_VALUES};
+// plane-space transitions of the multi-step kernels (board_ops.hpp, transition_oriented): 16 selector records
+// [orientation][action] followed by 4 rank-mask records [action], 16 bytes each
+__constant__ uint32_t ORIENT_TABLE[80] = {ENV2048_ORIENT_SELECTOR_VALUES, ENV2048_ORIENT_RANK_MASK_VALUES};
 
 constexpr uint32_t INTERNAL_FLAG_WIDE_OUTPUTS = 0x80000000u;  // reward 16-B / done 4-B aligned: transposed wide stores
 constexpr uint32_t INTERNAL_FLAG_WRITE_THROUGH = 0x40000000u;  // sc1 stores (host decides by launch size)
@@ -657,7 +660,7 @@ template <bool STATS, bool REPLAY = false, int BPL = ENV2048_BOARDS_PER_LANE>
 __global__ __launch_bounds__(BLOCK) void rollout_kernel(RolloutArgs a)
 {
     constexpr int BOARDS_PER_LANE = BPL, TILE_BOARDS = tile_boards(BPL), WORD_STRIP = word_strip_words(BPL);  // (shadow the globals)
-    __shared__ uint4 dir_lds[8];
+    __shared__ uint4 orient_lds[20];  // [4 * orientation + action] selectors, then [16 + action] rank masks
     __shared__ __attribute__((aligned(16))) uint32_t word_lds[WAVES_PER_BLOCK][WORD_STRIP];
     __shared__ unsigned long long stats_lds[STATS ? ENV2048_ROLLOUT_STATS_WORDS : 1];
     // REPLAY, wide rows: per wave 256 reward words + 256 done bytes + 256 action bytes, to turn the lane's four boards
@@ -670,7 +673,7 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(RolloutArgs a)
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (tid < 8u) dir_lds[tid] = reinterpret_cast<const uint4 *>(DIR_TABLE)[tid];
+    if (tid < 20u) orient_lds[tid] = reinterpret_cast<const uint4 *>(ORIENT_TABLE)[tid];
     __syncthreads();
 
     const uint64_t tile0 = ((uint64_t)blockIdx.x * WAVES_PER_BLOCK + wave) * TILE_BOARDS;
@@ -679,7 +682,10 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(RolloutArgs a)
     uint32_t *strip = word_lds[wave];
     const uint32_t strip_off = (uint32_t)env0 & 3u;
 
+    // The boards live in the PLANE SPACE of their last move for the whole kernel (transition_oriented: one byte network per
+    // step instead of two); ori16[j] = 16 * orientation of bd[j] = the LDS offset of that orientation's selector rows / 4.
     Board bd[BOARDS_PER_LANE];
+    uint32_t ori16[BOARDS_PER_LANE];
     bool valid[BOARDS_PER_LANE];
     int64_t ret[BOARDS_PER_LANE];
     uint32_t eps[BOARDS_PER_LANE], moves[BOARDS_PER_LANE];
@@ -690,6 +696,7 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(RolloutArgs a)
         const uint64_t i = tile0 + 64u * j + lane;
         valid[j] = i < a.n;
         bd[j] = valid[j] ? load_board(a.boards, i) : Board{0u, 0u, 0u, 0u};
+        ori16[j] = 16u * ORIENT_BOARD;
         ret[j] = 0;
         eps[j] = 0u;
         moves[j] = 0u;
@@ -744,7 +751,13 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(RolloutArgs a)
             const uint32_t word = strip[strip_off + 64u * j + lane];
             uint32_t reward;
             bool changed, done;
-            transition(bd[j], load_selectors(dir_lds, (REPLAY ? act[j] : word) & 3u), word, reward, changed, done);
+            {
+                const uint32_t act16 = ((REPLAY ? act[j] : word) & 3u) << 4;  // 16 * action: byte offset of its rank-mask row
+                const uint4 sel = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(orient_lds) + (4u * ori16[j] + act16));
+                const uint4 msk = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(orient_lds + 16) + act16);
+                transition_oriented(bd[j], OrientStep{sel.x, sel.y, sel.z, sel.w, msk.x, msk.y, msk.z, msk.w}, word, reward, changed, done);
+                ori16[j] = act16;
+            }
             ret[j] += reward;
             eps[j] += done ? 1u : 0u;
             moves[j] += changed ? 1u : 0u;
@@ -799,7 +812,10 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(RolloutArgs a)
                 const Board fresh = fresh_board(w0, w1, w2, w3);
 #pragma unroll
                 for (int jj = 0; jj < BOARDS_PER_LANE; ++jj)
-                    if (j == (uint32_t)jj) bd[jj] = fresh;
+                    if (j == (uint32_t)jj) {
+                        bd[jj] = fresh;  // rows: orientation ORIENT_BOARD
+                        ori16[jj] = 16u * ORIENT_BOARD;
+                    }
             }
         }
     }
@@ -808,6 +824,10 @@ __global__ __launch_bounds__(BLOCK) void rollout_kernel(RolloutArgs a)
     for (int j = 0; j < BOARDS_PER_LANE; ++j) {
         if (!valid[j]) continue;
         const uint64_t i = tile0 + 64u * j + lane;
+        {  // back to rows: one pass from the board's orientation to ORIENT_BOARD
+            const uint4 sel = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(orient_lds) + (4u * ori16[j] + 16u * ORIENT_BOARD));
+            bd[j] = orient_network(bd[j], sel.x, sel.y, sel.z, sel.w);
+        }
         store_board(a.boards, i, bd[j]);
         if (a.return_sum) a.return_sum[i] = ret[j];
         if (a.episodes) a.episodes[i] = eps[j];

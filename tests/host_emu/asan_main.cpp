@@ -34,6 +34,16 @@ int main()
     emu_step_words(n, 5, 77, 3, words.data());
     emu_step(n, 5, boards.data(), actions.data(), words.data(), reward.data(), done.data(), legal.data(), 77, 3, 1u);
     emu_step(n, 5, boards.data(), actions.data(), words.data(), reward.data(), done.data(), nullptr, 77, 4, 3u);
+    {
+        const uint32_t T = 3;
+        std::vector<uint8_t> acts(T * n);
+        std::vector<uint32_t> w3(T * n), dcount(n);
+        std::vector<int64_t> rsum(n);
+        for (auto &a : acts) a = (uint8_t)next();
+        for (uint32_t t = 0; t < T; ++t) emu_step_words(n, 5, 77, 10 + t, w3.data() + t * n);
+        emu_steps_oriented(n, 5, boards.data(), acts.data(), w3.data(), T, rsum.data(), dcount.data(), done.data(), 77, 10, 1u);
+        emu_steps_oriented(n, 5, boards.data(), nullptr, w3.data(), T, rsum.data(), dcount.data(), done.data(), 77, 10, 3u);
+    }
     emu_status(n, boards.data(), done.data(), legal.data(), n_empty.data());
     emu_spawn(n, boards.data(), k.data(), e.data(), placed.data());
     emu_reset(n, (1ull << 33) + 1, out.data(), 9, 9);

@@ -72,6 +72,46 @@ void emu_step(uint64_t n, uint64_t env_base, uint8_t *boards, const uint8_t *act
     }
 }
 
+// T transitions with every board held in the plane space of its last move (what the multi-step kernels do) and mapped
+// back to rows once at the end: must equal T emu_step calls.  words / actions are [T][n].
+void emu_steps_oriented(uint64_t n, uint64_t env_base, uint8_t *boards, const uint8_t *actions, const uint32_t *words, uint32_t T,
+                        int64_t *reward_sum, uint32_t *done_count, uint8_t *last_done, uint64_t seed, uint64_t step0, uint32_t flags)
+{
+    for (uint64_t i = 0; i < n; ++i) {
+        Board pl = load(boards + 16 * i);
+        uint32_t ori = ORIENT_BOARD;
+        int64_t sum = 0;
+        uint32_t dones = 0;
+        bool dn = false;
+        for (uint32_t t = 0; t < T; ++t) {
+            const uint32_t w = words[(uint64_t)t * n + i];
+            const uint32_t action = (flags & 2u) ? (w & 3u) : (actions[(uint64_t)t * n + i] & 3u);
+            OrientStep s;
+            std::memcpy(&s.sA, ORIENT_SELECTORS + 4 * (4 * ori + action), 16);
+            std::memcpy(&s.m0, ORIENT_RANK_MASKS + 4 * action, 16);
+            uint32_t r;
+            bool ch;
+            transition_oriented(pl, s, w, r, ch, dn);
+            ori = action;
+            sum += r;
+            dones += dn;
+            if ((flags & 1u) && dn) {
+                const uint64_t step = step0 + t;
+                const RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)step, (uint32_t)(step >> 32)};
+                uint32_t w0, w1, w2, w3;
+                env_block(key, env_base + i, STREAM_RESET, w0, w1, w2, w3);
+                pl = fresh_board(w0, w1, w2, w3);
+                ori = ORIENT_BOARD;
+            }
+        }
+        const uint32_t *back = ORIENT_SELECTORS + 4 * (4 * ori + ORIENT_BOARD);
+        store(boards + 16 * i, orient_network(pl, back[0], back[1], back[2], back[3]));
+        reward_sum[i] = sum;
+        done_count[i] = dones;
+        last_done[i] = dn;
+    }
+}
+
 void emu_step_words(uint64_t n, uint64_t env_base, uint64_t seed, uint64_t step, uint32_t *words)
 {
     const RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)step, (uint32_t)(step >> 32)};

@@ -205,6 +205,69 @@ def test_random_boards_vs_oracle(emu):
     np.testing.assert_array_equal(legal, ref['legal'])
 
 
+@pytest.mark.parametrize('flags', [0, 1, 2, 3])
+def test_plane_space_transitions_equal_plain_steps(emu, flags):
+    """Boards held in the plane space of their last move over T steps (transition_oriented: what the rollout / replay kernels
+    run) and mapped back to rows once at the end == T plain transitions, for host actions and for actions taken from the step
+    words, with and without auto-reset; start boards include empty, full and high-tile boards; every (previous action, action)
+    pair occurs thousands of times.  The oracle checks the final boards and the sums as well."""
+    rng = np.random.default_rng(40 + flags)
+    n, T = 6000, 24
+    seed, step0, env_base = 0xFEEDFACE12345678, (1 << 32) - 7, 5_000_000_003
+    boards = np.where(rng.random((n, 16)) < 0.3, 0, rng.integers(0, 18, size=(n, 16))).astype(np.uint8)
+    boards[: n // 2] = np.where(rng.random((n // 2, 16)) < 0.15, 0, rng.integers(1, 5, size=(n // 2, 16)))
+    boards[0] = 0
+    boards[1] = np.arange(1, 17)
+    boards[2] = 17
+    actions = rng.integers(0, 256, size=(T, n)).astype(np.uint8)
+    words = np.zeros((T, n), dtype=np.uint32)
+    for t in range(T):
+        emu.emu_step_words(ctypes.c_uint64(n), ctypes.c_uint64(env_base), ctypes.c_uint64(seed), ctypes.c_uint64(step0 + t),
+                           ptr(words[t], ctypes.c_uint32))
+    plain = boards.copy()
+    sums, dones = np.zeros(n, dtype=np.int64), np.zeros(n, dtype=np.uint32)
+    reward, done = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.uint8)
+    for t in range(T):
+        emu.emu_step(ctypes.c_uint64(n), ctypes.c_uint64(env_base), u8(plain), u8(actions[t]), ptr(words[t], ctypes.c_uint32),
+                     ptr(reward, ctypes.c_int32), u8(done), None, ctypes.c_uint64(seed), ctypes.c_uint64(step0 + t), flags)
+        sums += reward
+        dones += done
+    got = boards.copy()
+    got_sums, got_dones, last_done = np.zeros(n, dtype=np.int64), np.zeros(n, dtype=np.uint32), np.zeros(n, dtype=np.uint8)
+    emu.emu_steps_oriented(ctypes.c_uint64(n), ctypes.c_uint64(env_base), u8(got), u8(actions), ptr(words, ctypes.c_uint32), ctypes.c_uint32(T),
+                           ptr(got_sums, ctypes.c_int64), ptr(got_dones, ctypes.c_uint32), u8(last_done), ctypes.c_uint64(seed),
+                           ctypes.c_uint64(step0), ctypes.c_uint32(flags))
+    np.testing.assert_array_equal(got, plain)
+    np.testing.assert_array_equal(got_sums, sums)
+    np.testing.assert_array_equal(got_dones, dones)
+    np.testing.assert_array_equal(last_done, done)
+    want = oracle.rollout_batch(boards, seed, step0, T, env_base=env_base, flags=flags) if flags & 2 else None
+    if want is not None:
+        np.testing.assert_array_equal(got, want['boards'])
+        np.testing.assert_array_equal(got_sums, want['return_sum'])
+
+
+def test_orientation_tables_are_what_the_generator_derives():
+    """ORIENT_SELECTORS / ORIENT_RANK_MASKS in board_ops.hpp == what tools/gen_orientation_tables.py derives from DIR_SELECTORS."""
+    import re
+    import subprocess
+    import sys
+
+    out = subprocess.run([sys.executable, str(REPO / 'tools' / 'gen_orientation_tables.py')], capture_output=True, text=True, check=True).stdout
+    header = (REPO / 'simulate_2048_amd' / 'csrc' / 'board_ops.hpp').read_text()
+
+    def values(text, start, stop):
+        body = text[text.index(start):]
+        body = body[:body.index(stop)]
+        return [int(v, 16) for v in re.findall(r'0x([0-9A-Fa-f]{8})u', body)]
+
+    gen_sel = values(out, 'constexpr uint32_t ORIENT_SELECTORS[64]', '};')
+    gen_masks = values(out, 'constexpr uint32_t ORIENT_RANK_MASKS[16]', '};')
+    assert len(gen_sel) == 64 and len(gen_masks) == 16
+    assert values(header, '#define ENV2048_ORIENT_SELECTOR_VALUES', '#define ENV2048_ORIENT_RANK_MASK_VALUES') == gen_sel
+    assert values(header, '#define ENV2048_ORIENT_RANK_MASK_VALUES', 'constexpr uint32_t ORIENT_SELECTORS') == gen_masks
+
+
 def test_batch_loops_under_asan_and_ubsan(tmp_path):
     """ASan + UBSan over every batch function of the host build (the shared object only had UBSan)."""
     exe = tmp_path / 'emu_asan'
