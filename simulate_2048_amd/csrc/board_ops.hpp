@@ -1,3 +1,4 @@
+// [step-kernel-source-begin] (bench.py hashes the code between these markers: what step_kernel is built from)
 // board_ops.hpp -- per-lane 2048 board arithmetic for gfx950 (CDNA4), header-only device code.
 //
 // One board lives in four VGPRs: dword r = row r, byte c = column c, byte value = log2(tile)
@@ -633,6 +634,7 @@ ENV2048_DEV void transition(Board &bd, const DirSelectors &sel, uint32_t word, u
     done = (empties_left == 0u) & no_equal_neighbours(bd);
 }
 
+// [step-kernel-source-end]
 // ---- boards kept in the PLANE SPACE of their last move (multi-step kernels: rollout, replay) -----------------------------
 // transition() maps rows -> planes of the action, slides, and maps back: 8 + 8 v_perm_b32.  A kernel that keeps a board in
 // registers over many steps does not need the way back: the four planes of action a ARE the board in one of four fixed
