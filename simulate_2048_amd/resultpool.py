@@ -47,7 +47,7 @@ def _align(x: int, a: int = 16) -> int:
 class ResultSet:
     __slots__ = ('n', 'arena', 'storage', 'cdata', 'board', 'obs', 'step_count', 'max_tile', 'total', 'reward', 'legal', 'done',
                  'tensors', 'ptr', 'idle_refs', 'idle_use', 'version', 'pooled', 'leased', 'layout', 'serial',
-                 'mirror', 'mirror_fields', 'mirror_key', 'mirror_copies', 'mirror_delta', 'direct_serial')
+                 'mirror', 'mirror_fields', 'mirror_key', 'mirror_copies', 'mirror_delta', 'direct_serial', 'stream')
 
     def __init__(self, n: int, device: torch.device):
         self.n = n
@@ -95,6 +95,8 @@ class ResultSet:
         self.mirror_key = None
         self.mirror_delta = 0  # (mirror address) - (arena address): what the mirrored entry points of the C-ABI take
         self.direct_serial = -1  # the launch (serial) whose kernel wrote the mirror itself
+        # the pool keeps sets per launch stream, so this is the stream every launch into this set is enqueued on
+        self.stream = torch.cuda.current_stream(arena.device) if arena.is_cuda else None
         if arena.is_cuda and arena.numel() <= MIRROR_MAX_BYTES:
             self.mirror = torch.empty((arena.numel(),), dtype=torch.uint8, pin_memory=True)
             host = self.mirror.numpy()
@@ -136,7 +138,7 @@ class ResultSet:
         key = (self.serial, arena._version)
         if self.mirror_key != key:
             if self.direct_serial == self.serial and arena._version == self.version:
-                torch.cuda.current_stream(arena.device).synchronize()  # the launch has written the mirror itself: wait for it
+                self.stream.synchronize()  # the launch has written the mirror itself: wait for it (on ITS stream)
             else:
                 self.mirror.copy_(arena, non_blocking=True)
                 torch.cuda.current_stream(arena.device).synchronize()

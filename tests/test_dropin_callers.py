@@ -468,3 +468,26 @@ def test_numpy_reads_of_a_state_come_from_the_host_mirror():
     # a large batch is not mirrored (its arrays are read one by one as before)
     big = batched_reset(_loop_keys(rng, 4096))
     assert resultpool.pool.lookup(big.board)[0].mirror_delta == 0 and np.array(big.board).shape == (4096, 4, 4)
+
+
+@pytest.mark.gpu
+def test_host_mirror_waits_for_the_stream_the_move_was_launched_on():
+    """A move enqueued on a side stream behind a long-running kernel, read back while ANOTHER stream is current: the NumPy read
+    synchronises the stream the launch went to (the set is bound to it), so it never sees a half-written mirror."""
+    n = 8
+    rng = np.random.default_rng(55)
+    resultpool.pool.clear()
+    side = torch.cuda.Stream()
+    big = torch.empty((1 << 26,), dtype=torch.float32, device='cuda')
+    for rep in range(5):
+        with torch.cuda.stream(side):
+            states = batched_reset(_loop_keys(rng, n))
+            keys = _loop_keys(rng, n)
+            before = np.array(states.board).reshape(n, 16)
+            for _ in range(6):
+                big.normal_()  # ~1 ms of work on the side stream in front of the move
+            new_states, rewards, dones, _ = batched_step(states, np.zeros(n, dtype=np.int32), keys)
+        got = np.array(new_states.board).reshape(n, 16), np.array(rewards)  # the default stream is current here
+        want = oracle.step_state_i32_keyed(before, np.zeros(n, dtype=np.int32), np.zeros(n, np.int32), np.zeros(n, np.uint8),
+                                           np.zeros(n, np.float32), keys)
+        assert np.array_equal(got[0], want['boards']) and np.array_equal(got[1], want['reward']), rep
