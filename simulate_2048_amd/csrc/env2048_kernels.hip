@@ -1334,27 +1334,16 @@ struct D2After {  // one (board, action) entry of the LDS strip: 24 bytes
 // best reward over the legal moves of one board (0 if it has none): one byte transpose shared by the four slides
 __device__ __forceinline__ int32_t best_move_reward(const Board &bd)
 {
+    // max over the four moves of the merge score.  Opposite directions score the same: after compaction a line is a sequence
+    // of runs of equal tiles, and a run of L tiles of value v gives floor(L / 2) merges worth 2v each whether the greedy pairing
+    // starts at its left or at its right end (gameboard.py:56-67 pairs from the wall outward; runs do not interact).  A move
+    // that changes nothing merges nothing (score 0), so legality never has to be looked at: two slides instead of four.
     uint32_t c0, c1, c2, c3, changed;
     transpose4x4(bd.r0, bd.r1, bd.r2, bd.r3, c0, c1, c2, c3);
-    int32_t best = 0;
-    {
-        uint32_t a = c0, b = c1, c = c2, d = c3;
-        const int32_t r = (int32_t)slide_merge_planes(a, b, c, d, changed);  // left (a move that changes nothing merges nothing: r = 0)
-        best = max(best, r);
-    }
-    {
-        uint32_t a = bd.r0, b = bd.r1, c = bd.r2, d = bd.r3;
-        best = max(best, (int32_t)slide_merge_planes(a, b, c, d, changed));  // up
-    }
-    {
-        uint32_t a = c3, b = c2, c = c1, d = c0;
-        best = max(best, (int32_t)slide_merge_planes(a, b, c, d, changed));  // right
-    }
-    {
-        uint32_t a = bd.r3, b = bd.r2, c = bd.r1, d = bd.r0;
-        best = max(best, (int32_t)slide_merge_planes(a, b, c, d, changed));  // down
-    }
-    return best;  // illegal moves score 0 and never win against a legal one with a merge; all-zero = no merge anywhere: 0 either way
+    const int32_t horizontal = (int32_t)slide_merge_planes(c0, c1, c2, c3, changed);  // left == right
+    uint32_t a = bd.r0, b = bd.r1, c = bd.r2, d = bd.r3;
+    const int32_t vertical = (int32_t)slide_merge_planes(a, b, c, d, changed);  // up == down
+    return max(horizontal, vertical);  // all-zero = no merge anywhere: 0 either way
 }
 
 constexpr int D2_BLOCK = 256;

@@ -100,3 +100,18 @@ def test_depth2_kernel_matches_oracle_and_reference_fixture(golden):
         lib.expectimax_depth2(DEV, stream(), 4, p(b), None, None, None, None)  # no output requested
     with pytest.raises(capi.Env2048Error):
         lib.expectimax_depth2(DEV, stream(), 4, p(b) + 1, None, None, p(best), None)  # misaligned boards
+
+
+def test_opposite_moves_score_the_same(golden):
+    """What the depth-2 kernel's leaf evaluation rests on (two slides instead of four): the merge score of a move equals that of
+    the opposite move -- on the REFERENCE's own latent_state outputs (fixture afterstates.npz: reward of all four actions of
+    6008 boards, written by oracle/gen_golden.py from the imported reference) and on 200 000 random boards through the oracle."""
+    r = golden['afterstates']['reward']
+    assert np.array_equal(r[:, 0], r[:, 2]) and np.array_equal(r[:, 1], r[:, 3])
+    assert (r[:, 0] != r[:, 1]).any()  # (horizontal and vertical scores do differ)
+    rng = np.random.default_rng(8)
+    n = 200_000
+    boards = np.where(rng.random((n, 16)) < 0.25, 0, rng.integers(1, 6, size=(n, 16))).astype(np.uint8)
+    boards[n // 2:] = np.where(rng.random((n - n // 2, 16)) < 0.1, 0, rng.integers(0, 18, size=(n - n // 2, 16)))
+    score = [oracle.afterstate_batch(boards, np.full(n, a, dtype=np.uint8))['reward'] for a in range(4)]
+    assert np.array_equal(score[0], score[2]) and np.array_equal(score[1], score[3])

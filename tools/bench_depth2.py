@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Time env2048_expectimax_depth2 (the whole two-ply expectimax tree per board in one launch) on mid-game boards (GPU box).
 Reports microseconds per launch, root boards / s and leaf evaluations / s (every legal (action, cell, tile) successor is
-evaluated with four slides).  The kernel is pure VALU work (16 B in, 89 B out per board): its roofline is the measured VALU
+evaluated with two slides: opposite moves score the same, so one horizontal and one vertical slide cover the four moves).  The kernel is pure VALU work (16 B in, 89 B out per board): its roofline is the measured VALU
 issue ceiling (profiles/valu_ceiling.json); run it under `rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES` for the instruction count."""
 import json
 import statistics
@@ -41,7 +41,7 @@ def main():
         us = statistics.median(times)
         leaves = int(terms[:, :, 3].sum()) * 2  # successors evaluated: 2 tiles per empty cell of every legal afterstate
         out[f'2^{lg}'] = {'us_per_launch': round(us, 2), 'root_boards_per_s': n / us * 1e6, 'successors_per_board': leaves / n,
-                          'successor_evaluations_per_s': leaves / us * 1e6, 'slides_per_s': 4 * leaves / us * 1e6}
+                          'successor_evaluations_per_s': leaves / us * 1e6, 'leaf_slides_per_s': 2 * leaves / us * 1e6}
     print(json.dumps(out, indent=1))
 
 
