@@ -10,6 +10,10 @@
  *   - Every pointer is a DEVICE pointer on HIP device `device` (plain hipMalloc memory or the
  *     storage of a torch tensor); the caller owns every buffer; the library allocates nothing
  *     and keeps no per-batch state.  Environment state is exactly `boards` + (seed, step_index).
+ *     "Device pointer" means device-ACCESSIBLE: pinned (hipHostMalloc) host memory is as good wherever a few hundred bytes
+ *     move -- the mirrors stage small key / action arrays through it and env2048_*_mirrored write result copies into it.
+ *     The only process-lifetime state is per device and independent of any batch: one internal stream, one helper thread
+ *     and two events, created by the first env2048_step_sequence call that runs as two chains (see there).
  *   - `stream` is a hipStream_t (NULL = the device's default stream).  Calls are ASYNCHRONOUS on
  *     that stream; the caller synchronises.  Entry points are re-entrant and thread-safe.
  *   - Return value: 0 (ENV2048_OK) or a negative error code; env2048_last_error() returns a
