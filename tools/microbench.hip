@@ -428,12 +428,13 @@ int main(int argc, char **argv)
     run("LIB env2048_step", [&](int t) {
         env2048_step(0, s, n, 0, (uint8_t *)B(t), A(t), R(t), D(t), nullptr, nullptr, 0x2048, t, 1);
     });
+    static const uint32_t many_flags = getenv("MB_MANY_FLAGS") ? (uint32_t)atoi(getenv("MB_MANY_FLAGS")) : 1u;  // record flags of the shared launch
     run("LIB step_many x sets (per launch)", [&](int t) {  // the fused multi-record launch over ALL sets, once every `sets` launches
         if (t % sets) return;
         static std::vector<env2048_step_args> recs;
         recs.resize(sets);
         for (int k = 0; k < sets; ++k)
-            recs[k] = env2048_step_args{n, (uint64_t)k * n, (uint8_t *)B(k), A(k), R(k), D(k), nullptr, nullptr, 0x2048, (uint64_t)t, 1, 0, nullptr, nullptr};
+            recs[k] = env2048_step_args{n, (uint64_t)k * n, (uint8_t *)B(k), A(k), R(k), D(k), nullptr, nullptr, 0x2048, (uint64_t)t, many_flags, 0, nullptr, nullptr};
         env2048_step_many(0, s, sets, recs.data());
     });
     run("LIB step no-reset", [&](int t) {
