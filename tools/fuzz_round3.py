@@ -2,7 +2,8 @@
 """Randomised differential run of the round-3 entry points against the CPU oracle (GPU box):
   * env2048_step_many over RANDOM record sets -- independent batches (shared launches), repeated batches (dependent chains),
     mixed kernel variants, hints, ragged sizes, empty records -- against the oracle applied record by record, in order;
-  * env2048_step_state_i32_keyed_status / env2048_reset_keyed_i32_status (fused observation + legal bytes);
+  * env2048_step_state_i32_keyed_status / env2048_reset_keyed_i32_status (fused observation + legal bytes), and the
+    reinforce.game mirrors end to end (pooled result sets, env2048_*_mirrored host mirror, np.array reads);
   * env2048_expectimax_depth2 (integer terms, q, best, value);  env2048_random_actions;
   * env2048_step_sequence as two half-batch chains vs ENV2048_FLAG_SINGLE_CHAIN (GPU vs GPU, 2^20-board batches).
 python tools/fuzz_round3.py [seconds]"""
@@ -22,7 +23,7 @@ lib = capi.library()
 rng = np.random.default_rng(int(time.time()))
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 t0 = last = time.time()
-counts = {'step_many': 0, 'records': 0, 'shared_launches': 0, 'keyed_status': 0, 'depth2': 0, 'random_actions': 0, 'two_chains': 0}
+counts = {'mirrors': 0, 'step_many': 0, 'records': 0, 'shared_launches': 0, 'keyed_status': 0, 'depth2': 0, 'random_actions': 0, 'two_chains': 0}
 S = lambda: torch.cuda.current_stream().cuda_stream
 P = lambda t: None if t is None else t.data_ptr()
 SIZES = [1, 2, 63, 64, 65, 255, 256, 257, 2047, 2048, 2049, 4096, 8191]
@@ -130,6 +131,35 @@ def fuzz_keyed_status():
     counts['keyed_status'] += 1
 
 
+def fuzz_mirrors():
+    """The reinforce.game mirrors end to end at small batch sizes: result sets from the pool, kernels that also write the
+    pinned host mirror, np.array(...) reads through it -- against the oracle and against plain device-to-host copies."""
+    from simulate_2048_amd.reinforce.game import env as genv
+
+    n = int(rng.integers(1, 460))  # around the mirror size limit (N ~ 430) as well
+    keys = rng.integers(0, 1 << 32, size=(n, 2), dtype=np.uint64).astype(np.uint32)
+    states = genv.batched_reset(keys)
+    want = oracle.reset_keyed_i32(keys)
+    np.testing.assert_array_equal(np.array(states.board).reshape(n, 16), want)
+    assert not np.array(states.step_count).any() and not np.array(states.done).any() and not np.array(states.total_reward).any()
+    for move in range(int(rng.integers(1, 6))):
+        before = (np.array(states.board).reshape(n, 16), np.array(states.step_count), np.array(states.done).astype(np.uint8),
+                  np.array(states.total_reward))
+        actions = rng.integers(0, 4, size=n).astype(np.int32)
+        keys = rng.integers(0, 1 << 32, size=(n, 2), dtype=np.uint64).astype(np.uint32)
+        states, rewards, dones, info = genv.batched_step(states, actions, keys)
+        ref = oracle.step_state_i32_keyed(before[0], actions, before[1], before[2], before[3], keys)
+        st = oracle.status_batch(oracle.pack_values(ref['boards']).reshape(n, 16))
+        fields = ((states.board, ref['boards'].reshape(n, 4, 4)), (states.step_count, ref['step_count']), (dones, ref['done'].astype(bool)),
+                  (states.total_reward, ref['total_reward']), (rewards, ref['reward']), (info['max_tile'], ref['max_tile']),
+                  (genv.batched_get_observation(states), st['obs']),
+                  (genv.batched_get_legal_actions(states), ((st['legal'][:, None] >> np.arange(4)) & 1).astype(bool)))
+        for t, expect in fields:
+            np.testing.assert_array_equal(np.array(t), expect, err_msg=f'mirrors n={n} move={move}')
+            np.testing.assert_array_equal(t.as_subclass(torch.Tensor).cpu().numpy(), expect)
+    counts['mirrors'] += 1
+
+
 def fuzz_depth2():
     n = int(rng.choice(SIZES[:9] + [int(rng.integers(1, 1500))]))
     boards = boards_for(n)
@@ -192,7 +222,7 @@ def fuzz_two_chains():
     counts['two_chains'] += 1
 
 
-CASES = [(fuzz_step_many, 10), (fuzz_keyed_status, 3), (fuzz_depth2, 3), (fuzz_random_actions, 2), (fuzz_two_chains, 1)]
+CASES = [(fuzz_step_many, 10), (fuzz_mirrors, 3), (fuzz_keyed_status, 3), (fuzz_depth2, 3), (fuzz_random_actions, 2), (fuzz_two_chains, 1)]
 weights = np.array([w for _, w in CASES], dtype=float)
 weights /= weights.sum()
 while time.time() - t0 < budget:
