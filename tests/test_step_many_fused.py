@@ -322,3 +322,46 @@ def test_step_sequence_two_chains_equal_single_chain_and_single_steps(n):
     lib.step_sequence(DEV, stream(), n, base, p(b2), table, p(r2), p(d2), None, None, 0, seed, 9, K, AUTO | capi.FLAG_SINGLE_CHAIN)
     torch.cuda.synchronize()
     assert torch.equal(b1, b2) and torch.equal(r1, r2) and torch.equal(d1, d2)
+
+
+@pytest.mark.gpu
+def test_two_chain_sequences_from_several_threads_on_one_device():
+    """Three host threads, each with its own stream and its own 2^20-board batch, call env2048_step_sequence (two chains each)
+    on the SAME device at once: the calls share the device's helper thread and side stream one at a time, and every batch ends
+    exactly where its single-chain run ends."""
+    import threading
+
+    lib = capi.library()
+    n, K, seed = 1 << 20, 40, 0x5EED
+    starts = [midgame(lib, n, env_base=1000 * i, seed=seed + i) for i in range(3)]
+    want = []
+    for i, start in enumerate(starts):
+        b = start.clone()
+        r = torch.zeros((n,), dtype=torch.int32, device='cuda')
+        d = torch.zeros((n,), dtype=torch.uint8, device='cuda')
+        lib.step_sequence(DEV, stream(), n, 1000 * i, p(b), None, p(r), p(d), None, None, 0, seed + i, 900, K, AUTO | RANDOM | capi.FLAG_SINGLE_CHAIN)
+        torch.cuda.synchronize()
+        want.append((b.cpu(), r.cpu(), d.cpu()))
+    got, errors = [None] * 3, []
+
+    def run(i):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for rep in range(3):  # several calls per thread: the hand-over of the helper is exercised repeatedly
+                    b = starts[i].clone()
+                    r = torch.zeros((n,), dtype=torch.int32, device='cuda')
+                    d = torch.zeros((n,), dtype=torch.uint8, device='cuda')
+                    lib.step_sequence(DEV, s.cuda_stream, n, 1000 * i, p(b), None, p(r), p(d), None, None, 0, seed + i, 900, K, AUTO | RANDOM)
+                    s.synchronize()
+                got[i] = (b.cpu(), r.cpu(), d.cpu())
+        except BaseException as exc:  # noqa: BLE001
+            errors.append(exc)
+
+    threads = [threading.Thread(target=run, args=(i,)) for i in range(3)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors, errors[0]
+    for i in range(3):
+        for a, b in zip(got[i], want[i]):
+            assert torch.equal(a, b), i
