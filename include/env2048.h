@@ -514,6 +514,33 @@ ENV2048_EXPORT int env2048_expectimax_depth2(int device, void *stream, uint64_t 
                                              uint8_t *best_action, float *value);
 
 /*
+ * Depth-d expectimax, d >= 3: the building blocks of a search tree that stays on the device as one DENSE frontier per level.
+ *     V_d(s) = max over legal a of Q_d(s, a);   Q_d(s, a) = r(s, a) + (0.9 * S2 + 0.1 * S4) / num_empty,
+ *     S2 / S4 = the sums of V_{d-1} over the chance outcomes of afterstate(s, a) that spawned a 2 / a 4  (0 for a terminal board)
+ * [composes gameboard.py:105-129 latent_state, :132-171 after_state, gamemove.py:132-164 can_move, like the depth-2 call].
+ * The CHILDREN of a board are those outcomes for its legal actions, in the order (action, empty cell in row-major rank, tile 2
+ * then 4): on mid-game boards about 34 of the 128 possible.
+ *   env2048_expand_count   counts[i] = number of children of board i.
+ *   env2048_expand         writes them densely: offsets = the exclusive prefix sums of counts (caller-computed), children =
+ *                          (sum of counts) x 16 bytes, plus per (board, action) the merge score reward[4i + a] (0 if illegal) and
+ *                          n_empty[4i + a] = empty cells of the afterstate (0 = illegal action; a legal move always leaves one).
+ *                          The children of (i, a) start at offsets[i] + 2 * (n_empty of the actions before a), cell k at + 2k.
+ *   env2048_expectimax_depth2_f64   V_2 of every board as float64 (the deepest frontier's values).
+ *   env2048_expectimax_backup       folds child values into the values of a level: value[i] = V (float64), optionally q (n x 4
+ *                          float64, -inf for an illegal action) and best_action (255: terminal).  Sums run in child order and
+ *                          every operation is a separate correctly rounded double operation: results do not depend on the
+ *                          device's contraction or scheduling.
+ * Depth d = expand x (d - 2), depth2_f64 on the last frontier, backup x (d - 2) (simulate_2048_amd.ops.expectimax does that).
+ */
+ENV2048_EXPORT int env2048_expand_count(int device, void *stream, uint64_t n, const uint8_t *boards, uint32_t *counts);
+ENV2048_EXPORT int env2048_expand(int device, void *stream, uint64_t n, const uint8_t *boards, const uint64_t *offsets, uint8_t *children,
+                                  int32_t *reward, uint8_t *n_empty);
+ENV2048_EXPORT int env2048_expectimax_depth2_f64(int device, void *stream, uint64_t n, const uint8_t *boards, double *value);
+ENV2048_EXPORT int env2048_expectimax_backup(int device, void *stream, uint64_t n, const int32_t *reward, const uint8_t *n_empty,
+                                             const uint64_t *offsets, const double *child_value, double *value, double *q,
+                                             uint8_t *best_action);
+
+/*
  * Read-only board status; every output may be NULL.
  *     done / legal / obs as in env2048_step;  max_exp[i] = log2(max tile);  n_empty[i] = #zeros
  * [replaces: twentyfortyeight/core/gameboard.py:328-348 is_done;

@@ -740,6 +740,94 @@ ORACLE_API int oracle_expectimax_depth2(uint64_t n, const uint8_t *boards, int32
     return 0;
 }
 
+/* Depth-d expectimax (d >= 2) by plain recursion over the same building blocks:
+ *   V_2(s) = the value oracle_expectimax_depth2 reports (exact fraction, one division);
+ *   Q_d(s, a) = r(s, a) + (0.9 * S2 + 0.1 * S4) / num_empty  for d >= 3, with S2 / S4 = the sums of V_{d-1} over the outcomes
+ *   of after_state(afterstate) that spawned a 2 / a 4, added in after_state's order (empty cells row-major) [ref:
+ *   gameboard.py:105-171 composed as in the depth-2 case]; V_d = max over the legal a (the first maximum), 0 for a terminal board.
+ * Every operation is a separate IEEE double operation in the order written (ISO C mode: no contraction), which the HIP back-up
+ * kernel repeats under `#pragma clang fp contract(off)`, so the two agree bit for bit. */
+static double oracle_value_depth(const uint8_t *b, int depth)
+{
+    if (depth <= 2) {
+        int32_t terms[16];
+        double q[4], value;
+        uint8_t best;
+        oracle_expectimax_depth2(1, b, terms, q, &best, &value);
+        return best == 255 ? 0.0 : value;
+    }
+    double best_q = 0.0;
+    int best_a = 255;
+    for (int a = 0; a < 4; ++a) {
+        uint8_t after[16];
+        const int64_t r = oracle_latent_state(b, a, after);
+        if (memcmp(after, b, 16) == 0) continue;
+        const int n_empty = oracle_count_empty(after);
+        double s2 = 0.0, s4 = 0.0;
+        for (int k = 0; k < n_empty; ++k) {
+            uint8_t o[16];
+            memcpy(o, after, 16);
+            oracle_fill_cell_kv(o, k, 1);
+            s2 = s2 + oracle_value_depth(o, depth - 1);
+            memcpy(o, after, 16);
+            oracle_fill_cell_kv(o, k, 2);
+            s4 = s4 + oracle_value_depth(o, depth - 1);
+        }
+        const double t2 = 0.9 * s2, t4 = 0.1 * s4, mix = t2 + t4, mean = mix / (double)n_empty, q = (double)r + mean;
+        if (best_a == 255 || q > best_q) {
+            best_q = q;
+            best_a = a;
+        }
+    }
+    return best_a == 255 ? 0.0 : best_q;
+}
+
+ORACLE_API int oracle_expectimax_depth(uint64_t n, const uint8_t *boards, int depth, double *q, uint8_t *best_action, double *value)
+{
+    if (depth < 2) return -1;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1)
+#endif
+    for (int64_t ii = 0; ii < (int64_t)n; ++ii) {
+        const uint64_t i = (uint64_t)ii;
+        const uint8_t *b = boards + 16 * i;
+        if (depth == 2) {
+            int32_t terms[16];
+            oracle_expectimax_depth2(1, b, terms, q + 4 * i, best_action + i, value + i);
+            if (best_action[i] == 255) value[i] = 0.0;
+            continue;
+        }
+        double best_q = 0.0;
+        int best_a = 255;
+        for (int a = 0; a < 4; ++a) {
+            uint8_t after[16];
+            const int64_t r = oracle_latent_state(b, a, after);
+            q[4 * i + a] = -INFINITY;
+            if (memcmp(after, b, 16) == 0) continue;
+            const int n_empty = oracle_count_empty(after);
+            double s2 = 0.0, s4 = 0.0;
+            for (int k = 0; k < n_empty; ++k) {
+                uint8_t o[16];
+                memcpy(o, after, 16);
+                oracle_fill_cell_kv(o, k, 1);
+                s2 = s2 + oracle_value_depth(o, depth - 1);
+                memcpy(o, after, 16);
+                oracle_fill_cell_kv(o, k, 2);
+                s4 = s4 + oracle_value_depth(o, depth - 1);
+            }
+            const double t2 = 0.9 * s2, t4 = 0.1 * s4, mix = t2 + t4, mean = mix / (double)n_empty;
+            q[4 * i + a] = (double)r + mean;
+            if (best_a == 255 || q[4 * i + a] > best_q) {
+                best_q = q[4 * i + a];
+                best_a = a;
+            }
+        }
+        best_action[i] = (uint8_t)best_a;
+        value[i] = best_a == 255 ? 0.0 : best_q;
+    }
+    return 0;
+}
+
 ORACLE_API int oracle_encode_onehot(uint64_t n, const uint8_t *boards, uint32_t width, uint8_t *out)
 {
     memset(out, 0, (size_t)n * 16 * width);

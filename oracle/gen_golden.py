@@ -368,6 +368,48 @@ def gen_expectimax_d2():
     return n, int((best == 255).sum()), float(np.nanmax(np.where(np.isfinite(q), q, np.nan)))
 
 
+def gen_expectimax_d3(count: int = 36):
+    """Depth-3 expectimax composed LITERALLY from the reference's functions (latent_state, after_state with ITS probabilities,
+    can_move), by plain recursion, float64, outcomes in after_state's order: Q3(s, a) = r + sum P(o) * V2(o),
+    V2(o) = max over legal a' of [r' + sum P(o') * best legal latent_state reward of o'].  Pins oracle_expectimax_depth /
+    the device back-up chain to ~1e-12 relative (the build sums 0.9 * S2 + 0.1 * S4 and divides once; the reference's
+    per-outcome products round differently) and the arg-max wherever it is not a near-tie."""
+    boards = np.load(OUT / 'chance_outcomes.npz')['boards']
+    pick = np.linspace(0, boards.shape[0] - 1, count).astype(int)
+    boards = boards[pick]
+
+    def legal(state, a):
+        return bool(ref_move.can_move(np.rot90(state, k=a)))
+
+    def value(state, depth):
+        best = None
+        for a in range(4):
+            if not legal(state, a):
+                continue
+            after, r = ref_board.latent_state(state, a)
+            q = float(r)
+            if depth > 1:
+                q += sum(pr * value(o, depth - 1) for o, pr in ref_board.after_state(after))
+            best = q if best is None or q > best else best
+        return 0.0 if best is None else best
+
+    n = boards.shape[0]
+    q = np.full((n, 4), -np.inf, dtype=np.float64)
+    best = np.full(n, 255, dtype=np.uint8)
+    val = np.zeros(n, dtype=np.float64)
+    for i in range(n):
+        state = to_values(boards[i]).reshape(4, 4)
+        for a in range(4):
+            if legal(state, a):
+                after, r = ref_board.latent_state(state, a)
+                q[i, a] = float(r) + sum(pr * value(o, 2) for o, pr in ref_board.after_state(after))
+        if np.isfinite(q[i]).any():
+            best[i] = int(np.argmax(q[i]))
+            val[i] = q[i, best[i]]
+    np.savez_compressed(OUT / 'expectimax_d3.npz', boards=boards, q=q, best=best, value=val)
+    return n, int((best == 255).sum()), float(val.max())
+
+
 def gen_random_play_stats(games: int = 3000):
     """Whole games of the reference engine under uniformly random actions with ITS OWN spawn RNG (seeded per step):
     the bitstream cannot be reproduced, the DISTRIBUTION of game length / score / max tile can -- it pins
@@ -407,6 +449,7 @@ def main():
     print('transforms', gen_transforms(rng))
     print('chance_outcomes', gen_chance_outcomes())
     print('expectimax_d2', gen_expectimax_d2())
+    print('expectimax_d3', gen_expectimax_d3())
     print('random_play_stats', gen_random_play_stats())
     with open(OUT / 'SHA256SUMS', 'w') as fh:
         for p in sorted(OUT.glob('*.npz')):

@@ -102,6 +102,10 @@ PROTOTYPES = {
     'env2048_chance_outcomes': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr]),
     'env2048_expectimax_ply': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
     'env2048_expectimax_depth2': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    'env2048_expand_count': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr]),
+    'env2048_expand': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    'env2048_expectimax_depth2_f64': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr]),
+    'env2048_expectimax_backup': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
     'env2048_status': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
     'env2048_encode_onehot': (_c_int, [_c_int, _ptr, _u64, _ptr, _u32, _ptr]),
     'env2048_pack_i32': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr]),
@@ -246,6 +250,18 @@ class Library:
 
     def expectimax_depth2(self, device, stream, n, boards, terms, q, best_action, value) -> None:
         self._check(self._dll.env2048_expectimax_depth2(device, stream, n, boards, terms, q, best_action, value))
+
+    def expand_count(self, device, stream, n, boards, counts) -> None:
+        self._check(self._dll.env2048_expand_count(device, stream, n, boards, counts))
+
+    def expand(self, device, stream, n, boards, offsets, children, reward, n_empty) -> None:
+        self._check(self._dll.env2048_expand(device, stream, n, boards, offsets, children, reward, n_empty))
+
+    def expectimax_depth2_f64(self, device, stream, n, boards, value) -> None:
+        self._check(self._dll.env2048_expectimax_depth2_f64(device, stream, n, boards, value))
+
+    def expectimax_backup(self, device, stream, n, reward, n_empty, offsets, child_value, value, q, best_action) -> None:
+        self._check(self._dll.env2048_expectimax_backup(device, stream, n, reward, n_empty, offsets, child_value, value, q, best_action))
 
     def status_i32(self, device, stream, n, boards, obs, legal4, done) -> None:
         self._check(self._dll.env2048_status_i32(device, stream, n, boards, obs, legal4, done))

@@ -1349,7 +1349,7 @@ __device__ __forceinline__ int32_t best_move_reward(const Board &bd)
 constexpr int D2_BLOCK = 256;
 
 __global__ __launch_bounds__(D2_BLOCK) void expectimax_depth2_kernel(uint64_t n, const uint8_t *boards, int32_t *terms, float *q,
-                                                                      uint8_t *best_action, float *value)
+                                                                      uint8_t *best_action, float *value, double *value64)
 {
     __shared__ __attribute__((aligned(16))) D2After strip_lds[D2_BLOCK / 64][64 * 4];
     __shared__ int32_t sums_lds[D2_BLOCK / 64][64 * 4][2];   // per (board, action): S2, S4
@@ -1489,6 +1489,126 @@ __global__ __launch_bounds__(D2_BLOCK) void expectimax_depth2_kernel(uint64_t n,
     if (q) reinterpret_cast<float4 *>(q)[mine] = make_float4(q4[0], q4[1], q4[2], q4[3]);
     if (best_action) best_action[mine] = (uint8_t)best_a;
     if (value) value[mine] = (float)best_q;
+    if (value64) value64[mine] = best_q;  // (0 / 1 = 0.0 for a terminal board)
+}
+
+// ---- depth-d expectimax (d >= 3): the tree is kept on the device as one dense FRONTIER per level -------------------------
+// expand: the children of a board are the (empty cell, tile) outcomes of its LEGAL afterstates, in the order (action, cell in
+// row-major rank, tile 2 then 4) [ref: gameboard.py:105-171 latent_state + after_state composed]; a count pass, an exclusive
+// prefix sum (host side: one torch.cumsum) and a write pass build the next level densely -- on mid-game boards 34 of the 128
+// possible children exist.  The deepest frontier is valued by the depth-2 kernel; the back-up kernel folds a level's child
+// values into its boards' values: Q(s, a) = r + (0.9 * S2 + 0.1 * S4) / num_empty with S2 / S4 summed in child order, every
+// operation a separate correctly rounded double operation (compiled with fp contract off), V = the first maximum over the legal actions.
+__device__ __forceinline__ void four_afterstates(const Board &bd, Board after[4], int32_t rewards[4], uint32_t &legal)
+{
+    uint32_t c0, c1, c2, c3, changed;
+    transpose4x4(bd.r0, bd.r1, bd.r2, bd.r3, c0, c1, c2, c3);
+    legal = 0u;
+    {
+        uint32_t a = c0, b = c1, c = c2, d = c3;
+        rewards[0] = (int32_t)slide_merge_planes(a, b, c, d, changed);
+        transpose4x4(a, b, c, d, after[0].r0, after[0].r1, after[0].r2, after[0].r3);
+        legal |= changed != 0u ? 1u : 0u;
+    }
+    {
+        uint32_t a = bd.r0, b = bd.r1, c = bd.r2, d = bd.r3;
+        rewards[1] = (int32_t)slide_merge_planes(a, b, c, d, changed);
+        after[1] = Board{a, b, c, d};
+        legal |= changed != 0u ? 2u : 0u;
+    }
+    {
+        uint32_t a = c3, b = c2, c = c1, d = c0;
+        rewards[2] = (int32_t)slide_merge_planes(a, b, c, d, changed);
+        transpose4x4(d, c, b, a, after[2].r0, after[2].r1, after[2].r2, after[2].r3);
+        legal |= changed != 0u ? 4u : 0u;
+    }
+    {
+        uint32_t a = bd.r3, b = bd.r2, c = bd.r1, d = bd.r0;
+        rewards[3] = (int32_t)slide_merge_planes(a, b, c, d, changed);
+        after[3] = Board{d, c, b, a};
+        legal |= changed != 0u ? 8u : 0u;
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void expand_count_kernel(uint64_t n, const uint8_t *boards, uint32_t *counts)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    Board after[4];
+    int32_t rewards[4];
+    uint32_t legal;
+    four_afterstates(load_board(boards, i), after, rewards, legal);
+    uint32_t count = 0u;
+#pragma unroll
+    for (uint32_t act = 0; act < 4u; ++act)
+        if ((legal >> act) & 1u) count += 2u * ENV2048_POPC(empty_mask(after[act]));
+    counts[i] = count;
+}
+
+__global__ __launch_bounds__(BLOCK) void expand_kernel(uint64_t n, const uint8_t *boards, const uint64_t *offsets, uint8_t *children,
+                                                       int32_t *reward, uint8_t *n_empty)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    Board after[4];
+    int32_t rewards[4];
+    uint32_t legal;
+    four_afterstates(load_board(boards, i), after, rewards, legal);
+    uint64_t at = offsets[i];
+#pragma unroll
+    for (uint32_t act = 0; act < 4u; ++act) {
+        const bool ok = ((legal >> act) & 1u) != 0u;
+        const uint32_t empt = ok ? empty_mask(after[act]) : 0u;  // a legal move always leaves an empty cell
+        const uint32_t ne = ENV2048_POPC(empt);
+        reward[4 * i + act] = ok ? rewards[act] : 0;
+        n_empty[4 * i + act] = (uint8_t)ne;  // 0 = illegal action
+        for (uint32_t k = 0; k < ne; ++k) {
+            const uint32_t bit = kth_empty(empt, k);
+            Board two = after[act], four = after[act];
+            place_tile(two, bit, false);
+            place_tile(four, bit, true);
+            store_board(children, at, two);
+            store_board(children, at + 1u, four);
+            at += 2u;
+        }
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void expectimax_backup_kernel(uint64_t n, const int32_t *reward, const uint8_t *n_empty,
+                                                                  const uint64_t *offsets, const double *child_value, double *value,
+                                                                  double *q, uint8_t *best_action)
+{
+#pragma clang fp contract(off)  // plain operators below, created under contract(off): no fma for 0.9 * S2 + 0.1 * S4 (HIP's __dmul_rn /
+    // __dadd_rn are inline functions built under the default mode -- inlined, their multiply and add DO fuse)
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    uint64_t at = offsets[i];
+    double best_q = 0.0;
+    uint32_t best_a = 255u;
+#pragma unroll
+    for (uint32_t act = 0; act < 4u; ++act) {
+        const uint32_t ne = n_empty[4 * i + act];
+        double qa = -__builtin_inf();
+        if (ne) {
+            double s2 = 0.0, s4 = 0.0;
+            for (uint32_t k = 0; k < ne; ++k) {
+                s2 = s2 + child_value[at];
+                s4 = s4 + child_value[at + 1u];
+                at += 2u;
+            }
+            const double t2 = 0.9 * s2, t4 = 0.1 * s4;
+            const double mix = t2 + t4;
+            const double mean = mix / (double)ne;
+            qa = (double)reward[4 * i + act] + mean;
+            if (best_a == 255u || qa > best_q) {
+                best_q = qa;
+                best_a = act;
+            }
+        }
+        if (q) q[4 * i + act] = qa;
+    }
+    value[i] = best_a == 255u ? 0.0 : best_q;
+    if (best_action) best_action[i] = (uint8_t)best_a;
 }
 
 __global__ __launch_bounds__(BLOCK) void spawn_kernel(uint64_t n, uint8_t *boards, const uint8_t *spawn_k,
@@ -2775,8 +2895,63 @@ int env2048_expectimax_depth2(int device, void *stream, uint64_t n, const uint8_
     DeviceScope scope(device);
     if (scope.rc) return scope.rc;
     hipLaunchKernelGGL(expectimax_depth2_kernel, dim3((unsigned)((n + D2_BLOCK - 1) / D2_BLOCK)), dim3(D2_BLOCK), 0, (hipStream_t)stream, n,
-                       boards, terms, q, best_action, value);
+                       boards, terms, q, best_action, value, static_cast<double *>(nullptr));
     return launched("env2048_expectimax_depth2 launch");
+}
+
+int env2048_expectimax_depth2_f64(int device, void *stream, uint64_t n, const uint8_t *boards, double *value)
+{
+    if (n == 0) return ENV2048_OK;
+    if (!boards || !value) return fail(ENV2048_ERR_INVALID_ARG, "env2048_expectimax_depth2_f64: NULL argument");
+    if (misaligned(boards, 16) || misaligned(value, 8)) return fail(ENV2048_ERR_ALIGNMENT, "env2048_expectimax_depth2_f64: boards must be 16-byte, value 8-byte aligned");
+    if (int rc = check_count(n)) return rc;
+    DeviceScope scope(device);
+    if (scope.rc) return scope.rc;
+    hipLaunchKernelGGL(expectimax_depth2_kernel, dim3((unsigned)((n + D2_BLOCK - 1) / D2_BLOCK)), dim3(D2_BLOCK), 0, (hipStream_t)stream, n,
+                       boards, static_cast<int32_t *>(nullptr), static_cast<float *>(nullptr), static_cast<uint8_t *>(nullptr),
+                       static_cast<float *>(nullptr), value);
+    return launched("env2048_expectimax_depth2_f64 launch");
+}
+
+int env2048_expand_count(int device, void *stream, uint64_t n, const uint8_t *boards, uint32_t *counts)
+{
+    if (n == 0) return ENV2048_OK;
+    if (!boards || !counts) return fail(ENV2048_ERR_INVALID_ARG, "env2048_expand_count: NULL argument");
+    if (misaligned(boards, 16) || misaligned(counts, 4)) return fail(ENV2048_ERR_ALIGNMENT, "env2048_expand_count: boards must be 16-byte, counts 4-byte aligned");
+    if (int rc = check_count(n)) return rc;
+    DeviceScope scope(device);
+    if (scope.rc) return scope.rc;
+    hipLaunchKernelGGL(expand_count_kernel, grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, n, boards, counts);
+    return launched("env2048_expand_count launch");
+}
+
+int env2048_expand(int device, void *stream, uint64_t n, const uint8_t *boards, const uint64_t *offsets, uint8_t *children, int32_t *reward,
+                   uint8_t *n_empty)
+{
+    if (n == 0) return ENV2048_OK;
+    if (!boards || !offsets || !reward || !n_empty) return fail(ENV2048_ERR_INVALID_ARG, "env2048_expand: boards, offsets, reward and n_empty are required");
+    if (misaligned(boards, 16) || misaligned(children, 16) || misaligned(offsets, 8) || misaligned(reward, 4))
+        return fail(ENV2048_ERR_ALIGNMENT, "env2048_expand: boards / children must be 16-byte, offsets 8-byte, reward 4-byte aligned");
+    if (int rc = check_count(n)) return rc;
+    DeviceScope scope(device);
+    if (scope.rc) return scope.rc;
+    hipLaunchKernelGGL(expand_kernel, grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, n, boards, offsets, children, reward, n_empty);
+    return launched("env2048_expand launch");
+}
+
+int env2048_expectimax_backup(int device, void *stream, uint64_t n, const int32_t *reward, const uint8_t *n_empty, const uint64_t *offsets,
+                              const double *child_value, double *value, double *q, uint8_t *best_action)
+{
+    if (n == 0) return ENV2048_OK;
+    if (!reward || !n_empty || !offsets || !value) return fail(ENV2048_ERR_INVALID_ARG, "env2048_expectimax_backup: reward, n_empty, offsets and value are required");
+    if (misaligned(reward, 4) || misaligned(offsets, 8) || misaligned(child_value, 8) || misaligned(value, 8) || misaligned(q, 8))
+        return fail(ENV2048_ERR_ALIGNMENT, "env2048_expectimax_backup: misaligned array");
+    if (int rc = check_count(n)) return rc;
+    DeviceScope scope(device);
+    if (scope.rc) return scope.rc;
+    hipLaunchKernelGGL(expectimax_backup_kernel, grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, n, reward, n_empty, offsets, child_value,
+                       value, q, best_action);
+    return launched("env2048_expectimax_backup launch");
 }
 
 int env2048_encode_onehot(int device, void *stream, uint64_t n, const uint8_t *boards, uint32_t width, uint8_t *out)

@@ -160,6 +160,69 @@ def expectimax_depth2(boards: torch.Tensor, *, want_terms: bool = False, rt=None
     return out
 
 
+def expand(boards: torch.Tensor, rt=None) -> dict:
+    """One level of the search tree, densely: the children of every board (the (empty cell, tile) outcomes of its legal
+    afterstates, in the order action / cell rank / tile 2, 4) as the next frontier.  -> dict(children (total, 16) u8,
+    offsets (n,) int64 = first child of every board, reward (n, 4) i32, n_empty (n, 4) u8 (0 = illegal action)).
+    env2048_expand_count -> exclusive prefix sum -> env2048_expand; reading the total back is the one synchronisation."""
+    rt = rt or runtime.current()
+    n = boards.shape[0]
+    if n == 0:
+        return {'children': torch.empty((0, 16), dtype=torch.uint8, device=rt.device), 'offsets': torch.empty((0,), dtype=torch.int64, device=rt.device),
+                'reward': torch.empty((0, 4), dtype=torch.int32, device=rt.device), 'n_empty': torch.empty((0, 4), dtype=torch.uint8, device=rt.device)}
+    dev, stream = rt.handles()
+    counts = torch.empty((n,), dtype=torch.int32, device=rt.device)
+    rt.lib.expand_count(dev, stream, n, _p(boards), _p(counts))
+    ends = torch.cumsum(counts, dim=0, dtype=torch.int64)
+    offsets = ends - counts
+    total = int(ends[-1])
+    out = {'children': torch.empty((total, 16), dtype=torch.uint8, device=rt.device), 'offsets': offsets,
+           'reward': torch.empty((n, 4), dtype=torch.int32, device=rt.device), 'n_empty': torch.empty((n, 4), dtype=torch.uint8, device=rt.device)}
+    rt.lib.expand(dev, stream, n, _p(boards), _p(offsets), _p(out['children']) if total else None, _p(out['reward']), _p(out['n_empty']))
+    return out
+
+
+def expectimax(boards: torch.Tensor, depth: int, rt=None) -> dict:
+    """Depth-d expectimax of the true environment (d >= 2) with the tree kept on the device: d - 2 expansions into dense
+    frontiers (about 34 children per mid-game board and level), the depth-2 kernel on the deepest frontier, d - 2 back-ups.
+    -> dict(q (n,4) f64, -inf for illegal actions; best (n,) u8, 255 = terminal; value (n,) f64, 0 for a terminal board;
+    frontier = boards per level).  Memory: 16 B per frontier board -- 2^12 roots at depth 4 are about 5 million leaves."""
+    if depth < 2:
+        raise ValueError('expectimax depth must be >= 2')
+    rt = rt or runtime.current()
+    dev, stream = rt.handles()
+    levels, frontier, sizes = [], boards, [boards.shape[0]]
+    for _ in range(depth - 2):
+        level = expand(frontier, rt=rt)
+        levels.append((frontier.shape[0], level))
+        frontier = level['children']
+        sizes.append(frontier.shape[0])
+    m = frontier.shape[0]
+    value = torch.empty((m,), dtype=torch.float64, device=rt.device)
+    if depth == 2:
+        terms = torch.empty((m, 4, 4), dtype=torch.int32, device=rt.device)
+        best = torch.empty((m,), dtype=torch.uint8, device=rt.device)
+        rt.lib.expectimax_depth2(dev, stream, m, _p(frontier), _p(terms), None, _p(best), None)
+        t = terms.to(torch.int64)
+        d = 10 * t[..., 3]
+        q = torch.where(t[..., 3] > 0, (d * t[..., 0] + 9 * t[..., 1] + t[..., 2]).double() / d.clamp(min=1).double(),
+                        torch.full((), float('-inf'), dtype=torch.float64, device=rt.device))
+        value = torch.where(best != 255, q.max(dim=1).values, torch.zeros((), dtype=torch.float64, device=rt.device))
+        return {'q': q, 'best': best, 'value': value, 'frontier': sizes}
+    if m:
+        rt.lib.expectimax_depth2_f64(dev, stream, m, _p(frontier), _p(value))
+    q = best = None
+    for k, (n_level, level) in reversed(list(enumerate(levels))):
+        parent = torch.empty((n_level,), dtype=torch.float64, device=rt.device)
+        if k == 0:
+            q = torch.empty((n_level, 4), dtype=torch.float64, device=rt.device)
+            best = torch.empty((n_level,), dtype=torch.uint8, device=rt.device)
+        rt.lib.expectimax_backup(dev, stream, n_level, _p(level['reward']), _p(level['n_empty']), _p(level['offsets']),
+                                 _p(value) if value.numel() else None, _p(parent), _p(q) if k == 0 else None, _p(best) if k == 0 else None)
+        value = parent
+    return {'q': q, 'best': best, 'value': value, 'frontier': sizes}
+
+
 def onehot(boards: torch.Tensor, width: int = 31, rt=None) -> torch.Tensor:
     rt = rt or runtime.current()
     n = boards.shape[0]

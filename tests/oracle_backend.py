@@ -319,6 +319,72 @@ class OracleLibrary:
         if value is not None:
             _view(value, n, np.float32)[:] = res['value'].astype(np.float32)
 
+    # ---- depth-d expectimax building blocks (restated with the oracle's afterstates; children in (action, cell, tile) order) ----
+    def _afterstates(self, boards, n):
+        b = _view(boards, n * 16, np.uint8).reshape(n, 16).copy()
+        return b, [oracle.afterstate_batch(b, np.full(n, a, dtype=np.uint8)) for a in range(4)]
+
+    def expand_count(self, device, stream, n, boards, counts):
+        self.calls.append(('expand_count', n))
+        _, after = self._afterstates(boards, n)
+        c = np.zeros(n, dtype=np.uint32)
+        for a in range(4):
+            c += (2 * after[a]['changed'].astype(np.uint32) * (after[a]['boards'] == 0).sum(axis=1).astype(np.uint32))
+        _view(counts, n, np.uint32)[:] = c
+
+    def expand(self, device, stream, n, boards, offsets, children, reward, n_empty):
+        self.calls.append(('expand', n))
+        _, after = self._afterstates(boards, n)
+        off = _view(offsets, n, np.int64)
+        rw, ne = _view(reward, n * 4, np.int32).reshape(n, 4), _view(n_empty, n * 4, np.uint8).reshape(n, 4)
+        total = 0
+        for i in range(n):
+            total += sum(2 * int((after[a]['boards'][i] == 0).sum()) for a in range(4) if after[a]['changed'][i])
+        kids = _view(children, total * 16, np.uint8).reshape(total, 16) if total else None
+        for i in range(n):
+            at = int(off[i])
+            for a in range(4):
+                ok = bool(after[a]['changed'][i])
+                cells = np.flatnonzero(after[a]['boards'][i] == 0) if ok else []
+                rw[i, a] = int(after[a]['reward'][i]) if ok else 0
+                ne[i, a] = len(cells)
+                for cell in cells:  # row-major rank order
+                    for e in (1, 2):
+                        kids[at] = after[a]['boards'][i]
+                        kids[at, cell] = e
+                        at += 1
+
+    def expectimax_depth2_f64(self, device, stream, n, boards, value):
+        self.calls.append(('expectimax_depth2_f64', n))
+        res = oracle.expectimax_depth2(_view(boards, n * 16, np.uint8).reshape(n, 16).copy())
+        _view(value, n, np.float64)[:] = np.where(res['best'] == 255, 0.0, res['value'])
+
+    def expectimax_backup(self, device, stream, n, reward, n_empty, offsets, child_value, value, q, best_action):
+        self.calls.append(('expectimax_backup', n))
+        rw, ne = _view(reward, n * 4, np.int32).reshape(n, 4), _view(n_empty, n * 4, np.uint8).reshape(n, 4)
+        off = _view(offsets, n, np.int64)
+        total = int(ne.astype(np.int64).sum()) * 2
+        cv = _view(child_value, total, np.float64) if total else None
+        val = _view(value, n, np.float64)
+        for i in range(n):
+            at, best_q, best_a = int(off[i]), 0.0, 255
+            for a in range(4):
+                qa = float('-inf')
+                if ne[i, a]:
+                    s2 = s4 = 0.0
+                    for k in range(int(ne[i, a])):
+                        s2 = s2 + float(cv[at])
+                        s4 = s4 + float(cv[at + 1])
+                        at += 2
+                    qa = float(rw[i, a]) + (0.9 * s2 + 0.1 * s4) / float(ne[i, a])
+                    if best_a == 255 or qa > best_q:
+                        best_q, best_a = qa, a
+                if q is not None:
+                    _view(q, n * 4, np.float64)[4 * i + a] = qa
+            val[i] = 0.0 if best_a == 255 else best_q
+            if best_action is not None:
+                _view(best_action, n, np.uint8)[i] = best_a
+
     def status_i32(self, device, stream, n, boards, obs, legal4, done):
         self.calls.append(('status_i32', n))
         res = oracle.status_batch(oracle.pack_values(_view(boards, n * 16, np.int32)).reshape(n, 16))

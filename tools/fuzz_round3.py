@@ -23,7 +23,7 @@ lib = capi.library()
 rng = np.random.default_rng(int(time.time()))
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 t0 = last = time.time()
-counts = {'mirrors': 0, 'step_many': 0, 'records': 0, 'shared_launches': 0, 'keyed_status': 0, 'depth2': 0, 'random_actions': 0, 'two_chains': 0}
+counts = {'depth_d': 0, 'mirrors': 0, 'step_many': 0, 'records': 0, 'shared_launches': 0, 'keyed_status': 0, 'depth2': 0, 'random_actions': 0, 'two_chains': 0}
 S = lambda: torch.cuda.current_stream().cuda_stream
 P = lambda t: None if t is None else t.data_ptr()
 SIZES = [1, 2, 63, 64, 65, 255, 256, 257, 2047, 2048, 2049, 4096, 8191]
@@ -178,6 +178,22 @@ def fuzz_depth2():
     counts['depth2'] += 1
 
 
+def fuzz_depth_d():
+    """ops.expectimax at depth 3 (sometimes 4) on a few random boards: dense frontiers + depth-2 kernel + back-ups == the oracle's
+    recursion, bit for bit."""
+    from simulate_2048_amd import ops, runtime
+
+    depth = 4 if rng.random() < 0.15 else 3
+    n = int(rng.integers(1, 5 if depth == 4 else 40))
+    boards = boards_for(n)
+    out = ops.expectimax(torch.from_numpy(boards).cuda(), depth, rt=runtime.Runtime(lib, 'cuda:0'))
+    ref = oracle.expectimax_depth(boards, depth)
+    np.testing.assert_array_equal(out['q'].cpu().numpy(), ref['q'])
+    np.testing.assert_array_equal(out['best'].cpu().numpy(), ref['best'])
+    np.testing.assert_array_equal(out['value'].cpu().numpy(), ref['value'])
+    counts['depth_d'] += 1
+
+
 def fuzz_random_actions():
     n = int(rng.choice(SIZES + [int(rng.integers(1, 5000))]))
     base, seed, step = int(rng.choice([0, 1, 3, int(rng.integers(0, 1 << 40))])), int(rng.integers(0, 1 << 62)), int(rng.integers(0, 1 << 40))
@@ -222,7 +238,7 @@ def fuzz_two_chains():
     counts['two_chains'] += 1
 
 
-CASES = [(fuzz_step_many, 10), (fuzz_mirrors, 3), (fuzz_keyed_status, 3), (fuzz_depth2, 3), (fuzz_random_actions, 2), (fuzz_two_chains, 1)]
+CASES = [(fuzz_step_many, 10), (fuzz_mirrors, 3), (fuzz_keyed_status, 3), (fuzz_depth2, 3), (fuzz_depth_d, 2), (fuzz_random_actions, 2), (fuzz_two_chains, 1)]
 weights = np.array([w for _, w in CASES], dtype=float)
 weights /= weights.sum()
 while time.time() - t0 < budget:
