@@ -217,8 +217,9 @@ def expectimax(boards: torch.Tensor, depth: int, rt=None) -> dict:
         if k == 0:
             q = torch.empty((n_level, 4), dtype=torch.float64, device=rt.device)
             best = torch.empty((n_level,), dtype=torch.uint8, device=rt.device)
-        rt.lib.expectimax_backup(dev, stream, n_level, _p(level['reward']), _p(level['n_empty']), _p(level['offsets']),
-                                 _p(value) if value.numel() else None, _p(parent), _p(q) if k == 0 else None, _p(best) if k == 0 else None)
+        if n_level:
+            rt.lib.expectimax_backup(dev, stream, n_level, _p(level['reward']), _p(level['n_empty']), _p(level['offsets']),
+                                     _p(value) if value.numel() else None, _p(parent), _p(q) if k == 0 else None, _p(best) if k == 0 else None)
         value = parent
     return {'q': q, 'best': best, 'value': value, 'frontier': sizes}
 

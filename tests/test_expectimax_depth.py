@@ -128,3 +128,12 @@ def test_depth3_at_scale_matches_the_oracle():
     with pytest.raises(capi.Env2048Error) as e:
         lib.expectimax_depth2_f64(0, s, n, boards.data_ptr(), v.data_ptr() + 4)
     assert e.value.code == capi.ERR_ALIGNMENT
+
+
+def test_all_terminal_roots_have_empty_frontiers(api_runtime):
+    """Roots without a legal move: every frontier is empty, nothing is launched on it, values are 0 and best is 255."""
+    b = np.tile(np.array([1, 2, 1, 2, 2, 1, 2, 1, 1, 2, 1, 2, 2, 1, 2, 1], dtype=np.uint8), (5, 1))
+    out = ops.expectimax(torch.from_numpy(b).to(api_runtime.device), 4)
+    assert out['frontier'] == [5, 0, 0]
+    assert (out['best'].cpu().numpy() == 255).all() and not out['value'].cpu().numpy().any()
+    assert np.isneginf(out['q'].cpu().numpy()).all()
