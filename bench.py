@@ -58,7 +58,8 @@ INFINITY_CACHE_BYTES = 256 << 20
 # every SIMD.  The fallback is the figure of the committed table (2.85 cycles per instruction -> 862 G wave-instr/s).
 VALU_PEAK_GINSTR_FALLBACK = 256 * 4 * 2.4 / 2.85
 SEED = 0x2048
-KERNEL_SOURCES = ['simulate_2048_amd/csrc/env2048_kernels.hip', 'simulate_2048_amd/csrc/board_ops.hpp']
+KERNEL_SOURCES = ['simulate_2048_amd/csrc/' + name for name in ('step_kernels.hip', 'board_ops.hpp', 'board_io.hpp', 'philox_strip.hpp',
+                                                                  'tiling.hpp', 'step_planner.hpp')]
 
 
 def parse_args(argv=None):
@@ -233,10 +234,10 @@ def cpu_baseline(boards_np, seconds: float):
 
 
 def kernel_source_sha() -> str:
-    """Hash of what the step kernel is built from: board_ops.hpp and the regions of env2048_kernels.hip between the
-    [step-kernel-source-begin] / [step-kernel-source-end] markers (device code of step_kernel and its host launch policy),
-    with comments and whitespace removed.  Edits to other kernels of the file, or to comments, do not invalidate the
-    committed counters."""
+    """Hash of what the step kernel is built from: the regions of step_kernels.hip and of the headers it is made of
+    (KERNEL_SOURCES) between the [step-kernel-source-begin] / [step-kernel-source-end] markers (device code of step_kernel
+    and its host launch policy), with comments and whitespace removed.  Edits to the other kernel families, or to comments,
+    do not invalidate the committed counters."""
     import re
 
     h = hashlib.sha256()

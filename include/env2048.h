@@ -13,7 +13,8 @@
  *     "Device pointer" means device-ACCESSIBLE: pinned (hipHostMalloc) host memory is as good wherever a few hundred bytes
  *     move -- the mirrors stage small key / action arrays through it and env2048_*_mirrored write result copies into it.
  *     The only process-lifetime state is per device and independent of any batch: one internal stream, one helper thread
- *     and two events, created by the first env2048_step_sequence call that runs as two chains (see there).
+ *     and two events, created by the first env2048_step_sequence call that runs as two chains (see there, and "The helper
+ *     thread" below it for what that thread costs and how to switch its polling off).
  *   - `stream` is a hipStream_t (NULL = the device's default stream).  Calls are ASYNCHRONOUS on
  *     that stream; the caller synchronises.  Entry points are re-entrant and thread-safe.
  *   - Return value: 0 (ENV2048_OK) or a negative error code; env2048_last_error() returns a
@@ -60,7 +61,7 @@ extern "C" {
 #define ENV2048_EXPORT
 #endif
 
-#define ENV2048_ABI_VERSION 3
+#define ENV2048_ABI_VERSION 4
 
 #define ENV2048_OK 0
 #define ENV2048_ERR_INVALID_ARG (-1) /* NULL required pointer, bad flag bits */
@@ -154,7 +155,9 @@ ENV2048_EXPORT int env2048_step(int device, void *stream, uint64_t n, uint64_t e
  * stop being bound by the launch rate.  Dependent records (the same boards stepped K times) are launched one by one, in
  * order, as before.  The decision depends on the records alone (addresses, sizes, flags); env2048_step_many_plan reports
  * it.  Tiling and store policy of a shared launch follow the size rules of env2048_step applied to the launch's TOTAL
- * board count.
+ * board count.  A record with n == 0 is a no-op wherever it stands -- any number of them, leading, trailing or between
+ * live records: it enqueues nothing and neither joins nor separates its neighbours (only its flags / reserved field are
+ * validated); planning is one pass over the records and terminates on every input.
  */
 typedef struct env2048_step_args {
     uint64_t n, env_base;
@@ -224,6 +227,32 @@ ENV2048_EXPORT int env2048_step_sequence_plan(uint64_t n, uint32_t count, uint32
 ENV2048_EXPORT int env2048_step_sequence(int device, void *stream, uint64_t n, uint64_t env_base, uint8_t *boards,
                                          const uint8_t *const *actions, int32_t *reward, uint8_t *done, uint8_t *legal, void *obs,
                                          uint64_t row_stride, uint64_t seed, uint64_t step_index, uint32_t count, uint32_t flags);
+
+/*
+ * The helper thread (what a maintainer embedding the library needs to know).
+ *   - Exists only after the first env2048_step_sequence call on a device that ran as two chains; a process that never makes
+ *     such a call (or passes ENV2048_FLAG_SINGLE_CHAIN every time) has no extra thread, stream or event.  One per device,
+ *     detached, never joined; a child created by fork() does not inherit it and creates its own on its first split call.
+ *   - What it does: enqueues the second chain's `count` launches on the internal stream while the caller's thread enqueues
+ *     the first chain.  It never synchronises with the GPU and touches none of the caller's memory.
+ *   - Poll window: after a job it polls (a `pause` loop on one atomic flag) for the next one for ENV2048_HELPER_SPIN_US
+ *     microseconds -- an environment variable read once when the process's first helper is created; default 300, 0 = go to
+ *     sleep at once, capped at 100 000 -- and then sleeps on a condition variable.  While polling it occupies one hardware
+ *     thread: a stepping loop that calls every few microseconds keeps it busy all the time (one core per device in use),
+ *     an idle process pays nothing after the window.  With 0 every call pays a futex wake-up (tens of microseconds) instead,
+ *     which only long sequences amortise.  CPU-pinned callers (one core per worker) should set 0 or SINGLE_CHAIN.
+ *   - Concurrency: split calls on one device are serialised by a mutex held from posting the second chain until it has
+ *     been enqueued, so two threads stepping different batches on the same device are served one after the other (each
+ *     call still returns as soon as its own launches are enqueued); calls on different devices do not interact.
+ *   - env2048_helper_stats reports what the helper of `device` has cost so far: created (0/1), spin_us (the window in
+ *     force), jobs served, and cpu_ns = thread CPU time consumed (CLOCK_THREAD_CPUTIME_ID, sampled after every job and
+ *     poll window).  It makes no device call.  bench.py prints it for the K = 200 leg.
+ */
+typedef struct env2048_helper_info {
+    uint32_t created, spin_us;
+    uint64_t jobs, cpu_ns;
+} env2048_helper_info;
+ENV2048_EXPORT int env2048_helper_stats(int device, env2048_helper_info *out);
 
 /*
  * The reinforce/game form of one transition, fused: boards are int32 tile VALUES (n x 16, in

@@ -1,18 +1,30 @@
-"""Compile the HIP kernels + C-ABI into simulate_2048_amd/lib/libenv2048.so (gfx950 only)."""
+"""Compile the HIP kernels + C-ABI into simulate_2048_amd/lib/libenv2048.so (gfx950 only).
+
+One translation unit per kernel family (csrc/*.hip), compiled side by side and linked into one shared library; there are no
+device calls across translation units, so no relocatable device code is needed."""
 
 from __future__ import annotations
 
 import os
 import shutil
 import subprocess
+import tempfile
+from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
 REPO = PKG.parent
-SOURCES = [PKG / 'csrc' / 'env2048_kernels.hip']
-HEADERS = [PKG / 'csrc' / 'board_ops.hpp', REPO / 'include' / 'env2048.h']
+CSRC = PKG / 'csrc'
+SOURCES = [CSRC / name for name in ('step_kernels.hip', 'rollout_kernels.hip', 'state_i32_kernels.hip', 'search_kernels.hip',
+                                    'transform_kernels.hip')]
+HEADERS = sorted(CSRC.glob('*.hpp')) + [REPO / 'include' / 'env2048.h']
 LIB = PKG / 'lib' / 'libenv2048.so'
 ARCH = 'gfx950'
+COMMON_FLAGS = [f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden', '-pthread', '-DENV2048_BUILDING',
+                f'-I{REPO / "include"}', f'-I{CSRC}', '-Wall', '-Wno-unused-function',
+                # leading kernel arguments arrive in SGPRs with the wave instead of through an s_load (gfx950 kernarg
+                # preload; the code object keeps the s_load prologue as the fallback for firmware without it)
+                '-mllvm', '-amdgpu-kernarg-preload-count=16']
 
 
 def hipcc() -> str:
@@ -29,29 +41,45 @@ def needs_build() -> bool:
     return LIB.stat().st_mtime < newest
 
 
-def build_library(force: bool = False, verbose: bool = False, extra_flags: list[str] | None = None) -> Path:
-    """hipcc --offload-arch=gfx950 -shared -fPIC ... -> lib/libenv2048.so. Cross-compiles without a GPU."""
-    if not force and not needs_build():
-        return LIB
-    LIB.parent.mkdir(exist_ok=True)
-    tmp = LIB.with_suffix('.so.tmp%d' % os.getpid())
-    cmd = [hipcc(), f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-shared', '-fPIC', '-fvisibility=hidden',
-           '-pthread', '-DENV2048_BUILDING', f'-I{REPO / "include"}', f'-I{PKG / "csrc"}', '-Wall', '-Wno-unused-function',
-           # leading kernel arguments arrive in SGPRs with the wave instead of through an s_load (gfx950 kernarg
-           # preload; the code object keeps the s_load prologue as the fallback for firmware without it)
-           '-mllvm', '-amdgpu-kernarg-preload-count=16']
-    cmd += extra_flags or []
-    cmd += [str(s) for s in SOURCES] + ['-o', str(tmp)]
+def _run(cmd: list[str], verbose: bool) -> None:
     proc = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or proc.returncode != 0:
         print(' '.join(cmd))
         print(proc.stdout + proc.stderr)
     if proc.returncode != 0:
-        tmp.unlink(missing_ok=True)
         raise RuntimeError('hipcc failed:\n' + proc.stderr)
-    os.replace(tmp, LIB)
-    return LIB
+
+
+def build_library(force: bool = False, verbose: bool = False, extra_flags: list[str] | None = None, out: Path | None = None) -> Path:
+    """hipcc --offload-arch=gfx950 -c csrc/*.hip (in parallel) + one -shared link -> lib/libenv2048.so (or `out`, for the
+    experiment builds of tools/build_exp.sh).  Cross-compiles without a GPU."""
+    target = Path(out) if out else LIB
+    if not force and out is None and not needs_build():
+        return LIB
+    target.parent.mkdir(exist_ok=True)
+    flags = COMMON_FLAGS + (extra_flags or [])
+    with tempfile.TemporaryDirectory(prefix='env2048_build_') as tmpdir:
+        objects = [Path(tmpdir) / (s.stem + '.o') for s in SOURCES]
+        with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:
+            jobs = [pool.submit(_run, [hipcc(), *flags, '-c', str(s), '-o', str(o)], verbose) for s, o in zip(SOURCES, objects)]
+            for job in jobs:
+                job.result()
+        tmp = target.with_suffix('.so.tmp%d' % os.getpid())
+        try:
+            _run([hipcc(), f'--offload-arch={ARCH}', '-shared', '-fPIC', '-pthread', *[str(o) for o in objects], '-o', str(tmp)], verbose)
+            os.replace(tmp, target)
+        finally:
+            tmp.unlink(missing_ok=True)
+    return target
 
 
 if __name__ == '__main__':
-    print(build_library(force=True, verbose=True))
+    import sys
+
+    args = sys.argv[1:]
+    out_path = None
+    if '--out' in args:
+        i = args.index('--out')
+        out_path = Path(args[i + 1])
+        del args[i:i + 2]
+    print(build_library(force=True, verbose=True, extra_flags=args, out=out_path))

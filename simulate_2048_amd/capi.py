@@ -12,7 +12,7 @@ from __future__ import annotations
 import ctypes
 from pathlib import Path
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 OK = 0
 ERR_INVALID_ARG = -1
@@ -56,6 +56,12 @@ class Episode(ctypes.Structure):
                 ('reserved', ctypes.c_uint16), ('total_reward', ctypes.c_double)]
 
 
+class HelperInfo(ctypes.Structure):
+    """``env2048_helper_info`` of include/env2048.h: what the library's helper thread of one device has cost so far."""
+
+    _fields_ = [('created', _u32), ('spin_us', _u32), ('jobs', _u64), ('cpu_ns', _u64)]
+
+
 EPISODES_FROZEN = 1
 EPISODES_REWARD_F32 = 2
 ROLLOUT_STATS_WORDS = 40
@@ -76,6 +82,7 @@ PROTOTYPES = {
     'env2048_advance_counter': (_c_int, [_c_int, _ptr, _ptr, _u64]),
     'env2048_step_sequence': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, ctypes.POINTER(_ptr), _ptr, _ptr, _ptr, _ptr, _u64, _u64, _u64,
                                         _u32, _u32]),
+    'env2048_helper_stats': (_c_int, [_c_int, ctypes.POINTER(HelperInfo)]),
     'env2048_step_state_i32': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _u64, _u64]),
     'env2048_step_state_i32_to': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _u64,
                                             _u64]),
@@ -205,6 +212,13 @@ class Library:
         """``actions``: None or a ctypes array ``(c_void_p * count)`` of device pointers, one per step."""
         self._check(self._dll.env2048_step_sequence(device, stream, n, env_base, boards, actions, reward, done, legal, obs,
                                                     row_stride, seed, step_index, count, flags))
+
+    def helper_stats(self, device: int) -> dict:
+        """The helper thread of ``device`` (env2048_step_sequence's second chain): {'created', 'spin_us', 'jobs', 'cpu_ns'}.
+        No device call."""
+        info = HelperInfo()
+        self._check(self._dll.env2048_helper_stats(device, ctypes.byref(info)))
+        return {'created': bool(info.created), 'spin_us': info.spin_us, 'jobs': info.jobs, 'cpu_ns': info.cpu_ns}
 
     def step_state_i32(self, device, stream, n, env_base, boards, actions, step_count, done_io, total_reward, reward, max_tile,
                        seed, step_index) -> None:

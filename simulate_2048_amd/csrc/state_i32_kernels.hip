@@ -1,0 +1,301 @@
+// state_i32_kernels.hip -- the reinforce/game GameState API on int32 value boards (one launch per env.py call) and its
+// C-ABI entry points of include/env2048.h.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "env2048.h"
+#include "board_ops.hpp"
+#include "board_io.hpp"
+#include "tiling.hpp"
+#include "device_scope.hpp"
+
+using namespace env2048;
+using namespace env2048::host;
+
+namespace {
+// reinforce/game step on int32 value boards, everything of env.py:79-133 in one launch (one board
+// per lane; a compatibility path for the JAX-shaped API, not the throughput path).
+__device__ __forceinline__ uint32_t pack4(int4 v)
+{
+    auto e = [](int x) -> uint32_t { return x > 0 ? (uint32_t)(31 - __clz(x)) : 0u; };
+    return e(v.x) | (e(v.y) << 8) | (e(v.z) << 16) | (e(v.w) << 24);
+}
+__device__ __forceinline__ int4 unpack4(uint32_t r)
+{
+    auto v = [](uint32_t e) -> int { return e ? (int)(1u << (e & 31u)) : 0; };
+    return make_int4(v(r & 0xFFu), v((r >> 8) & 0xFFu), v((r >> 16) & 0xFFu), v(r >> 24));
+}
+
+// `*_in` -> `*_out` (the same pointers for the in-place entry point): a finished game copies through.
+__global__ __launch_bounds__(BLOCK) void step_state_i32_kernel(uint64_t n, uint64_t env_base, const int32_t *boards_in,
+                                                               int32_t *boards_out, const int32_t *actions,
+                                                               const int32_t *step_count_in, int32_t *step_count_out,
+                                                               const uint8_t *done_in, uint8_t *done_out,
+                                                               const float *total_in, float *total_out, float *reward_out,
+                                                               int32_t *max_tile, RngKey key, const uint2 *keys, float *obs_out,
+                                                               uint32_t *legal4_out, int64_t mirror)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    // `mirror` != 0: every output element is ALSO written `mirror` bytes further on -- the caller's pinned-host copy of its
+    // result block (a few hundred bytes at the reference's batch sizes), so that reading the results back needs no copy
+    auto put = [mirror](auto *p, auto v) {
+        *p = v;
+        if (mirror) *reinterpret_cast<decltype(p)>(reinterpret_cast<char *>(p) + mirror) = v;
+    };
+    const int4 *rows_in = reinterpret_cast<const int4 *>(boards_in) + 4 * i;
+    int4 *rows_out = reinterpret_cast<int4 *>(boards_out) + 4 * i;
+    const int4 v0 = rows_in[0], v1 = rows_in[1], v2 = rows_in[2], v3 = rows_in[3];
+    Board bd{pack4(v0), pack4(v1), pack4(v2), pack4(v3)};
+    const bool was_done = done_in[i] != 0;
+    const bool in_place = boards_in == boards_out && done_in == done_out && step_count_in == step_count_out && total_in == total_out;
+    // keyed form: environment i draws from ITS OWN key, as environment 0 at step 0 of the stream seeded with
+    // (keys[i][0] << 32) | keys[i][1] -- row i of the batch equals the single-environment call with keys[i]
+    const uint64_t env = keys ? 0u : env_base + i;
+    if (keys) {
+        const uint2 k = keys[i];
+        key = RngKey{k.y, k.x, 0u, 0u};
+    }
+    uint32_t w[4];
+    env_block(key, env >> 2, STREAM_STEP, w[0], w[1], w[2], w[3]);
+    const uint32_t sel = (uint32_t)env & 3u;
+    const uint32_t word = sel == 0u ? w[0] : sel == 1u ? w[1] : sel == 2u ? w[2] : w[3];
+    float reward = 0.0f;
+    int32_t steps = step_count_in ? step_count_in[i] : 0;
+    float total = total_in ? total_in[i] : 0.0f;
+    uint8_t done = 1;
+    uint32_t legal_bits = 0u;
+    if (!was_done) {
+        uint32_t score;
+        bool changed;
+        afterstate(bd, (uint32_t)actions[i] & 3u, score, changed);
+        spawn_tile_word(bd, word, changed);
+        reward = (float)score;  // exact: a step's score is < 2^24
+        put(rows_out + 0, unpack4(bd.r0));
+        put(rows_out + 1, unpack4(bd.r1));
+        put(rows_out + 2, unpack4(bd.r2));
+        put(rows_out + 3, unpack4(bd.r3));
+        legal_bits = legal_mask(bd);
+        done = legal_bits == 0u ? 1 : 0;
+        steps += 1;
+        total += reward;
+    } else if (legal4_out) {
+        legal_bits = legal_mask(bd);  // (a frozen game: the mask of the board as it stands)
+    }
+    // what the caller asks about the NEW state right after a move (reinforce/training/self_play.py:316-317), in the same
+    // launch: observation and (N, 4) legal bytes of the board this step leaves behind -- a finished game's unchanged board
+    if (obs_out) {
+        store_obs(obs_out, i, bd);
+        if (mirror) store_obs(reinterpret_cast<float *>(reinterpret_cast<char *>(obs_out) + mirror), i, bd);
+    }
+    if (legal4_out) put(legal4_out + i, (legal_bits & 1u) | ((legal_bits & 2u) << 7) | ((legal_bits & 4u) << 14) | ((legal_bits & 8u) << 21));
+    if (was_done && !in_place) {  // the values as they came in (not re-derived from the packed form)
+        put(rows_out + 0, v0);
+        put(rows_out + 1, v1);
+        put(rows_out + 2, v2);
+        put(rows_out + 3, v3);
+    }
+    if (!was_done || !in_place) {
+        put(done_out + i, done);
+        if (step_count_out) put(step_count_out + i, steps);
+        if (total_out) put(total_out + i, total);
+    }
+    put(reward_out + i, reward);
+    if (max_tile) {
+        const uint32_t rws[4] = {bd.r0, bd.r1, bd.r2, bd.r3};
+        uint32_t m = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            m = max(m, rws[r] & 0xFFu);
+            m = max(m, (rws[r] >> 8) & 0xFFu);
+            m = max(m, (rws[r] >> 16) & 0xFFu);
+            m = max(m, rws[r] >> 24);
+        }
+        put(max_tile + i, m ? (int32_t)(1u << (m & 31u)) : 0);
+    }
+}
+
+// batched_reset with one PRNG key per environment, straight to int32 value boards: board i = the fresh board of
+// environment 0 at step 0 of the stream seeded with keys[i] (= create_initial_board(keys[i])).
+// step_count / done / total (each may be NULL): the bookkeeping fields of a fresh GameState, written as zeros.
+__global__ __launch_bounds__(BLOCK) void reset_keyed_i32_kernel(uint64_t n, const uint2 *keys, int32_t *boards, float *obs_out,
+                                                                uint32_t *legal4_out, int32_t *step_count, uint8_t *done, float *total,
+                                                                int64_t mirror)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    auto put = [mirror](auto *p, auto v) {  // (see step_state_i32_kernel)
+        *p = v;
+        if (mirror) *reinterpret_cast<decltype(p)>(reinterpret_cast<char *>(p) + mirror) = v;
+    };
+    const uint2 k = keys[i];
+    uint32_t w0, w1, w2, w3;
+    env_block(RngKey{k.y, k.x, 0u, 0u}, 0u, STREAM_RESET, w0, w1, w2, w3);
+    const Board bd = fresh_board(w0, w1, w2, w3);
+    int4 *rows = reinterpret_cast<int4 *>(boards) + 4 * i;
+    put(rows + 0, unpack4(bd.r0));
+    put(rows + 1, unpack4(bd.r1));
+    put(rows + 2, unpack4(bd.r2));
+    put(rows + 3, unpack4(bd.r3));
+    if (obs_out) {
+        store_obs(obs_out, i, bd);
+        if (mirror) store_obs(reinterpret_cast<float *>(reinterpret_cast<char *>(obs_out) + mirror), i, bd);
+    }
+    if (legal4_out) {
+        const uint32_t bits = legal_mask(bd);
+        put(legal4_out + i, (bits & 1u) | ((bits & 2u) << 7) | ((bits & 4u) << 14) | ((bits & 8u) << 21));
+    }
+    if (step_count) put(step_count + i, (int32_t)0);
+    if (done) put(done + i, (uint8_t)0);
+    if (total) put(total + i, 0.0f);
+}
+
+// What the reinforce/game callers ask about a batch of int32 value boards, in one launch: the f32
+// observation, the legal-action mask as four 0/1 BYTES per board (a torch/NumPy bool array) and the
+// JAX-flavoured done flag ("no action changes the board").
+__global__ __launch_bounds__(BLOCK) void status_i32_kernel(uint64_t n, const int32_t *boards, float *obs, uint32_t *legal4,
+                                                           uint8_t *done)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int4 *rows = reinterpret_cast<const int4 *>(boards) + 4 * i;
+    const Board bd{pack4(rows[0]), pack4(rows[1]), pack4(rows[2]), pack4(rows[3])};
+    if (obs) store_obs(obs, i, bd);
+    if (legal4 || done) {
+        const uint32_t bits = legal_mask(bd);
+        if (legal4) legal4[i] = (bits & 1u) | ((bits & 2u) << 7) | ((bits & 4u) << 14) | ((bits & 8u) << 21);
+        if (done) done[i] = bits == 0u ? 1 : 0;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+static int step_state_i32_common(const char *who, int device, void *stream, uint64_t n, uint64_t env_base, const uint32_t *keys,
+                                 const int32_t *boards_in, int32_t *boards_out, const int32_t *actions, const int32_t *step_count_in,
+                                 int32_t *step_count_out, const uint8_t *done_in, uint8_t *done_out, const float *total_reward_in,
+                                 float *total_reward_out, float *reward, int32_t *max_tile, uint64_t seed, uint64_t step_index,
+                                 float *obs_out = nullptr, uint8_t *legal4_out = nullptr, int64_t host_mirror_delta = 0)
+{
+    if (n == 0) return ENV2048_OK;
+    if (misaligned(obs_out, 16) || misaligned(legal4_out, 4)) return fail(ENV2048_ERR_ALIGNMENT, "%s: obs must be 16-byte, legal4 4-byte aligned", who);
+    if (host_mirror_delta & 15) return fail(ENV2048_ERR_ALIGNMENT, "%s: host_mirror_delta must be a multiple of 16 bytes", who);
+    if (host_mirror_delta && boards_in == boards_out)
+        return fail(ENV2048_ERR_INVALID_ARG, "%s: a host mirror goes with the out-of-place form (outputs in one block of their own)", who);
+    if (!boards_in || !boards_out || !actions || !done_in || !done_out || !reward)
+        return fail(ENV2048_ERR_INVALID_ARG, "%s: boards, actions, done and reward are required", who);
+    if ((step_count_in == nullptr) != (step_count_out == nullptr) || (total_reward_in == nullptr) != (total_reward_out == nullptr))
+        return fail(ENV2048_ERR_INVALID_ARG, "%s: step_count / total_reward need both their in and out array", who);
+    if (misaligned(boards_in, 16) || misaligned(boards_out, 16)) return fail(ENV2048_ERR_ALIGNMENT, "%s: boards must be 16-byte aligned", who);
+    if (misaligned(actions, 4) || misaligned(step_count_in, 4) || misaligned(step_count_out, 4) || misaligned(total_reward_in, 4) ||
+        misaligned(total_reward_out, 4) || misaligned(reward, 4) || misaligned(max_tile, 4))
+        return fail(ENV2048_ERR_ALIGNMENT, "%s: misaligned 4-byte array", who);
+    if (misaligned(keys, 8)) return fail(ENV2048_ERR_ALIGNMENT, "%s: keys must be 8-byte aligned", who);
+    if (int rc = check_range(n, env_base)) return rc;
+    if (int rc = check_count(n)) return rc;
+    DeviceScope scope(device);
+    if (scope.rc) return scope.rc;
+    const RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)step_index, (uint32_t)(step_index >> 32)};
+    hipLaunchKernelGGL(step_state_i32_kernel, grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, n, env_base, boards_in, boards_out,
+                       actions, step_count_in, step_count_out, done_in, done_out, total_reward_in, total_reward_out, reward,
+                       max_tile, key, reinterpret_cast<const uint2 *>(keys), obs_out, reinterpret_cast<uint32_t *>(legal4_out),
+                       host_mirror_delta);
+    return launched(who);
+}
+
+int env2048_step_state_i32_to(int device, void *stream, uint64_t n, uint64_t env_base, const int32_t *boards_in,
+                              int32_t *boards_out, const int32_t *actions, const int32_t *step_count_in, int32_t *step_count_out,
+                              const uint8_t *done_in, uint8_t *done_out, const float *total_reward_in, float *total_reward_out,
+                              float *reward, int32_t *max_tile, uint64_t seed, uint64_t step_index)
+{
+    return step_state_i32_common("env2048_step_state_i32", device, stream, n, env_base, nullptr, boards_in, boards_out, actions,
+                                 step_count_in, step_count_out, done_in, done_out, total_reward_in, total_reward_out, reward, max_tile,
+                                 seed, step_index);
+}
+
+int env2048_step_state_i32_keyed(int device, void *stream, uint64_t n, const uint32_t *keys, const int32_t *boards_in,
+                                 int32_t *boards_out, const int32_t *actions, const int32_t *step_count_in, int32_t *step_count_out,
+                                 const uint8_t *done_in, uint8_t *done_out, const float *total_reward_in, float *total_reward_out,
+                                 float *reward, int32_t *max_tile)
+{
+    if (n && !keys) return fail(ENV2048_ERR_INVALID_ARG, "env2048_step_state_i32_keyed: keys is NULL");
+    return step_state_i32_common("env2048_step_state_i32_keyed", device, stream, n, 0, keys, boards_in, boards_out, actions,
+                                 step_count_in, step_count_out, done_in, done_out, total_reward_in, total_reward_out, reward, max_tile,
+                                 0, 0);
+}
+
+int env2048_reset_state_i32_keyed(int device, void *stream, uint64_t n, const uint32_t *keys, int32_t *boards, int32_t *step_count,
+                                  uint8_t *done, float *total_reward, float *obs, uint8_t *legal4, int64_t host_mirror_delta)
+{
+    if (n == 0) return ENV2048_OK;
+    if (!keys || !boards) return fail(ENV2048_ERR_INVALID_ARG, "env2048_reset_keyed_i32: keys and boards are required");
+    if (misaligned(keys, 8) || misaligned(boards, 16) || misaligned(obs, 16) || misaligned(legal4, 4) || misaligned(step_count, 4) ||
+        misaligned(total_reward, 4))
+        return fail(ENV2048_ERR_ALIGNMENT, "env2048_reset_keyed_i32: keys must be 8-byte, boards / obs 16-byte, the other arrays 4-byte aligned");
+    if (host_mirror_delta & 15) return fail(ENV2048_ERR_ALIGNMENT, "env2048_reset_state_i32_keyed: host_mirror_delta must be a multiple of 16 bytes");
+    if (int rc = check_count(n)) return rc;
+    DeviceScope scope(device);
+    if (scope.rc) return scope.rc;
+    hipLaunchKernelGGL(reset_keyed_i32_kernel, grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, n, reinterpret_cast<const uint2 *>(keys),
+                       boards, obs, reinterpret_cast<uint32_t *>(legal4), step_count, done, total_reward, host_mirror_delta);
+    return launched("env2048_reset_keyed_i32 launch");
+}
+
+int env2048_reset_keyed_i32_status(int device, void *stream, uint64_t n, const uint32_t *keys, int32_t *boards, float *obs,
+                                   uint8_t *legal4)
+{
+    return env2048_reset_state_i32_keyed(device, stream, n, keys, boards, nullptr, nullptr, nullptr, obs, legal4, 0);
+}
+
+int env2048_reset_keyed_i32(int device, void *stream, uint64_t n, const uint32_t *keys, int32_t *boards)
+{
+    return env2048_reset_keyed_i32_status(device, stream, n, keys, boards, nullptr, nullptr);
+}
+
+int env2048_step_state_i32_keyed_status(int device, void *stream, uint64_t n, const uint32_t *keys, const int32_t *boards_in,
+                                        int32_t *boards_out, const int32_t *actions, const int32_t *step_count_in,
+                                        int32_t *step_count_out, const uint8_t *done_in, uint8_t *done_out, const float *total_reward_in,
+                                        float *total_reward_out, float *reward, int32_t *max_tile, float *obs, uint8_t *legal4)
+{
+    if (n && !keys) return fail(ENV2048_ERR_INVALID_ARG, "env2048_step_state_i32_keyed_status: keys is NULL");
+    return step_state_i32_common("env2048_step_state_i32_keyed_status", device, stream, n, 0, keys, boards_in, boards_out, actions,
+                                 step_count_in, step_count_out, done_in, done_out, total_reward_in, total_reward_out, reward, max_tile,
+                                 0, 0, obs, legal4);
+}
+
+int env2048_step_state_i32_keyed_mirrored(int device, void *stream, uint64_t n, const uint32_t *keys, const int32_t *boards_in,
+                                          int32_t *boards_out, const int32_t *actions, const int32_t *step_count_in,
+                                          int32_t *step_count_out, const uint8_t *done_in, uint8_t *done_out, const float *total_reward_in,
+                                          float *total_reward_out, float *reward, int32_t *max_tile, float *obs, uint8_t *legal4,
+                                          int64_t host_mirror_delta)
+{
+    if (n && !keys) return fail(ENV2048_ERR_INVALID_ARG, "env2048_step_state_i32_keyed_mirrored: keys is NULL");
+    return step_state_i32_common("env2048_step_state_i32_keyed_mirrored", device, stream, n, 0, keys, boards_in, boards_out, actions,
+                                 step_count_in, step_count_out, done_in, done_out, total_reward_in, total_reward_out, reward, max_tile,
+                                 0, 0, obs, legal4, host_mirror_delta);
+}
+
+int env2048_step_state_i32(int device, void *stream, uint64_t n, uint64_t env_base, int32_t *boards, const int32_t *actions,
+                           int32_t *step_count, uint8_t *done_io, float *total_reward, float *reward, int32_t *max_tile,
+                           uint64_t seed, uint64_t step_index)
+{
+    return env2048_step_state_i32_to(device, stream, n, env_base, boards, boards, actions, step_count, step_count, done_io, done_io,
+                                     total_reward, total_reward, reward, max_tile, seed, step_index);
+}
+
+int env2048_status_i32(int device, void *stream, uint64_t n, const int32_t *boards, float *obs, uint8_t *legal4, uint8_t *done)
+{
+    if (n == 0) return ENV2048_OK;
+    if (!boards) return fail(ENV2048_ERR_INVALID_ARG, "env2048_status_i32: boards is NULL");
+    if (misaligned(boards, 16) || misaligned(obs, 16) || misaligned(legal4, 4))
+        return fail(ENV2048_ERR_ALIGNMENT, "env2048_status_i32: boards/obs must be 16-byte, legal4 4-byte aligned");
+    if (int rc = check_count(n)) return rc;
+    DeviceScope scope(device);
+    if (scope.rc) return scope.rc;
+    hipLaunchKernelGGL(status_i32_kernel, grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, n, boards, obs,
+                       reinterpret_cast<uint32_t *>(legal4), done);
+    return launched("env2048_status_i32 launch");
+}
+
+}  // extern "C"

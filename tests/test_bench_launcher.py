@@ -83,10 +83,10 @@ def test_bench_without_gpu_exits_nonzero_in_every_mode():
 def test_profile_table_is_keyed_by_kernel_source():
     sha = bench.kernel_source_sha()
     assert len(sha) == 16 and sha == bench.kernel_source_sha()
-    # the hash covers the step kernel's own source regions (device code + host launch policy) and board_ops.hpp only
+    # the hash covers the step kernel's own source regions (device code + host launch policy) and the headers they use
     import re
 
-    text = (REPO / 'simulate_2048_amd' / 'csrc' / 'env2048_kernels.hip').read_text()
+    text = (REPO / 'simulate_2048_amd' / 'csrc' / 'step_kernels.hip').read_text()
     regions = re.findall(r'\[step-kernel-source-begin\](.*?)\[step-kernel-source-end\]', text, flags=re.S)
     assert len(regions) == 2 and 'void step_kernel(' in regions[0] and 'void launch_step(' in regions[1]
     assert 'rollout_kernel' not in ''.join(regions) and 'expectimax_ply_kernel' not in ''.join(regions)

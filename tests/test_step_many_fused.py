@@ -101,7 +101,7 @@ def test_plan_variant_hint_size_counter_and_empty_records():
     c = plan([disjoint(0), disjoint(1, counter=0x6000_0000_0000), disjoint(2), disjoint(3)])
     assert c['launch_of'] == [0, 1, 2, 2]  # a record that reads its step index from device memory goes alone
     e = plan([disjoint(0), rec(None, 0, actions=None, reward=None, done=None), disjoint(1), disjoint(2)])
-    assert e['launches'] == 2 and e['launch_of'][0] == 0 and e['launch_of'][2] == e['launch_of'][3] == 1  # an empty record ends a run, launches nothing
+    assert e['launches'] == 1 and e['launch_of'] == [0, 0, 0, 0]  # an empty record launches nothing and neither joins nor separates its neighbours
     with pytest.raises(capi.Env2048Error):
         plan([disjoint(0), rec(B + 1, n)])  # validated like env2048_step_many: misaligned boards
 
@@ -365,3 +365,46 @@ def test_two_chain_sequences_from_several_threads_on_one_device():
     for i in range(3):
         for a, b in zip(got[i], want[i]):
             assert torch.equal(a, b), i
+
+
+@pytest.mark.gpu
+def test_long_runs_of_empty_records_launch_nothing_and_do_not_hang():
+    """64 empty records followed by more made env2048_step_many loop forever in host code.  The same
+    array -- 64 empty records, then 6 live batches (one of them twice: a dependent pair) with empty records between them --
+    against one env2048_step per live record, with the result checked by the oracle as well."""
+    lib = capi.library()
+    rng = np.random.default_rng(64)
+    n = 3000
+    starts = [midgame(lib, n, env_base=500 * s) for s in range(5)]
+    which = [0, 1, 2, 3, 4, 0]
+    acts = [torch.from_numpy(rng.integers(0, 4, size=n).astype(np.uint8)).cuda() for _ in which]
+    empty = capi.StepArgs(0, 0, None, None, None, None, None, None, 0, 0, 0, 0, None, None)
+
+    def run(shared: bool):
+        boards = [s.clone() for s in starts]
+        outs = [outputs(n, False) for _ in which]
+        live = [capi.StepArgs(n, 500 * w, p(boards[w]), p(acts[k]), p(outs[k]['reward']), p(outs[k]['done']), None, None, 3, 10 + k, AUTO, 0,
+                              None, None) for k, w in enumerate(which)]
+        if shared:
+            layout = [empty] * 64 + [live[0], live[1]] + [empty] * 70 + live[2:5] + [empty] + [live[5]] + [empty] * 33
+            recs = (capi.StepArgs * len(layout))(*layout)
+            plan = lib.step_many_plan(recs)
+            assert plan['launches'] == 2 and plan['launch_of'][:64] == [0] * 64 and plan['launch_of'][-34:] == [1] * 34
+            lib.step_many(DEV, stream(), recs)
+        else:
+            for r in live:
+                lib.step_many(DEV, stream(), (capi.StepArgs * 1)(r))
+        torch.cuda.synchronize()
+        return boards, outs
+
+    b1, o1 = run(True)
+    b2, o2 = run(False)
+    for x, y in zip(b1, b2):
+        assert torch.equal(x, y)
+    for x, y in zip(o1, o2):
+        assert torch.equal(x['reward'], y['reward']) and torch.equal(x['done'], y['done'])
+    ref = oracle.step_batch(starts[1].cpu().numpy(), acts[1].cpu().numpy(), 3, 11, env_base=500, flags=AUTO)
+    assert np.array_equal(b1[1].cpu().numpy(), ref['boards']) and np.array_equal(o1[1]['reward'].cpu().numpy(), ref['reward'])
+    all_empty = (capi.StepArgs * 150)(*([empty] * 150))
+    lib.step_many(DEV, stream(), all_empty)  # no work at all: returns, launches nothing
+    torch.cuda.synchronize()

@@ -4,6 +4,5 @@
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 NAME=$1; shift
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -fvisibility=hidden -pthread -DENV2048_BUILDING -I$R/include -I$R/simulate_2048_amd/csrc \
-  -mllvm -amdgpu-kernarg-preload-count=16 "$@" $R/simulate_2048_amd/csrc/env2048_kernels.hip -o $R/tools/libexp_$NAME.so
+python3 $R/simulate_2048_amd/build.py --out $R/tools/libexp_$NAME.so "$@" > /dev/null
 echo built tools/libexp_$NAME.so

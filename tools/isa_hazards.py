@@ -32,10 +32,18 @@ def build_assembly(out: Path) -> Path:
     sys.path.insert(0, str(REPO))
     from simulate_2048_amd import build as hip_build
 
-    cmd = [hip_build.hipcc(), f'--offload-arch={hip_build.ARCH}', '-O3', '-std=c++17', '-DENV2048_BUILDING', f'-I{REPO / "include"}',
-           f'-I{hip_build.PKG / "csrc"}', '-mllvm', '-amdgpu-kernarg-preload-count=16', '-S', '--cuda-device-only', '-o', str(out)]
-    cmd += [str(s) for s in hip_build.SOURCES]
-    subprocess.run(cmd, check=True, capture_output=True)
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(src: Path) -> str:  # one translation unit -> its device assembly
+        part = out.with_name(out.stem + '.' + src.stem + '.s')
+        cmd = [hip_build.hipcc(), f'--offload-arch={hip_build.ARCH}', '-O3', '-std=c++17', '-DENV2048_BUILDING', f'-I{REPO / "include"}',
+               f'-I{hip_build.PKG / "csrc"}', '-mllvm', '-amdgpu-kernarg-preload-count=16', '-S', '--cuda-device-only', '-o', str(part),
+               str(src)]
+        subprocess.run(cmd, check=True, capture_output=True)
+        return part.read_text()
+
+    with ThreadPoolExecutor(max_workers=len(hip_build.SOURCES)) as pool:
+        out.write_text('\n'.join(pool.map(one, hip_build.SOURCES)))
     return out
 
 

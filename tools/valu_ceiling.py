@@ -47,7 +47,7 @@ def histogram() -> tuple[collections.Counter, int]:
     with tempfile.TemporaryDirectory() as tmp:
         cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-fvisibility=hidden', '-DENV2048_BUILDING',
                f'-I{REPO / "include"}', f'-I{REPO / "simulate_2048_amd" / "csrc"}', '-mllvm', '-amdgpu-kernarg-preload-count=16',
-               '-save-temps', str(REPO / 'simulate_2048_amd' / 'csrc' / 'env2048_kernels.hip'), '-o', str(Path(tmp) / 'lib.so')]
+               '-save-temps', str(REPO / 'simulate_2048_amd' / 'csrc' / 'step_kernels.hip'), '-o', str(Path(tmp) / 'lib.so')]
         subprocess.run(cmd, cwd=tmp, check=True, capture_output=True)
         text = next(Path(tmp).glob('*gfx950.s')).read_text()
     m = re.search(r'^' + re.escape(KERNEL) + r':[^\n]*\n(.*?)\n\s*s_endpgm', text, flags=re.S | re.M)
