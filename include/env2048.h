@@ -347,6 +347,54 @@ ENV2048_EXPORT int env2048_step_state_i32_keyed_mirrored(int device, void *strea
                                                          int32_t *max_tile, float *obs, uint8_t *legal4, int64_t host_mirror_delta);
 
 /*
+ * The mirrored calls with a COMPLETION WORD, for launches of at most ENV2048_SIGNAL_MAX_ENVS environments (one workgroup):
+ * host_sequence is a device-accessible, 8-byte aligned word of PINNED HOST memory owned by the caller (typically 16 bytes
+ * reserved at the end of the host mirror block).  After every result store of the launch -- to the device block and to the
+ * host mirror -- has been performed at system scope, the kernel stores `sequence_value` there (release, system scope) and
+ * ends.  The caller hands out increasing values (a launch serial) and, instead of synchronising the stream -- an
+ * interrupt-driven wake-up of 20 us and more around a 4 us kernel -- polls the word: once it reads `sequence_value`, the host
+ * mirror holds the results of that launch.  The kernel terminates by itself in every case; nothing on the GPU waits for the
+ * host; a caller that never looks at the word loses nothing.  host_sequence == NULL: exactly the _mirrored form.
+ * Errors: host_sequence without a mirror (host_mirror_delta == 0), misaligned, or n > ENV2048_SIGNAL_MAX_ENVS ->
+ * ENV2048_ERR_INVALID_ARG / _ALIGNMENT, nothing launched (larger batches keep the stream-synchronisation path).
+ * env2048_wait_sequence is the host side: poll *host_sequence until it equals `value` (returns 1) or timeout_us microseconds
+ * have passed (returns 0: the caller falls back to synchronising the stream, so a lost launch can never hang the host);
+ * negative on a NULL / misaligned pointer.  It makes no device call and holds no lock.
+ * [replaces: batched_reset / batched_step + the caller's np.array(...) read-backs, reinforce/game/env.py:176-211,
+ *  reinforce/training/self_play.py:298-300,346-356]
+ */
+#define ENV2048_SIGNAL_MAX_ENVS 512
+ENV2048_EXPORT int env2048_reset_state_i32_keyed_signalled(int device, void *stream, uint64_t n, const uint32_t *keys, int32_t *boards,
+                                                           int32_t *step_count, uint8_t *done, float *total_reward, float *obs,
+                                                           uint8_t *legal4, int64_t host_mirror_delta, uint64_t *host_sequence,
+                                                           uint64_t sequence_value);
+ENV2048_EXPORT int env2048_step_state_i32_keyed_signalled(int device, void *stream, uint64_t n, const uint32_t *keys, const int32_t *boards_in,
+                                                          int32_t *boards_out, const int32_t *actions, const int32_t *step_count_in,
+                                                          int32_t *step_count_out, const uint8_t *done_in, uint8_t *done_out,
+                                                          const float *total_reward_in, float *total_reward_out, float *reward,
+                                                          int32_t *max_tile, float *obs, uint8_t *legal4, int64_t host_mirror_delta,
+                                                          uint64_t *host_sequence, uint64_t sequence_value);
+ENV2048_EXPORT int env2048_wait_sequence(const uint64_t *host_sequence, uint64_t value, uint32_t timeout_us);
+
+/*
+ * env2048_step_state_i32_keyed_signalled for at most ENV2048_INLINE_MAX_ENVS environments with the per-move INPUTS TAKEN FROM
+ * ORDINARY HOST MEMORY: host_keys (n x 2 uint32) and host_actions (n int32) are host pointers -- pageable memory is fine --
+ * that the library reads DURING THE CALL and sends along in the kernel-argument block; the caller may overwrite them as soon
+ * as the call returns, and nothing needs to be staged in pinned or device memory.  This is the shape of the reference's move
+ * loop: keys and actions are produced on the host for every move (reinforce/training/self_play.py:333-354, N = 2 ... 8 games).
+ * All other pointers are device pointers as before; host_mirror_delta / host_sequence as in the _signalled form (both
+ * optional).  Results are those of env2048_step_state_i32_keyed on the same keys and actions.
+ * [replaces: batched_step with host-side keys / actions, reinforce/game/env.py:193-211]
+ */
+#define ENV2048_INLINE_MAX_ENVS 64
+ENV2048_EXPORT int env2048_step_state_i32_keyed_inline(int device, void *stream, uint64_t n, const uint32_t *host_keys, const int32_t *boards_in,
+                                                       int32_t *boards_out, const int32_t *host_actions, const int32_t *step_count_in,
+                                                       int32_t *step_count_out, const uint8_t *done_in, uint8_t *done_out,
+                                                       const float *total_reward_in, float *total_reward_out, float *reward,
+                                                       int32_t *max_tile, float *obs, uint8_t *legal4, int64_t host_mirror_delta,
+                                                       uint64_t *host_sequence, uint64_t sequence_value);
+
+/*
  * Per-move queries of the reinforce/game callers on int32 tile VALUE boards (n x 16), one launch, each
  * output optional:
  *     obs[16*i..]    float32 log2(tile)/16, 0 for empty      (encode_observation, core.py:346-377)

@@ -65,6 +65,8 @@ class HelperInfo(ctypes.Structure):
 EPISODES_FROZEN = 1
 EPISODES_REWARD_F32 = 2
 ROLLOUT_STATS_WORDS = 40
+SIGNAL_MAX_ENVS = 512
+INLINE_MAX_ENVS = 64
 
 # name -> (restype, argtypes): exactly the prototypes of include/env2048.h
 PROTOTYPES = {
@@ -95,6 +97,13 @@ PROTOTYPES = {
     'env2048_reset_state_i32_keyed': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, ctypes.c_int64]),
     'env2048_step_state_i32_keyed_mirrored': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
                                                         _ptr, _ptr, _ptr, _ptr, ctypes.c_int64]),
+    'env2048_reset_state_i32_keyed_signalled': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, ctypes.c_int64, _ptr,
+                                                          _u64]),
+    'env2048_step_state_i32_keyed_signalled': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
+                                                         _ptr, _ptr, _ptr, _ptr, ctypes.c_int64, _ptr, _u64]),
+    'env2048_wait_sequence': (_c_int, [_ptr, _u64, _u32]),
+    'env2048_step_state_i32_keyed_inline': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
+                                                      _ptr, _ptr, _ptr, _ptr, ctypes.c_int64, _ptr, _u64]),
     'env2048_status_i32': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr]),
     'env2048_rollout': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _u64, _u64, _u32, _ptr, _ptr, _ptr, _u32]),
     'env2048_replay': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _ptr, _ptr, _ptr, _u64, _u64, _u64, _u32, _u32, _ptr, _ptr, _ptr]),
@@ -258,6 +267,35 @@ class Library:
         self._check(self._dll.env2048_step_state_i32_keyed_mirrored(device, stream, n, keys, boards_in, boards_out, actions,
                                                                     step_count_in, step_count_out, done_in, done_out, total_in,
                                                                     total_out, reward, max_tile, obs, legal4, host_mirror_delta))
+
+    def reset_state_i32_keyed_signalled(self, device, stream, n, keys, boards, step_count, done, total, obs, legal4, host_mirror_delta,
+                                        host_sequence, sequence_value) -> None:
+        self._check(self._dll.env2048_reset_state_i32_keyed_signalled(device, stream, n, keys, boards, step_count, done, total, obs, legal4,
+                                                                      host_mirror_delta, host_sequence, sequence_value))
+
+    def step_state_i32_keyed_signalled(self, device, stream, n, keys, boards_in, boards_out, actions, step_count_in, step_count_out,
+                                       done_in, done_out, total_in, total_out, reward, max_tile, obs, legal4, host_mirror_delta,
+                                       host_sequence, sequence_value) -> None:
+        self._check(self._dll.env2048_step_state_i32_keyed_signalled(device, stream, n, keys, boards_in, boards_out, actions,
+                                                                     step_count_in, step_count_out, done_in, done_out, total_in,
+                                                                     total_out, reward, max_tile, obs, legal4, host_mirror_delta,
+                                                                     host_sequence, sequence_value))
+
+    def step_state_i32_keyed_inline(self, device, stream, n, host_keys, boards_in, boards_out, host_actions, step_count_in, step_count_out,
+                                    done_in, done_out, total_in, total_out, reward, max_tile, obs, legal4, host_mirror_delta=0,
+                                    host_sequence=None, sequence_value=0) -> None:
+        """``host_keys`` / ``host_actions``: HOST addresses (read during the call); n <= INLINE_MAX_ENVS."""
+        self._check(self._dll.env2048_step_state_i32_keyed_inline(device, stream, n, host_keys, boards_in, boards_out, host_actions,
+                                                                  step_count_in, step_count_out, done_in, done_out, total_in, total_out,
+                                                                  reward, max_tile, obs, legal4, host_mirror_delta, host_sequence,
+                                                                  sequence_value))
+
+    def wait_sequence(self, host_sequence, value, timeout_us) -> bool:
+        """Poll the completion word of a *_signalled launch: True once it holds ``value``, False after ``timeout_us``."""
+        rc = self._dll.env2048_wait_sequence(host_sequence, value, timeout_us)
+        if rc < 0:
+            raise Env2048Error(rc, self.last_error())
+        return rc == 1
 
     def random_actions(self, device, stream, n, env_base, seed, step_index, actions) -> None:
         self._check(self._dll.env2048_random_actions(device, stream, n, env_base, seed, step_index, actions))

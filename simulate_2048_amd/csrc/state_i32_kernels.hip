@@ -9,6 +9,11 @@
 #include "tiling.hpp"
 #include "device_scope.hpp"
 
+#include <string.h>
+
+#include <atomic>
+#include <chrono>
+
 using namespace env2048;
 using namespace env2048::host;
 
@@ -26,17 +31,27 @@ __device__ __forceinline__ int4 unpack4(uint32_t r)
     return make_int4(v(r & 0xFFu), v((r >> 8) & 0xFFu), v((r >> 16) & 0xFFu), v(r >> 24));
 }
 
-// `*_in` -> `*_out` (the same pointers for the in-place entry point): a finished game copies through.
-__global__ __launch_bounds__(BLOCK) void step_state_i32_kernel(uint64_t n, uint64_t env_base, const int32_t *boards_in,
-                                                               int32_t *boards_out, const int32_t *actions,
-                                                               const int32_t *step_count_in, int32_t *step_count_out,
-                                                               const uint8_t *done_in, uint8_t *done_out,
-                                                               const float *total_in, float *total_out, float *reward_out,
-                                                               int32_t *max_tile, RngKey key, const uint2 *keys, float *obs_out,
-                                                               uint32_t *legal4_out, int64_t mirror)
+// Completion signal of a SINGLE-WORKGROUP launch with a host mirror (the *_signalled entry points): once every thread's
+// stores -- the device copies and the host-mirror copies -- are performed at system scope, one thread stores
+// `sequence_value` into the caller's pinned host word.  The host polls that word instead of synchronising the stream
+// (an interrupt-driven wake-up that costs more than the whole move at the reference's batch sizes).  Every thread of the
+// block calls this exactly once, on every path, as its last action; the kernel then ends by itself -- nothing on the GPU
+// ever waits for the host.  sequence == NULL (wave-uniform): no barrier, no fence, nothing.
+__device__ __forceinline__ void signal_sequence(uint64_t *sequence, uint64_t value)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
+    if (!sequence) return;
+    __threadfence_system();  // this thread's result stores are visible to the host before ...
+    __syncthreads();         // ... any thread of the (only) block gets past here
+    if (threadIdx.x == 0) __hip_atomic_store(sequence, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// One environment: `*_in` -> `*_out` (the same pointers for the in-place entry point): a finished game copies through.
+__device__ __forceinline__ void step_state_i32_one(uint64_t i, uint64_t env_base, const int32_t *boards_in, int32_t *boards_out,
+                                                   const int32_t *actions, const int32_t *step_count_in, int32_t *step_count_out,
+                                                   const uint8_t *done_in, uint8_t *done_out, const float *total_in, float *total_out,
+                                                   float *reward_out, int32_t *max_tile, RngKey key, const uint2 *keys, float *obs_out,
+                                                   uint32_t *legal4_out, int64_t mirror)
+{
     // `mirror` != 0: every output element is ALSO written `mirror` bytes further on -- the caller's pinned-host copy of its
     // result block (a few hundred bytes at the reference's batch sizes), so that reading the results back needs no copy
     auto put = [mirror](auto *p, auto v) {
@@ -115,15 +130,49 @@ __global__ __launch_bounds__(BLOCK) void step_state_i32_kernel(uint64_t n, uint6
     }
 }
 
+__global__ __launch_bounds__(BLOCK) void step_state_i32_kernel(uint64_t n, uint64_t env_base, const int32_t *boards_in,
+                                                               int32_t *boards_out, const int32_t *actions,
+                                                               const int32_t *step_count_in, int32_t *step_count_out,
+                                                               const uint8_t *done_in, uint8_t *done_out,
+                                                               const float *total_in, float *total_out, float *reward_out,
+                                                               int32_t *max_tile, RngKey key, const uint2 *keys, float *obs_out,
+                                                               uint32_t *legal4_out, int64_t mirror, uint64_t *sequence,
+                                                               uint64_t sequence_value)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n)
+        step_state_i32_one(i, env_base, boards_in, boards_out, actions, step_count_in, step_count_out, done_in, done_out, total_in, total_out,
+                           reward_out, max_tile, key, keys, obs_out, legal4_out, mirror);
+    signal_sequence(sequence, sequence_value);  // (outside the bounds check: every thread of the block takes part)
+}
+
+// The same move with the keys and actions of a SMALL batch travelling in the kernel-argument block (env2048_*_inline):
+// the host copies them out of ordinary host memory at call time, so nothing has to be staged in pinned or device memory and
+// the kernel's first loads do not cross the bus (measured at N = 8: 2 us less from launch to completion than reading the
+// same 96 bytes from pinned host memory).  One workgroup; lane i reads entry i of the block.
+struct InlineInputs {
+    uint2 keys[ENV2048_INLINE_MAX_ENVS];
+    int32_t actions[ENV2048_INLINE_MAX_ENVS];
+};
+
+__global__ __launch_bounds__(ENV2048_INLINE_MAX_ENVS) void step_state_i32_inline_kernel(
+    uint64_t n, const int32_t *boards_in, int32_t *boards_out, const int32_t *step_count_in, int32_t *step_count_out, const uint8_t *done_in,
+    uint8_t *done_out, const float *total_in, float *total_out, float *reward_out, int32_t *max_tile, float *obs_out, uint32_t *legal4_out,
+    int64_t mirror, uint64_t *sequence, uint64_t sequence_value, const InlineInputs in)
+{
+    const uint64_t i = threadIdx.x;
+    if (i < n)
+        step_state_i32_one(i, 0u, boards_in, boards_out, in.actions, step_count_in, step_count_out, done_in, done_out, total_in, total_out,
+                           reward_out, max_tile, RngKey{0u, 0u, 0u, 0u}, in.keys, obs_out, legal4_out, mirror);
+    signal_sequence(sequence, sequence_value);
+}
+
 // batched_reset with one PRNG key per environment, straight to int32 value boards: board i = the fresh board of
 // environment 0 at step 0 of the stream seeded with keys[i] (= create_initial_board(keys[i])).
 // step_count / done / total (each may be NULL): the bookkeeping fields of a fresh GameState, written as zeros.
-__global__ __launch_bounds__(BLOCK) void reset_keyed_i32_kernel(uint64_t n, const uint2 *keys, int32_t *boards, float *obs_out,
-                                                                uint32_t *legal4_out, int32_t *step_count, uint8_t *done, float *total,
-                                                                int64_t mirror)
+__device__ __forceinline__ void reset_keyed_i32_one(uint64_t i, const uint2 *keys, int32_t *boards, float *obs_out, uint32_t *legal4_out,
+                                                    int32_t *step_count, uint8_t *done, float *total, int64_t mirror)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
     auto put = [mirror](auto *p, auto v) {  // (see step_state_i32_kernel)
         *p = v;
         if (mirror) *reinterpret_cast<decltype(p)>(reinterpret_cast<char *>(p) + mirror) = v;
@@ -150,6 +199,15 @@ __global__ __launch_bounds__(BLOCK) void reset_keyed_i32_kernel(uint64_t n, cons
     if (total) put(total + i, 0.0f);
 }
 
+__global__ __launch_bounds__(BLOCK) void reset_keyed_i32_kernel(uint64_t n, const uint2 *keys, int32_t *boards, float *obs_out,
+                                                                uint32_t *legal4_out, int32_t *step_count, uint8_t *done, float *total,
+                                                                int64_t mirror, uint64_t *sequence, uint64_t sequence_value)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) reset_keyed_i32_one(i, keys, boards, obs_out, legal4_out, step_count, done, total, mirror);
+    signal_sequence(sequence, sequence_value);
+}
+
 // What the reinforce/game callers ask about a batch of int32 value boards, in one launch: the f32
 // observation, the legal-action mask as four 0/1 BYTES per board (a torch/NumPy bool array) and the
 // JAX-flavoured done flag ("no action changes the board").
@@ -168,6 +226,21 @@ __global__ __launch_bounds__(BLOCK) void status_i32_kernel(uint64_t n, const int
     }
 }
 
+// A launch that fits one workgroup gets a workgroup of only as many waves as it has boards for (at the reference's batch
+// sizes, N = 2 ... 8, one wave instead of eight: less to dispatch, and the completion signal's barrier spans one wave).
+inline dim3 block_for(uint64_t n) { return dim3(n >= (uint64_t)BLOCK ? (unsigned)BLOCK : (unsigned)((n + 63) / 64 * 64)); }
+
+int check_sequence(const char *who, uint64_t n, int64_t host_mirror_delta, const uint64_t *host_sequence)
+{
+    if (!host_sequence) return ENV2048_OK;
+    if (misaligned(host_sequence, 8)) return fail(ENV2048_ERR_ALIGNMENT, "%s: host_sequence must be 8-byte aligned", who);
+    if (!host_mirror_delta) return fail(ENV2048_ERR_INVALID_ARG, "%s: a completion word goes with a host mirror (host_mirror_delta != 0)", who);
+    if (n > ENV2048_SIGNAL_MAX_ENVS)
+        return fail(ENV2048_ERR_INVALID_ARG, "%s: a completion word needs a single-workgroup launch (n <= %d), got n = %llu", who,
+                    ENV2048_SIGNAL_MAX_ENVS, (unsigned long long)n);
+    return ENV2048_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -176,9 +249,11 @@ static int step_state_i32_common(const char *who, int device, void *stream, uint
                                  const int32_t *boards_in, int32_t *boards_out, const int32_t *actions, const int32_t *step_count_in,
                                  int32_t *step_count_out, const uint8_t *done_in, uint8_t *done_out, const float *total_reward_in,
                                  float *total_reward_out, float *reward, int32_t *max_tile, uint64_t seed, uint64_t step_index,
-                                 float *obs_out = nullptr, uint8_t *legal4_out = nullptr, int64_t host_mirror_delta = 0)
+                                 float *obs_out = nullptr, uint8_t *legal4_out = nullptr, int64_t host_mirror_delta = 0,
+                                 uint64_t *host_sequence = nullptr, uint64_t sequence_value = 0)
 {
     if (n == 0) return ENV2048_OK;
+    if (int rc = check_sequence(who, n, host_mirror_delta, host_sequence)) return rc;
     if (misaligned(obs_out, 16) || misaligned(legal4_out, 4)) return fail(ENV2048_ERR_ALIGNMENT, "%s: obs must be 16-byte, legal4 4-byte aligned", who);
     if (host_mirror_delta & 15) return fail(ENV2048_ERR_ALIGNMENT, "%s: host_mirror_delta must be a multiple of 16 bytes", who);
     if (host_mirror_delta && boards_in == boards_out)
@@ -197,10 +272,10 @@ static int step_state_i32_common(const char *who, int device, void *stream, uint
     DeviceScope scope(device);
     if (scope.rc) return scope.rc;
     const RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)step_index, (uint32_t)(step_index >> 32)};
-    hipLaunchKernelGGL(step_state_i32_kernel, grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, n, env_base, boards_in, boards_out,
+    hipLaunchKernelGGL(step_state_i32_kernel, grid_for(n), block_for(n), 0, (hipStream_t)stream, n, env_base, boards_in, boards_out,
                        actions, step_count_in, step_count_out, done_in, done_out, total_reward_in, total_reward_out, reward,
                        max_tile, key, reinterpret_cast<const uint2 *>(keys), obs_out, reinterpret_cast<uint32_t *>(legal4_out),
-                       host_mirror_delta);
+                       host_mirror_delta, host_sequence, sequence_value);
     return launched(who);
 }
 
@@ -225,10 +300,12 @@ int env2048_step_state_i32_keyed(int device, void *stream, uint64_t n, const uin
                                  0, 0);
 }
 
-int env2048_reset_state_i32_keyed(int device, void *stream, uint64_t n, const uint32_t *keys, int32_t *boards, int32_t *step_count,
-                                  uint8_t *done, float *total_reward, float *obs, uint8_t *legal4, int64_t host_mirror_delta)
+int env2048_reset_state_i32_keyed_signalled(int device, void *stream, uint64_t n, const uint32_t *keys, int32_t *boards, int32_t *step_count,
+                                            uint8_t *done, float *total_reward, float *obs, uint8_t *legal4, int64_t host_mirror_delta,
+                                            uint64_t *host_sequence, uint64_t sequence_value)
 {
     if (n == 0) return ENV2048_OK;
+    if (int rc = check_sequence("env2048_reset_state_i32_keyed_signalled", n, host_mirror_delta, host_sequence)) return rc;
     if (!keys || !boards) return fail(ENV2048_ERR_INVALID_ARG, "env2048_reset_keyed_i32: keys and boards are required");
     if (misaligned(keys, 8) || misaligned(boards, 16) || misaligned(obs, 16) || misaligned(legal4, 4) || misaligned(step_count, 4) ||
         misaligned(total_reward, 4))
@@ -237,9 +314,17 @@ int env2048_reset_state_i32_keyed(int device, void *stream, uint64_t n, const ui
     if (int rc = check_count(n)) return rc;
     DeviceScope scope(device);
     if (scope.rc) return scope.rc;
-    hipLaunchKernelGGL(reset_keyed_i32_kernel, grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, n, reinterpret_cast<const uint2 *>(keys),
-                       boards, obs, reinterpret_cast<uint32_t *>(legal4), step_count, done, total_reward, host_mirror_delta);
+    hipLaunchKernelGGL(reset_keyed_i32_kernel, grid_for(n), block_for(n), 0, (hipStream_t)stream, n, reinterpret_cast<const uint2 *>(keys),
+                       boards, obs, reinterpret_cast<uint32_t *>(legal4), step_count, done, total_reward, host_mirror_delta, host_sequence,
+                       sequence_value);
     return launched("env2048_reset_keyed_i32 launch");
+}
+
+int env2048_reset_state_i32_keyed(int device, void *stream, uint64_t n, const uint32_t *keys, int32_t *boards, int32_t *step_count,
+                                  uint8_t *done, float *total_reward, float *obs, uint8_t *legal4, int64_t host_mirror_delta)
+{
+    return env2048_reset_state_i32_keyed_signalled(device, stream, n, keys, boards, step_count, done, total_reward, obs, legal4,
+                                                   host_mirror_delta, nullptr, 0);
 }
 
 int env2048_reset_keyed_i32_status(int device, void *stream, uint64_t n, const uint32_t *keys, int32_t *boards, float *obs,
@@ -274,6 +359,67 @@ int env2048_step_state_i32_keyed_mirrored(int device, void *stream, uint64_t n, 
     return step_state_i32_common("env2048_step_state_i32_keyed_mirrored", device, stream, n, 0, keys, boards_in, boards_out, actions,
                                  step_count_in, step_count_out, done_in, done_out, total_reward_in, total_reward_out, reward, max_tile,
                                  0, 0, obs, legal4, host_mirror_delta);
+}
+
+int env2048_step_state_i32_keyed_signalled(int device, void *stream, uint64_t n, const uint32_t *keys, const int32_t *boards_in,
+                                           int32_t *boards_out, const int32_t *actions, const int32_t *step_count_in,
+                                           int32_t *step_count_out, const uint8_t *done_in, uint8_t *done_out, const float *total_reward_in,
+                                           float *total_reward_out, float *reward, int32_t *max_tile, float *obs, uint8_t *legal4,
+                                           int64_t host_mirror_delta, uint64_t *host_sequence, uint64_t sequence_value)
+{
+    if (n && !keys) return fail(ENV2048_ERR_INVALID_ARG, "env2048_step_state_i32_keyed_signalled: keys is NULL");
+    return step_state_i32_common("env2048_step_state_i32_keyed_signalled", device, stream, n, 0, keys, boards_in, boards_out, actions,
+                                 step_count_in, step_count_out, done_in, done_out, total_reward_in, total_reward_out, reward, max_tile,
+                                 0, 0, obs, legal4, host_mirror_delta, host_sequence, sequence_value);
+}
+
+int env2048_step_state_i32_keyed_inline(int device, void *stream, uint64_t n, const uint32_t *host_keys, const int32_t *boards_in,
+                                        int32_t *boards_out, const int32_t *host_actions, const int32_t *step_count_in,
+                                        int32_t *step_count_out, const uint8_t *done_in, uint8_t *done_out, const float *total_reward_in,
+                                        float *total_reward_out, float *reward, int32_t *max_tile, float *obs, uint8_t *legal4,
+                                        int64_t host_mirror_delta, uint64_t *host_sequence, uint64_t sequence_value)
+{
+    const char *who = "env2048_step_state_i32_keyed_inline";
+    if (n == 0) return ENV2048_OK;
+    if (n > ENV2048_INLINE_MAX_ENVS) return fail(ENV2048_ERR_INVALID_ARG, "%s: n = %llu exceeds ENV2048_INLINE_MAX_ENVS (%d)", who, (unsigned long long)n, ENV2048_INLINE_MAX_ENVS);
+    if (!host_keys || !host_actions) return fail(ENV2048_ERR_INVALID_ARG, "%s: host_keys and host_actions are required", who);
+    if (int rc = check_sequence(who, n, host_mirror_delta, host_sequence)) return rc;
+    if (misaligned(obs, 16) || misaligned(legal4, 4)) return fail(ENV2048_ERR_ALIGNMENT, "%s: obs must be 16-byte, legal4 4-byte aligned", who);
+    if (host_mirror_delta & 15) return fail(ENV2048_ERR_ALIGNMENT, "%s: host_mirror_delta must be a multiple of 16 bytes", who);
+    if (host_mirror_delta && boards_in == boards_out)
+        return fail(ENV2048_ERR_INVALID_ARG, "%s: a host mirror goes with the out-of-place form (outputs in one block of their own)", who);
+    if (!boards_in || !boards_out || !done_in || !done_out || !reward) return fail(ENV2048_ERR_INVALID_ARG, "%s: boards, done and reward are required", who);
+    if ((step_count_in == nullptr) != (step_count_out == nullptr) || (total_reward_in == nullptr) != (total_reward_out == nullptr))
+        return fail(ENV2048_ERR_INVALID_ARG, "%s: step_count / total_reward need both their in and out array", who);
+    if (misaligned(boards_in, 16) || misaligned(boards_out, 16)) return fail(ENV2048_ERR_ALIGNMENT, "%s: boards must be 16-byte aligned", who);
+    if (misaligned(host_keys, 4) || misaligned(host_actions, 4) || misaligned(step_count_in, 4) || misaligned(step_count_out, 4) ||
+        misaligned(total_reward_in, 4) || misaligned(total_reward_out, 4) || misaligned(reward, 4) || misaligned(max_tile, 4))
+        return fail(ENV2048_ERR_ALIGNMENT, "%s: misaligned 4-byte array", who);
+    DeviceScope scope(device);
+    if (scope.rc) return scope.rc;
+    InlineInputs in;  // (entries beyond n are never read by the kernel)
+    memcpy(in.keys, host_keys, n * sizeof(uint2));
+    memcpy(in.actions, host_actions, n * sizeof(int32_t));
+    hipLaunchKernelGGL(step_state_i32_inline_kernel, dim3(1), dim3(ENV2048_INLINE_MAX_ENVS), 0, (hipStream_t)stream, n, boards_in, boards_out,
+                       step_count_in, step_count_out, done_in, done_out, total_reward_in, total_reward_out, reward, max_tile, obs,
+                       reinterpret_cast<uint32_t *>(legal4), host_mirror_delta, host_sequence, sequence_value, in);
+    return launched(who);
+}
+
+// Host side of the completion word: poll until *host_sequence == value (1) or timeout_us have passed (0).  No device call.
+int env2048_wait_sequence(const uint64_t *host_sequence, uint64_t value, uint32_t timeout_us)
+{
+    if (!host_sequence || misaligned(host_sequence, 8)) return fail(ENV2048_ERR_INVALID_ARG, "env2048_wait_sequence: host_sequence is NULL or misaligned");
+    const auto *word = reinterpret_cast<const std::atomic<uint64_t> *>(host_sequence);
+    if (word->load(std::memory_order_acquire) == value) return 1;
+    const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(timeout_us);
+    for (;;) {
+        for (int spin = 0; spin < 64; ++spin) {
+            if (word->load(std::memory_order_acquire) == value) return 1;
+            __builtin_ia32_pause();
+        }
+        if (std::chrono::steady_clock::now() >= until) return word->load(std::memory_order_acquire) == value ? 1 : 0;
+    }
 }
 
 int env2048_step_state_i32(int device, void *stream, uint64_t n, uint64_t env_base, int32_t *boards, const int32_t *actions,

@@ -19,16 +19,11 @@ import numpy as np
 import torch
 
 
-_pool = None
-
-
-def _result_pool():
-    global _pool
-    if _pool is None:
-        from . import resultpool  # (imports this module for DeviceArray: resolved lazily)
-
-        _pool = resultpool.pool
-    return _pool
+# id(tensor) -> (ResultSet, field name, the tensor itself) for the tensors of pooled result sets; resultpool (which imports this
+# module for DeviceArray) fills it.  The third entry pins the identity: an id can be reused by another object once the
+# original is gone, the stored reference cannot be anything else.
+_registry: dict = {}
+_registry_get = _registry.get
 
 
 class DeviceArray(torch.Tensor):
@@ -45,12 +40,12 @@ class DeviceArray(torch.Tensor):
         return t if isinstance(t, DeviceArray) else t.as_subclass(DeviceArray)
 
     def __array__(self, dtype=None, copy=None):
-        if self.is_cuda:  # a field of a pooled result set of the reinforce.game mirrors: one copy per LAUNCH, not per array
-            hit = _result_pool().lookup(self)
-            if hit is not None:
-                host = hit[0].host_array(hit[1])
-                if host is not None:
-                    return host.astype(dtype) if dtype is not None and dtype != host.dtype else host.copy()
+        # a field of a pooled result set of the reinforce.game mirrors: one wait per LAUNCH, then host-side copies
+        hit = _registry_get(id(self))
+        if hit is not None and hit[2] is self:
+            host = hit[0].host_array(hit[1])
+            if host is not None:
+                return host.astype(dtype) if dtype is not None and dtype != host.dtype else host.copy()
         plain = self.as_subclass(torch.Tensor).detach()
         if plain.dtype == torch.bfloat16:  # NumPy has no bfloat16: widen (exact)
             plain = plain.to(torch.float32)

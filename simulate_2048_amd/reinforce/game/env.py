@@ -16,12 +16,13 @@ For throughput work use ``simulate_2048_amd.BatchedEnv2048``, which keeps boards
 
 from __future__ import annotations
 
+import threading
 from typing import NamedTuple
 
 import numpy as np
 import torch
 
-from ... import runtime
+from ... import capi, runtime
 from ...interop import key_words, keys_on_device, to_tensor, wrap
 from ...resultpool import STAGE_MAX_BYTES, pool, stager
 from .core import _board_tensor
@@ -77,6 +78,52 @@ def _actions_ptr(actions, n, rt):
     return t.data_ptr(), t
 
 
+class _InlineScratch(threading.local):
+    """Per-thread host arrays whose addresses are known: where the keys / actions of a small move are put (one NumPy
+    assignment each, which also converts dtype and layout) for env2048_step_state_i32_keyed_inline to read during the call."""
+
+    def __init__(self):
+        self.keys = np.zeros((capi.INLINE_MAX_ENVS, 2), dtype=np.uint32)
+        self.keys_i32 = self.keys.view(np.int32)
+        self.actions = np.zeros((capi.INLINE_MAX_ENVS,), dtype=np.int32)
+        self.keys_addr = self.keys.ctypes.data
+        self.actions_addr = self.actions.ctypes.data
+
+
+_inline = _InlineScratch()
+
+
+def _inline_inputs(keys, actions, n):
+    """(host address of n x 2 uint32 keys, host address of n int32 actions) when both are small HOST arrays -- the shape of the
+    reference's move loop (self_play.py:333-354: keys split and actions picked on the host for N = 2 ... 8 games) -- else None.
+    Raises the same ValueErrors as the staged path for wrong shapes."""
+    if n > capi.INLINE_MAX_ENVS:
+        return None
+    k = _host_small(keys)
+    if k is None or k.dtype.kind not in 'iu':
+        return None
+    a = _host_small(actions)
+    if a is None or a.dtype.kind not in 'iub':
+        return None
+    if k.ndim == 1 and k.size == 2:
+        k = k.reshape(1, 2)
+    if k.ndim != 2 or k.shape[1] != 2:
+        raise ValueError(f'expected PRNG keys of shape (N, 2), got {k.shape}')
+    if k.shape[0] != n:
+        raise ValueError(f'batched_step: {n} environments but {k.shape[0]} keys')
+    if a.size != n:
+        raise ValueError(f'batched_step: {n} environments but {a.size} actions')
+    s = _inline
+    if k.dtype == np.uint32:
+        s.keys[:n] = k
+    elif k.dtype == np.int32:
+        s.keys_i32[:n] = k  # the same 32 bits
+    else:
+        s.keys[:n] = k.astype(np.int64) & 0xFFFFFFFF  # keep the low 32 bits as a bit pattern
+    s.actions[:n] = a.reshape(n)
+    return s.keys_addr, s.actions_addr
+
+
 def _state_ptrs(states: GameState, rt):
     """Pointers of a state's four fields + n + keep-alive list.  Tensors that ARE the tensors of a pooled result set (the
     state came out of batched_step / batched_reset) are recognised by identity: nothing to check, nothing to convert."""
@@ -108,9 +155,13 @@ def batched_reset(keys) -> GameState:
     rs = pool.acquire(n, rt.device, stream or 0)
     try:
         p = rs.ptr
-        rt.lib.reset_state_i32_keyed(dev, stream, n, kptr, p['board'], p['step_count'], p['done'], p['total'], p['obs'], p['legal'],
-                                     rs.mirror_delta)
-        rs.mark_written(rs.mirror_delta != 0)
+        if rs.mirror_delta:  # pooled set with a pinned host mirror: the launch writes it and (small batches) signals completion
+            rt.lib.reset_state_i32_keyed_signalled(dev, stream, n, kptr, p['board'], p['step_count'], p['done'], p['total'], p['obs'],
+                                                   p['legal'], rs.mirror_delta, rs.seq_ptr, rs.next_serial())
+            rs.mark_written(True, rs.seq_ptr is not None)
+        else:
+            rt.lib.reset_state_i32_keyed(dev, stream, n, kptr, p['board'], p['step_count'], p['done'], p['total'], p['obs'], p['legal'], 0)
+            rs.mark_written()
         return GameState(board=rs.board, step_count=rs.step_count, done=rs.done, total_reward=rs.total)
     finally:
         rs.leased = False  # (the state being returned holds the tensors by now; after an error nobody does and the set is free)
@@ -129,7 +180,7 @@ def _dev(x, dtype, n, rt) -> torch.Tensor:
 def batched_step(states: GameState, actions, keys):
     """[ref env.py:193-211] one move per environment -> (GameState, reward (N,) f32, done (N,) bool, info).
 
-    ONE fused, out-of-place kernel (env2048_step_state_i32_keyed_mirrored): the input state is only read (functional API), the
+    ONE fused, out-of-place kernel (env2048_step_state_i32_keyed_signalled): the input state is only read (functional API), the
     new state, reward, done, max_tile AND the observation / legal mask of the new state are written by the same launch into a
     result set that is reused once the caller has let go of it (``resultpool``) -- a move of the reference's self-play loop
     (self_play.py:316-317,354: observation, legal mask, step) is one launch and creates no tensor.  Finished games are frozen
@@ -138,17 +189,31 @@ def batched_step(states: GameState, actions, keys):
     """
     rt = runtime.current()
     b_in, s_in, d_in, t_in, n, keep_state = _state_ptrs(states, rt)
-    kptr, nk, keep_keys = _keys_ptr(keys, rt)
-    if nk != n:
-        raise ValueError(f'batched_step: {n} environments but {nk} keys')
-    aptr, keep_actions = _actions_ptr(actions, n, rt)
     dev, stream = rt.handles()
     rs = pool.acquire(n, rt.device, stream or 0)  # (never the set the input state lives in: the caller still holds that one)
     try:
         p = rs.ptr
-        rt.lib.step_state_i32_keyed_mirrored(dev, stream, n, kptr, b_in, p['board'], aptr, s_in, p['step_count'], d_in, p['done'], t_in,
-                                             p['total'], p['reward'], p['max_tile'], p['obs'], p['legal'], rs.mirror_delta)
-        rs.mark_written(rs.mirror_delta != 0)
+        inline = _inline_inputs(keys, actions, n) if rs.mirror_delta else None
+        if inline is not None:  # host-side keys / actions of a small move ride in the kernel-argument block: nothing to stage
+            rt.lib.step_state_i32_keyed_inline(dev, stream, n, inline[0], b_in, p['board'], inline[1], s_in, p['step_count'], d_in, p['done'],
+                                               t_in, p['total'], p['reward'], p['max_tile'], p['obs'], p['legal'], rs.mirror_delta, rs.seq_ptr,
+                                               rs.next_serial())
+            rs.mark_written(True, rs.seq_ptr is not None)
+            new_state = GameState(board=rs.board, step_count=rs.step_count, done=rs.done, total_reward=rs.total)
+            return new_state, rs.reward, rs.done, {'max_tile': rs.max_tile, 'step_count': rs.step_count, 'total_reward': rs.total}
+        kptr, nk, keep_keys = _keys_ptr(keys, rt)
+        if nk != n:
+            raise ValueError(f'batched_step: {n} environments but {nk} keys')
+        aptr, keep_actions = _actions_ptr(actions, n, rt)
+        if rs.mirror_delta:
+            rt.lib.step_state_i32_keyed_signalled(dev, stream, n, kptr, b_in, p['board'], aptr, s_in, p['step_count'], d_in, p['done'], t_in,
+                                                  p['total'], p['reward'], p['max_tile'], p['obs'], p['legal'], rs.mirror_delta, rs.seq_ptr,
+                                                  rs.next_serial())
+            rs.mark_written(True, rs.seq_ptr is not None)
+        else:
+            rt.lib.step_state_i32_keyed_mirrored(dev, stream, n, kptr, b_in, p['board'], aptr, s_in, p['step_count'], d_in, p['done'], t_in,
+                                                 p['total'], p['reward'], p['max_tile'], p['obs'], p['legal'], 0)
+            rs.mark_written()
         new_state = GameState(board=rs.board, step_count=rs.step_count, done=rs.done, total_reward=rs.total)
         info = {'max_tile': rs.max_tile, 'step_count': rs.step_count, 'total_reward': rs.total}
         return new_state, rs.reward, rs.done, info

@@ -30,7 +30,8 @@ import threading
 import numpy as np
 import torch
 
-from .interop import DeviceArray
+from . import capi
+from .interop import DeviceArray, _registry
 
 _use_count = getattr(torch._C, '_storage_Use_Count', None)  # references to a StorageImpl (tensors, views, wrappers)
 
@@ -38,6 +39,7 @@ MAX_SETS_PER_KEY = 6
 MAX_KEYS = 16  # distinct (n, device, stream) keys kept; the least recently used shape's sets are dropped beyond that
 STAGE_MAX_BYTES = 16 << 10  # larger host arrays take an ordinary H2D copy (the kernel would read them across the bus)
 MIRROR_MAX_BYTES = 64 << 10  # result sets up to this size (N <= ~430) are read back through one pinned host mirror per launch
+SIGNAL_TIMEOUT_US = 50  # how long a read polls a launch's completion word before it falls back to synchronising the stream
 
 
 def _align(x: int, a: int = 16) -> int:
@@ -47,7 +49,8 @@ def _align(x: int, a: int = 16) -> int:
 class ResultSet:
     __slots__ = ('n', 'arena', 'storage', 'cdata', 'board', 'obs', 'step_count', 'max_tile', 'total', 'reward', 'legal', 'done',
                  'tensors', 'ptr', 'idle_refs', 'idle_use', 'version', 'pooled', 'leased', 'layout', 'serial',
-                 'mirror', 'mirror_fields', 'mirror_key', 'mirror_copies', 'mirror_delta', 'direct_serial', 'stream')
+                 'mirror', 'mirror_fields', 'mirror_key', 'mirror_copies', 'mirror_delta', 'direct_serial', 'stream',
+                 'seq_ptr', 'signal_serial', 'signal_hits', 'stream_syncs', 'wait_sequence')
 
     def __init__(self, n: int, device: torch.device):
         self.n = n
@@ -78,10 +81,7 @@ class ResultSet:
         self.tensors = (self.board, self.obs, self.step_count, self.total, self.done, self.max_tile, self.reward, self.legal)
         self.ptr = {name: base + offsets[name] for name, _ in sizes}
         self.version = arena._version  # ONE counter: the carved tensors are views of the arena and share its version counter
-        ts = self.tensors  # (measured exactly the way idle() measures: indexing adds no reference, a loop variable would)
-        self.idle_refs = (sys.getrefcount(ts[0]), sys.getrefcount(ts[1]), sys.getrefcount(ts[2]), sys.getrefcount(ts[3]),
-                          sys.getrefcount(ts[4]), sys.getrefcount(ts[5]), sys.getrefcount(ts[6]), sys.getrefcount(ts[7]))
-        self.idle_use = _use_count(self.cdata) if _use_count else -1
+        self.recount_idle()
         self.pooled = False
         self.leased = False  # set by ResultPool.acquire, cleared by the mirror once the caller-facing references exist
         # host mirror (see host_array): field -> (offset, bytes, NumPy dtype, shape); created on the first NumPy read
@@ -95,15 +95,40 @@ class ResultSet:
         self.mirror_key = None
         self.mirror_delta = 0  # (mirror address) - (arena address): what the mirrored entry points of the C-ABI take
         self.direct_serial = -1  # the launch (serial) whose kernel wrote the mirror itself
+        self.seq_ptr = None  # address of the mirror's completion word (single-workgroup launches: n <= capi.SIGNAL_MAX_ENVS)
+        self.signal_serial = -1  # the launch (serial) that was asked to store its serial into the completion word
+        self.wait_sequence = None
         # the pool keeps sets per launch stream, so this is the stream every launch into this set is enqueued on
         self.stream = torch.cuda.current_stream(arena.device) if arena.is_cuda else None
-        if arena.is_cuda and arena.numel() <= MIRROR_MAX_BYTES:
-            self.mirror = torch.empty((arena.numel(),), dtype=torch.uint8, pin_memory=True)
-            host = self.mirror.numpy()
-            self.mirror_fields = {k: host[o:o + b].view(dt).reshape(shape) for k, (o, b, dt, shape) in self.layout.items()}
-            delta = self.mirror.data_ptr() - base
-            self.mirror_delta = delta if delta % 16 == 0 else 0
-        self.mirror_copies = 0  # device-to-host copies made for NumPy reads (tests / tools read it)
+        self.mirror_copies = 0  # device-to-host copies made for NumPy reads (tests / tools read these three)
+        self.signal_hits = 0  # reads that found the launch's completion word (no stream synchronisation)
+        self.stream_syncs = 0  # reads that synchronised the stream
+
+    def recount_idle(self) -> None:
+        """Take the current reference counts as "nobody but the set (and the pool's registry) holds these tensors"."""
+        ts = self.tensors  # (measured exactly the way idle() measures: indexing adds no reference, a loop variable would)
+        self.idle_refs = (sys.getrefcount(ts[0]), sys.getrefcount(ts[1]), sys.getrefcount(ts[2]), sys.getrefcount(ts[3]),
+                          sys.getrefcount(ts[4]), sys.getrefcount(ts[5]), sys.getrefcount(ts[6]), sys.getrefcount(ts[7]))
+        self.idle_use = _use_count(self.cdata) if _use_count else -1
+
+    def attach_mirror(self) -> None:
+        """Give this set its pinned host mirror (+ 16 bytes for the completion word).  Only the POOL calls this, and only for
+        sets it keeps: a launch into a mirrored set writes pinned memory asynchronously, so the mirror must stay allocated
+        until that launch is done -- the pool holds its sets (and parks the ones it drops in a graveyard until an event
+        behind their last launch has completed); a set nobody keeps takes no mirror and the plain copy path."""
+        arena = self.arena
+        if self.mirror is not None or not arena.is_cuda or arena.numel() > MIRROR_MAX_BYTES:
+            return
+        size = arena.numel()
+        self.mirror = torch.zeros((size + 16,), dtype=torch.uint8, pin_memory=True)  # (zeros: completion word 0 = no launch yet)
+        host = self.mirror.numpy()
+        self.mirror_fields = {k: host[o:o + b].view(dt).reshape(shape) for k, (o, b, dt, shape) in self.layout.items()}
+        delta = self.mirror.data_ptr() - arena.data_ptr()
+        if delta % 16 == 0:
+            self.mirror_delta = delta
+            if self.n <= capi.SIGNAL_MAX_ENVS:
+                self.seq_ptr = self.mirror.data_ptr() + size
+                self.wait_sequence = capi.library().wait_sequence
 
     def idle(self) -> bool:
         """Nobody but this set references its tensors or their memory, and no other thread is between acquire() and its return."""
@@ -115,32 +140,47 @@ class ResultSet:
                 and sys.getrefcount(ts[3]) == refs[3] and sys.getrefcount(ts[4]) == refs[4] and sys.getrefcount(ts[5]) == refs[5]
                 and sys.getrefcount(ts[6]) == refs[6] and sys.getrefcount(ts[7]) == refs[7])
 
-    def mark_written(self, mirrored: bool = False) -> None:
+    def next_serial(self) -> int:
+        """The serial the NEXT launch into this set will have (what a *_signalled launch stores into the completion word)."""
+        return self.serial + 1
+
+    def mark_written(self, mirrored: bool = False, signalled: bool = False) -> None:
         """A launch has just been given this set to fill: the stash is valid from the current version on.  ``mirrored``: the
-        launch writes the host mirror too (it was given ``mirror_delta``)."""
+        launch writes the host mirror too (it was given ``mirror_delta``); ``signalled``: it also stores ``next_serial()`` into
+        the mirror's completion word when it is done."""
         self.version = self.arena._version
         self.serial += 1
         if mirrored:
             self.direct_serial = self.serial
+            if signalled:
+                self.signal_serial = self.serial
 
     def host_array(self, name: str):
         """Field `name` of this set as a NumPy array backed by the set's PINNED HOST MIRROR, or None when the set is not
         mirrored (host tensors; arenas above MIRROR_MAX_BYTES).  The reference's loop reads four arrays of every state back
         (``np.array(observations)``, ``np.array(legal_masks)``, ``np.array(rewards)``, ``np.array(dones)``,
         self_play.py:346-356): as four device-to-host copies that is four synchronisations (~18 us each).  Here the kernel
-        that fills the set writes every result into the mirror as well (``mirror_delta``, env2048_*_mirrored), so the FIRST read
-        after a launch is one stream synchronisation and every further read of that state is a host-side copy.  The mirror is
-        current for one (launch serial, torch version) pair: after an in-place torch edit of any field it is refreshed with
-        one asynchronous copy of the set.  The caller gets a COPY (what np.array means); the mirror itself is never handed out."""
+        that fills the set writes every result into the mirror as well (``mirror_delta``, env2048_*_signalled) and then stores
+        its serial into the mirror's completion word, so the FIRST read after a launch polls that word for a few microseconds
+        (no stream synchronisation: that is an interrupt-driven wake-up of ~20 us around a 4 us kernel; after
+        SIGNAL_TIMEOUT_US without the word the read synchronises the stream after all, so a lost launch cannot hang it) and
+        every further read of that state is a host-side copy.  The mirror is current for one (launch serial, torch version)
+        pair: after an in-place torch edit of any field it is refreshed with one asynchronous copy of the set.  The caller gets
+        a COPY (what np.array means); the mirror itself is never handed out."""
         if self.mirror is None:
             return None
         arena = self.arena
         key = (self.serial, arena._version)
         if self.mirror_key != key:
             if self.direct_serial == self.serial and arena._version == self.version:
-                self.stream.synchronize()  # the launch has written the mirror itself: wait for it (on ITS stream)
+                # the launch has written the mirror itself: wait for its completion word, else for ITS stream
+                if self.signal_serial == self.serial and self.wait_sequence(self.seq_ptr, self.serial, SIGNAL_TIMEOUT_US):
+                    self.signal_hits += 1
+                else:
+                    self.stream.synchronize()
+                    self.stream_syncs += 1
             else:
-                self.mirror.copy_(arena, non_blocking=True)
+                self.mirror[:arena.numel()].copy_(arena, non_blocking=True)  # (the mirror's tail is the completion word)
                 torch.cuda.current_stream(arena.device).synchronize()
                 self.mirror_copies += 1
             self.mirror_key = key
@@ -162,8 +202,24 @@ class ResultPool:
     def __init__(self):
         self._sets: dict = {}
         self._lock = threading.Lock()
-        self.registry: dict = {}  # id(tensor) -> (ResultSet, field name); only tensors of POOLED sets (kept alive by the pool)
+        self.registry: dict = _registry  # id(tensor) -> (ResultSet, field name, tensor); only tensors of POOLED sets (kept alive by the pool)
         self.created = 0  # sets ever created (tests read it)
+        # sets the pool has let go of (shape eviction, clear()) whose last launch may still be writing their pinned mirror:
+        # (event recorded on the set's stream at the time of the drop, set); released once the event has completed
+        self._graveyard: list = []
+
+    def _bury(self, sets) -> None:
+        for old in sets:
+            for t in old.tensors:
+                self.registry.pop(id(t), None)
+            if old.mirror is not None and old.stream is not None:
+                event = torch.cuda.Event()
+                event.record(old.stream)  # behind every launch that was ever given this set (they all went to this stream)
+                self._graveyard.append((event, old))
+
+    def _reap(self) -> None:
+        if self._graveyard:
+            self._graveyard = [(event, old) for event, old in self._graveyard if not event.query()]
 
     def acquire(self, n: int, device: torch.device, stream: int = 0) -> ResultSet:
         key = (n, device, stream)
@@ -171,12 +227,10 @@ class ResultPool:
             sets = self._sets.pop(key, None)  # (re-inserted below: dict order = recency of use)
             if sets is None:
                 sets = []
+                self._reap()
                 while len(self._sets) >= MAX_KEYS:  # a caller cycling through many batch sizes must not pin memory for all of them
-                    _, dropped = next(iter(self._sets.items()))
-                    for old in dropped:
-                        for t in old.tensors:
-                            self.registry.pop(id(t), None)
-                    del self._sets[next(iter(self._sets))]
+                    oldest = next(iter(self._sets))
+                    self._bury(self._sets.pop(oldest))
             self._sets[key] = sets
             for rs in sets:
                 if rs.idle():
@@ -188,22 +242,28 @@ class ResultPool:
             if len(sets) < MAX_SETS_PER_KEY and _use_count is not None:
                 sets.append(rs)
                 rs.pooled = True
+                rs.attach_mirror()  # (only sets the pool keeps: see attach_mirror)
                 reg = self.registry
                 for name, t in zip(('board', 'obs', 'step_count', 'total', 'done', 'max_tile', 'reward', 'legal'), rs.tensors):
-                    reg[id(t)] = (rs, name)
+                    reg[id(t)] = (rs, name, t)
+                del t  # (the loop variable is a reference too)
+                rs.recount_idle()  # the registry's references belong to the idle state
             return rs
 
     def lookup(self, tensor):
         """(set, field) if `tensor` IS one of a pooled set's tensors (the very object), else None."""
         hit = self.registry.get(id(tensor))
-        if hit is not None and getattr(hit[0], hit[1]) is tensor:
+        if hit is not None and hit[2] is tensor:
             return hit
         return None
 
     def clear(self) -> None:
         with self._lock:
+            for sets in self._sets.values():
+                self._bury(sets)
             self._sets.clear()
             self.registry.clear()
+            self._reap()
 
 
 class HostStager:

@@ -18,17 +18,25 @@ import torch
 from . import capi
 
 
+# torch's current stream of a device as a raw hipStream_t handle: the private accessor inductor uses costs 0.2 us, the public
+# Stream object 2.2 us -- a sixth of the host work of a reference-sized move.  Falls back to the public API when it is gone.
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 class Runtime:
     def __init__(self, lib, device):
         self.lib = lib
         self.device = torch.device(device)
+        self._index = self.device.index if self.device.type == 'cuda' else -1
 
     def handles(self):
         """(device ordinal, hipStream_t of torch's current stream) for a C-ABI call."""
         if self.device.type != 'cuda':
             return -1, None
-        index = self.device.index if self.device.index is not None else torch.cuda.current_device()
-        return index, torch.cuda.current_stream(self.device).cuda_stream
+        index = self._index if self._index is not None else torch.cuda.current_device()
+        if _raw_stream is not None:
+            return index, _raw_stream(index) or None
+        return index, torch.cuda.current_stream(self.device).cuda_stream or None
 
     def synchronize(self) -> None:
         if self.device.type == 'cuda':

@@ -471,6 +471,100 @@ def test_numpy_reads_of_a_state_come_from_the_host_mirror():
 
 
 @pytest.mark.gpu
+def test_the_fast_move_path_is_present_on_this_box():
+    """the 18-microsecond move depends on a private torch symbol (``torch._C._storage_Use_Count``: without it
+    no result set is ever reused), on pinned-memory mirrors and on the completion word.  None of them failing is an error --
+    the mirrors fall back to slower paths -- so THIS test fails loudly when a torch upgrade (or anything else) takes the fast
+    path away.  After a warm-up, one move of the reference's loop at N = 8 (self_play.py:316-317,346-356: two getters, the
+    step, four np.array read-backs): no new ResultSet, exactly ONE C-ABI launch, no device-to-host copy, no stream
+    synchronisation (the read-backs poll the launch's completion word)."""
+    from simulate_2048_amd import runtime
+
+    assert resultpool._use_count is not None, 'torch._C._storage_Use_Count is gone: result sets are never reused (3x slower moves)'
+    n = 8
+    rng = np.random.default_rng(77)
+    resultpool.pool.clear()
+    rt = runtime.current()
+    calls = []
+
+    class Spy:  # counts the C-ABI launches the mirrors make (wait_sequence is a host-side poll, not a launch)
+        def __init__(self, lib):
+            self._lib = lib
+
+        def __getattr__(self, name):
+            fn = getattr(self._lib, name)
+            if not callable(fn) or name == 'wait_sequence':
+                return fn
+
+            def counted(*args, **kwargs):
+                calls.append(name)
+                return fn(*args, **kwargs)
+
+            return counted
+
+    with runtime.use(Spy(rt.lib), rt.device):
+        states = batched_reset(_loop_keys(rng, n))
+
+        def one_move(states):
+            observations = batched_get_observation(states)
+            legal_masks = batched_get_legal_actions(states)
+            host_obs, host_legal = np.array(observations), np.array(legal_masks)
+            del observations, legal_masks
+            new_states, rewards, dones, _ = batched_step(states, (host_legal.argmax(axis=1)).astype(np.int32), _loop_keys(rng, n))
+            return new_states, host_obs, np.array(rewards), np.array(dones)
+
+        for _ in range(10):  # warm-up: the pool reaches its steady state (two sets alternate)
+            states, *_ = one_move(states)
+        created = resultpool.pool.created
+        sets = {id(rs): rs for sets in resultpool.pool._sets.values() for rs in sets}
+        before = {k: (rs.mirror_copies, rs.stream_syncs, rs.signal_hits) for k, rs in sets.items()}
+        calls.clear()
+        moves = 50
+        for _ in range(moves):
+            prev = np.array(states.board).reshape(n, 16)
+            states, host_obs, host_rewards, host_dones = one_move(states)
+        assert resultpool.pool.created == created, 'a steady-state move allocated a new ResultSet'
+        assert calls == ['step_state_i32_keyed_inline'] * moves, calls[:6]  # (host-side keys / actions: the inline form)
+        copies = sum(rs.mirror_copies - before[k][0] for k, rs in sets.items())
+        syncs = sum(rs.stream_syncs - before[k][1] for k, rs in sets.items())
+        hits = sum(rs.signal_hits - before[k][2] for k, rs in sets.items())
+        assert copies == 0, f'{copies} device-to-host copies for read-backs the launch should have mirrored'
+        assert hits + syncs == moves, (hits, syncs)  # one wait per launch: the first read-back of its results ...
+        assert syncs <= moves // 10, f'{syncs} of {moves} moves fell back to synchronising the stream'  # ... found the completion word (a rare timeout is legal)
+        assert all(rs.seq_ptr is not None and rs.mirror_delta != 0 for rs in sets.values())
+    torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+def test_more_live_states_than_the_pool_keeps_take_no_mirror():
+    """a set the pool does not keep is referenced by nobody once the call returns, so its pinned mirror
+    would go back to torch's host allocator while the launch is still writing it.  Such sets get NO mirror (delta 0, plain
+    copy path); the values read back are the same either way.  Sets the pool drops (clear, shape eviction) are parked until an
+    event behind their last launch has completed."""
+    n = 8
+    rng = np.random.default_rng(99)
+    resultpool.pool.clear()
+    held = [batched_reset(_loop_keys(rng, n)) for _ in range(resultpool.MAX_SETS_PER_KEY + 3)]  # the caller keeps every state
+    looked = [resultpool.pool.lookup(s.board) for s in held]
+    assert all(hit is not None for hit in looked[:resultpool.MAX_SETS_PER_KEY]) and all(hit is None for hit in looked[resultpool.MAX_SETS_PER_KEY:])
+    assert all(hit[0].mirror_delta != 0 and hit[0].mirror is not None for hit in looked[:resultpool.MAX_SETS_PER_KEY])
+    keys = _loop_keys(rng, n)
+    want = oracle.reset_keyed_i32(np.asarray(keys).astype(np.uint32))
+    overflow = batched_reset(keys)  # an un-pooled set: no mirror, results through the plain device-to-host path
+    assert resultpool.pool.lookup(overflow.board) is None
+    assert np.array_equal(np.array(overflow.board).reshape(n, 16), want)
+    pooled_again = held[0]
+    assert np.array(pooled_again.board).shape == (n, 4, 4)
+    # dropping pooled sets parks them (with their mirrors) behind an event on their stream
+    resultpool.pool.clear()
+    assert len(resultpool.pool._graveyard) <= resultpool.MAX_SETS_PER_KEY
+    torch.cuda.synchronize()
+    resultpool.pool._reap()
+    assert resultpool.pool._graveyard == []
+    del held
+
+
+@pytest.mark.gpu
 def test_host_mirror_waits_for_the_stream_the_move_was_launched_on():
     """A move enqueued on a side stream behind a long-running kernel, read back while ANOTHER stream is current: the NumPy read
     synchronises the stream the launch went to (the set is bound to it), so it never sees a half-written mirror."""

@@ -821,6 +821,83 @@ def test_mirrored_step_and_reset_write_the_host_block_too(lib):
     assert e.value.code == capi.ERR_INVALID_ARG
 
 
+def test_signalled_launches_publish_their_serial_after_the_mirror(lib):
+    """env2048_*_signalled: a single-workgroup launch with a host mirror stores `sequence_value` into
+    the caller's pinned completion word AFTER all its result stores -- so a host that sees the value WITHOUT synchronising the
+    stream finds the complete results in the mirror.  200 back-to-back moves per size, each checked against the oracle from
+    the mirror alone (no stream synchronisation anywhere in the loop); n = 1 ... 512 covers one to eight waves (the barrier
+    in front of the word spans the whole workgroup, lanes beyond n included).  Refused: a word without a mirror, n > 512,
+    a misaligned word.  env2048_wait_sequence times out (returns False) on a value nobody writes."""
+    rng = np.random.default_rng(404)
+    for n in (1, 2, 8, 63, 64, 65, 100, 333, 512):
+        sizes = [('board', 64 * n), ('obs', 64 * n), ('step_count', 4 * n), ('total', 4 * n), ('done', n), ('max_tile', 4 * n), ('reward', 4 * n),
+                 ('legal', 4 * n)]
+        off, at = {}, 0
+        for name, size in sizes:
+            off[name] = at
+            at = (at + size + 15) // 16 * 16
+        blocks = [torch.zeros((at,), dtype=torch.uint8, device='cuda') for _ in range(2)]  # ping-pong: out-of-place steps
+        hosts = [torch.zeros((at + 16,), dtype=torch.uint8).pin_memory() for _ in range(2)]
+        for b, h in zip(blocks, hosts):
+            assert (h.data_ptr() - b.data_ptr()) % 16 == 0
+
+        def field(buf, name, dtype, shape):
+            return buf[off[name]:off[name] + dict(sizes)[name]].view(dtype).reshape(shape)
+
+        keys = rng.integers(0, 1 << 32, size=(n, 2), dtype=np.uint64).astype(np.uint32)
+        k = cu(keys.view(np.int32))
+        q = {name: blocks[0].data_ptr() + o for name, o in off.items()}
+        serial = 1
+        lib.reset_state_i32_keyed_signalled(DEV, stream(), n, p(k), q['board'], q['step_count'], q['done'], q['total'], q['obs'], q['legal'],
+                                            hosts[0].data_ptr() - blocks[0].data_ptr(), hosts[0].data_ptr() + at, serial)
+        assert lib.wait_sequence(hosts[0].data_ptr() + at, serial, 2_000_000), 'the reset never published its serial'
+        host = hosts[0].numpy()
+        state = {'boards': field(host, 'board', np.int32, (n, 16)).copy(), 'step_count': field(host, 'step_count', np.int32, (n,)).copy(),
+                 'done': field(host, 'done', np.uint8, (n,)).copy(), 'total_reward': field(host, 'total', np.float32, (n,)).copy()}
+        np.testing.assert_array_equal(state['boards'], oracle.reset_keyed_i32(keys))
+        cur = 0
+        for move in range(200 if n <= 100 else 40):
+            keys = rng.integers(0, 1 << 32, size=(n, 2), dtype=np.uint64).astype(np.uint32)
+            actions = rng.integers(0, 4, size=n).astype(np.int32)
+            k, a = cu(keys.view(np.int32)), cu(actions)
+            src = {name: blocks[cur].data_ptr() + o for name, o in off.items()}
+            dst = {name: blocks[1 - cur].data_ptr() + o for name, o in off.items()}
+            serial += 1
+            word = hosts[1 - cur].data_ptr() + at
+            torch.cuda.current_stream().synchronize()  # (k / a uploaded; from here on NO synchronisation until the mirror is read)
+            lib.step_state_i32_keyed_signalled(DEV, stream(), n, p(k), src['board'], dst['board'], p(a), src['step_count'], dst['step_count'],
+                                               src['done'], dst['done'], src['total'], dst['total'], dst['reward'], dst['max_tile'], dst['obs'],
+                                               dst['legal'], hosts[1 - cur].data_ptr() - blocks[1 - cur].data_ptr(), word, serial)
+            assert lib.wait_sequence(word, serial, 2_000_000), (n, move)
+            host = hosts[1 - cur].numpy()
+            ref = oracle.step_state_i32_keyed(state['boards'], actions, state['step_count'], state['done'], state['total_reward'], keys)
+            np.testing.assert_array_equal(field(host, 'board', np.int32, (n, 16)), ref['boards'], err_msg=f'n={n} move={move}')
+            np.testing.assert_array_equal(field(host, 'reward', np.float32, (n,)), ref['reward'])
+            np.testing.assert_array_equal(field(host, 'done', np.uint8, (n,)), ref['done'])
+            np.testing.assert_array_equal(field(host, 'step_count', np.int32, (n,)), ref['step_count'])
+            np.testing.assert_array_equal(field(host, 'total', np.float32, (n,)), ref['total_reward'])
+            np.testing.assert_array_equal(field(host, 'max_tile', np.int32, (n,)), ref['max_tile'])
+            status = oracle.status_batch(oracle.pack_values(ref['boards']).reshape(n, 16))
+            np.testing.assert_array_equal(field(host, 'obs', np.float32, (n, 16)), status['obs'])
+            state = {'boards': ref['boards'], 'step_count': ref['step_count'], 'done': ref['done'], 'total_reward': ref['total_reward']}
+            cur = 1 - cur
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(field(blocks[cur].cpu().numpy(), 'board', np.int32, (n, 16)), state['boards'])  # device copy too
+    assert lib.wait_sequence(word, serial + 1000, 200) is False  # nobody writes that value: a timeout, not a hang
+    n = 8
+    args = (DEV, stream(), n, p(k[:n].contiguous()), src['board'], dst['board'], p(a[:n].contiguous()), src['step_count'], dst['step_count'],
+            src['done'], dst['done'], src['total'], dst['total'], dst['reward'], dst['max_tile'], dst['obs'], dst['legal'])
+    with pytest.raises(capi.Env2048Error, match='goes with a host mirror'):
+        lib.step_state_i32_keyed_signalled(*args, 0, word, 1)
+    with pytest.raises(capi.Env2048Error, match='8-byte aligned'):
+        lib.step_state_i32_keyed_signalled(*args, hosts[0].data_ptr() - blocks[0].data_ptr(), word + 4, 1)
+    big_keys = cu(np.zeros((513, 2), dtype=np.int32))
+    big = torch.zeros((513 * 200,), dtype=torch.uint8, device='cuda')
+    with pytest.raises(capi.Env2048Error, match='single-workgroup'):
+        lib.reset_state_i32_keyed_signalled(DEV, stream(), 513, p(big_keys), big.data_ptr(), None, None, None, None, None, 16, word, 1)
+    torch.cuda.synchronize()
+
+
 def test_step_state_i32_matches_oracle(lib):
     """Fused reinforce/game step on int32 value boards: done-guard, bookkeeping, JAX is_done."""
     rng = np.random.default_rng(11)

@@ -56,10 +56,14 @@ def main():
             'move_with_readback_us_numpy_inputs': round(run(n, moves, False, True), 2),
         }
     out['readback'] = ('np.array(...) of a pooled result reads the set\'s pinned host mirror, which the launch itself wrote '
-                       '(env2048_step_state_i32_keyed_mirrored): the first read after a launch is one stream synchronisation, further reads '
-                       f'of that state are host copies (resultpool.ResultSet.host_array; sets above {resultpool.MIRROR_MAX_BYTES >> 10} KiB are '
-                       'read array by array, one device-to-host copy each)')
+                       '(env2048_step_state_i32_keyed_signalled): the first read after a launch polls the launch\'s completion word in the '
+                       f'mirror (n <= 512; falls back to one stream synchronisation after {resultpool.SIGNAL_TIMEOUT_US} us or for larger n), '
+                       'further reads of that state are host copies (resultpool.ResultSet.host_array; sets above '
+                       f'{resultpool.MIRROR_MAX_BYTES >> 10} KiB are read array by array, one device-to-host copy each)')
     out['result_sets_created'] = resultpool.pool.created
+    sets = [rs for group in resultpool.pool._sets.values() for rs in group]
+    out['first_reads_served_by'] = {'completion_word': sum(rs.signal_hits for rs in sets), 'stream_synchronize': sum(rs.stream_syncs for rs in sets),
+                                    'device_to_host_copy': sum(rs.mirror_copies for rs in sets)}
     print(json.dumps(out, indent=1))
 
 
