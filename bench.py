@@ -21,12 +21,14 @@ block is repeated R times (>= --min-ms of GPU time in total); every block is tim
 clock and HIP events on the launch stream), the per-block MAX over ranks is taken, and the MEDIAN
 block gives `value` / `ms_per_step` (min and spread are reported next to it).
 
-The roofline object says what bounds the dominant kernel AT THIS SIZE: at 2^20 boards the working
-set (16 MiB boards + action pool + outputs) lives in the 256 MiB Infinity Cache and the kernel is
-VALU-issue-bound, so `bound` is "valu" and `hbm_resident_equiv` only restates the algorithmic bytes
-over the launch time.  `hbm_cold` is a second timed leg in the same run that defeats cache
-residency at the same launch size (round-robin over enough disjoint buffer sets to exceed twice the
-Infinity Cache): that one is a real HBM fraction.
+The roofline object is the metric BASELINE.json asks for: bound "hbm", achieved =
+ALGORITHMIC bytes per launch (38 B x boards) / the launch duration measured with HIP events in this
+run, peak = 8 TB/s, frac = achieved / peak.  At 2^20 boards the working set (16 MiB boards + action
+pool + outputs) lives in the 256 MiB Infinity Cache, so for the headline leg that fraction is a
+cache-resident equivalent and says so (`regime`); `roofline.hbm_cold` is a second timed leg in the same
+run that defeats cache residency at the same launch size (round-robin over enough disjoint buffer sets
+to exceed twice the Infinity Cache): that one is a true HBM fraction.  `roofline.valu` keeps the
+instruction-issue analysis (what the resident kernel is nearest to on chip).
 
 Prints exactly one JSON line on rank 0.
 """
@@ -302,18 +304,30 @@ def valu_ceiling(waves_per_simd: int = 4):
 
 
 def build_roofline(args, lib, n: int, flags: int, launch_s: float, obs_bytes: int) -> dict:
-    """The roofline object of a run whose dominant kernel is one env2048_step launch over n boards taking launch_s."""
+    """The roofline object of a run whose dominant kernel is one env2048_step launch over n boards taking launch_s:
+    SURVEY 8(d)'s definition at the top level (algorithmic bytes / launch time against the HBM peak), the VALU-issue analysis
+    of the cache-resident regime under `valu`."""
     bytes_per_launch = ALGO_BYTES_PER_STEP * n + (n * (1 + 16 * obs_bytes) if args.extras else 0)
     algo_gbs = bytes_per_launch / launch_s / 1e9
     working_set = n * (16 + 8 + 4 + 1) + (n * (1 + 16 * obs_bytes) if args.extras else 0)  # boards + 8-array action pool + outputs
     resident = working_set <= INFINITY_CACHE_BYTES
-    prof = None if args.extras else load_step_profile(n, 'resident')
     # the library's own launch policy (env2048_step_sequence_plan), not a copy of its size rules: the timed region is one
     # env2048_step_sequence call, which may run the batch as two half-batch chains on two streams
     plan = lib.step_sequence_plan(n, args.steps, flags)
+    leg = 'resident' if plan['chains'] == 2 else 'resident_one_chain'  # counters and kernel stats of the SHAPE that is timed
+    prof = None if args.extras else load_step_profile(n, leg)
     tiling = plan['boards_per_lane']
     kernel = f'step_kernel<false, false, {tiling}>' if not args.extras else f'step_kernel<true, false, {tiling}>'
     roofline = {
+        'bound': 'hbm',
+        'achieved': algo_gbs,
+        'peak': HBM_PEAK_GBS,
+        'unit': 'GB/s',
+        'frac': algo_gbs / HBM_PEAK_GBS,
+        'regime': (f'cache-resident: the {working_set / 2**20:.0f} MiB working set of back-to-back steps lives in the 256 MiB Infinity Cache, so this '
+                   f'fraction (algorithmic bytes / launch time / 8 TB/s, SURVEY 8(d)) is an EQUIVALENT, not bytes that crossed the HBM pins; the '
+                   f'true HBM fraction of this kernel is roofline.hbm_cold' if resident else
+                   'HBM: the working set exceeds the Infinity Cache'),
         'kernel': kernel,
         'launch_plan': plan,
         'launches_per_step': plan['chains'],
@@ -323,43 +337,34 @@ def build_roofline(args, lib, n: int, flags: int, launch_s: float, obs_bytes: in
                                ('' if plan['chains'] == 1 else '; the step is two half-batch launches on two streams that overlap each '
                                 'other, each lasting about one period (the rocprofv3 average of the half-batch kernel)'),
         'algorithmic_bytes_per_launch': bytes_per_launch,
-        'traffic': None if prof is None else prof.get('fabric_bytes_per_launch'),
-        'traffic_kind': 'fabric bytes per launch (2*FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes): L2 <-> Infinity '
-                        'Cache/HBM requests -- Infinity-Cache hits are counted, so this is HBM traffic only for the cold leg',
-        'traffic_source': None if prof is None else dict(source=prof.get('source'), stale=prof['stale']),
-        'rocprof_kernel_stats': load_kernel_stats('resident' if plan['chains'] == 2 else 'resident_one_chain'),
+        'traffic': None if prof is None else prof.get('fabric_bytes_per_launch'),  # (the table is scaled to one step over the whole batch)
+        'traffic_kind': 'fabric bytes per step over the whole batch (2*FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes of the timed '
+                        'shape): L2 <-> Infinity Cache/HBM requests -- Infinity-Cache hits are counted, so this is HBM traffic only for the cold leg',
+        'traffic_source': None if prof is None else dict(source=prof.get('source'), leg=leg, stale=prof['stale']),
+        'rocprof_kernel_stats': load_kernel_stats(leg),
     }
     if resident and prof is not None and prof.get('valu_insts_per_launch'):
-        ginstr = prof['valu_insts_per_launch'] / launch_s / 1e9
+        valu_per_step = prof['valu_insts_per_launch']  # (scaled to one step over the whole batch by tools/summarize_profiles.py)
+        ginstr = valu_per_step / launch_s / 1e9
         waves_per_simd = max(1, min(8, round(n / (64 * tiling) / 1024)))  # both half-batch chains are resident together
         peak, peak_source, real_stream = valu_ceiling(4 if waves_per_simd >= 4 else 2 if waves_per_simd >= 2 else 1)
-        per_lane = prof['valu_insts_per_launch'] * 64 / n  # wave64 instructions x 64 lanes / boards
-        roofline.update({
-            'bound': 'valu',
+        per_lane = valu_per_step * 64 / n  # wave64 instructions x 64 lanes / boards
+        roofline['valu'] = {
             'achieved': ginstr,
             'peak': peak,
             'peak_source': peak_source,
             'unit': 'G wave-instr/s',
             'frac': ginstr / peak,
-            'why': f'working set {working_set / 2**20:.0f} MiB is Infinity-Cache resident at this size, so no HBM fraction can be quoted '
-                   f'for this leg; of the on-chip limits VALU issue is the nearest: {per_lane:.0f} VALU instructions per board-step '
-                   f'(SQ_INSTS_VALU {prof["valu_insts_per_launch"]:.0f} wave64 instructions per launch = {prof["valu_insts_per_launch"] / n:.2f} per board, '
+            'why': f'of the on-chip limits of the cache-resident regime VALU issue is the nearest: {per_lane:.0f} VALU instructions per board-step '
+                   f'(SQ_INSTS_VALU {valu_per_step:.0f} wave64 instructions per step = {valu_per_step / n:.2f} per board, '
                    f'x 64 lanes / board), against the MEASURED issue ceiling of this opcode mix at {waves_per_simd} waves per SIMD.  '
-                   f'The launch is 15-20 % above its memory-only floor (tools/microbench, DESIGN 6.1); the HBM fraction of this '
-                   f'kernel is roofline.hbm_cold',
+                   f'The launch is 15-20 % above its memory-only floor (tools/microbench, DESIGN 6.1)',
             'vs_real_instruction_stream': None if not real_stream else {
                 'sustained_g_wave_instr_per_s': real_stream['saturated_g_wave_instr_per_s'],
                 'frac': ginstr / real_stream['saturated_g_wave_instr_per_s'], 'source': real_stream['source'],
                 'note': 'what the SAME instruction stream sustains with the boards in registers (env2048_rollout, any occupancy from 8 waves '
                         'per SIMD): the practical VALU ceiling of this code; `peak` above is the stricter single-opcode-probe bound'},
-            'hbm_resident_equiv': {'achieved': algo_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': algo_gbs / HBM_PEAK_GBS,
-                                   'note': 'algorithmic bytes / launch time; NOT an HBM fraction while the working set is cache-resident'},
-        })
-    else:
-        roofline.update({'bound': 'hbm', 'achieved': algo_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': algo_gbs / HBM_PEAK_GBS})
-        if resident:
-            roofline['why'] = ('working set is Infinity-Cache resident and no fresh VALU counter profile is committed for this size: '
-                               'algorithmic bytes / launch time is given, see hbm_cold for the HBM fraction')
+        }
     return roofline
 
 
@@ -373,6 +378,121 @@ def workload_text(n: int) -> str:
 # ------------------------------------------------------------------------------------------------
 # one rank
 # ------------------------------------------------------------------------------------------------
+class RankComm:
+    """The only collective traffic of the benchmark: the barrier that brackets a timed block, the max over ranks of the block
+    times and the gather of the per-rank medians (never on the hot path).  `backend` None = a single rank without a process
+    group; 'nccl' = RCCL with the reductions on `device`; 'gloo' = CPU tensors (rehearsals, CPU tests)."""
+
+    def __init__(self, backend, device=None):
+        import torch
+
+        self.torch = torch
+        self.dist = None
+        self.world = 1
+        self.reduce_device = 'cpu'
+        if backend is not None:
+            import torch.distributed as dist
+
+            if backend == 'nccl':
+                dist.init_process_group('nccl', device_id=device)
+                self.reduce_device = device
+            else:
+                dist.init_process_group(backend)
+            self.dist = dist
+            self.world = dist.get_world_size()
+
+    def barrier(self) -> None:
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def reduce_max(self, values):
+        t = self.torch.tensor(values, dtype=self.torch.float64, device=self.reduce_device)
+        if self.dist is not None:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return t.cpu().tolist()
+
+    def gather(self, values):
+        t = self.torch.tensor(values, dtype=self.torch.float64, device=self.reduce_device)
+        if self.dist is None:
+            return [t.tolist()]
+        out = [self.torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return [o.cpu().tolist() for o in out]
+
+    def teardown(self) -> None:
+        if self.dist is not None:
+            try:
+                self.dist.barrier()
+            finally:
+                self.dist.destroy_process_group()
+
+
+def reduce_timings(comm: RankComm, walls, events, K: int) -> dict:
+    """What rank 0 reports from every rank's per-block times: per block the SLOWEST rank (max over ranks), then the median
+    block; plus every rank's own medians."""
+    walls_max = comm.reduce_max(walls)
+    events_max = comm.reduce_max(events)
+    per_rank = comm.gather([statistics.median(events) / K * 1e6, statistics.median(walls) / K * 1e6])
+    return {'walls_max': walls_max, 'events_max': events_max, 'per_rank': per_rank, 'wall': statistics.median(walls_max),
+            'launch_s': statistics.median(events_max) / K}
+
+
+def assemble_result(args, world: int, n: int, timings: dict, blocks: int, enqueue_us: float, roofline: dict, *, rehearsal: bool = False,
+                    other=None, cpu=None) -> dict:
+    """The one JSON object rank 0 prints (the driver's contract): `value` = boards x K x ranks / the median block's wall time
+    (per block: the slowest rank)."""
+    K, W = args.steps, args.warmup
+    wall, launch_s, walls_max, events_max = timings['wall'], timings['launch_s'], timings['walls_max'], timings['events_max']
+    out = {
+        'metric': 'env_board_steps_per_sec',
+        'value': float(n) * K * world / wall,
+        'unit': 'board-steps/s',
+        'n_gpus': world,
+        'steps': K,
+        'warmup': W,
+        'ms_per_step': wall * 1e3 / K,
+        'higher_is_better': True,
+        'scaling': 'weak',
+        'vs_baseline': None,
+        'dtype': 'u8',
+        'data': 'synthetic',
+        'config': {
+            'workload': workload_text(n),
+            'boards_per_gpu': n,
+            'global_boards': n * world,
+            'launch_mode': 'env2048_step_sequence: the K steps enqueued from C by one call (two half-batch chains of K launches each when the '
+                           'library plans it so: roofline.launch_plan)',
+            'sharding': 'contiguous env-index slices, one process per GPU, no collective on the hot path',
+            'outputs': 'board,reward,done' + (f',legal,obs({args.obs_dtype})' if args.extras else ''),
+        },
+        'timing': {
+            'blocks': blocks,
+            'block_steps': K,
+            'wall_us_per_step': {'median': wall / K * 1e6, 'min': min(walls_max) / K * 1e6, 'max': max(walls_max) / K * 1e6},
+            'event_us_per_step': {'median': launch_s * 1e6, 'min': min(events_max) / K * 1e6, 'max': max(events_max) / K * 1e6},
+            'per_rank_us_per_step': [{'rank': r, 'event': v[0], 'wall': v[1]} for r, v in enumerate(timings['per_rank'])],
+            'host_enqueue_us_per_launch': enqueue_us,  # rank 0; meaningful while the launch queue has room (small K)
+            'note': 'value = boards x K x ranks / median over blocks of (max over ranks of the block wall time); wall-clock blocks '
+                    'and HIP-event blocks alternate (an event-timed block is not wall-timed: recording events is itself host work)',
+        },
+        'roofline': roofline,
+    }
+    if rehearsal:
+        out['config']['rehearsal'] = (f'{world} gloo ranks SHARING one GPU: exercises the multi-rank code path only; '
+                                      f'not a scaling measurement')
+    if other is not None:
+        out['other_configs'] = other
+    if cpu is not None:
+        out['cpu_baseline'] = cpu
+    elif world > 1:
+        out['cpu_baseline'] = None
+        out['cpu_baseline_note'] = 'timed on rank 0 of the N = 1 run only (the contract); run bench.py --gpus 1 for it'
+    else:
+        out['cpu_baseline'] = None
+        out['cpu_baseline_note'] = 'skipped by --no-cpu-baseline'
+    return out
+
+
 def run_rank(args) -> None:
     # Only the JSON line may reach stdout: libraries print there too (RCCL's version banner on its first collective,
     # gloo's connection notes), so file descriptor 1 is pointed at stderr for the whole run and the result line is
@@ -403,42 +523,10 @@ def run_rank(args) -> None:
                  f'use --dist-backend gloo to REHEARSE the multi-rank logic on fewer GPUs')
     torch.cuda.set_device(device_index)
     device = torch.device('cuda', device_index)
-    dist = None
     # ENV2048_BENCH_FORCE_DIST=1: initialise the process group even for one rank (started with RANK=0 WORLD_SIZE=1
     # MASTER_ADDR/PORT set) -- a one-GPU rehearsal of the RCCL barrier / all_reduce / all_gather calls of the N > 1 path
-    if world > 1 or os.environ.get('ENV2048_BENCH_FORCE_DIST') == '1':
-        import torch.distributed as dist
-
-        if args.dist_backend == 'nccl':
-            dist.init_process_group('nccl', device_id=device)
-        else:
-            dist.init_process_group(args.dist_backend)
-    reduce_device = device if (dist is not None and args.dist_backend == 'nccl') else 'cpu'
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-
-    def reduce_max(values):
-        t = torch.tensor(values, dtype=torch.float64, device=reduce_device)
-        if dist is not None:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return t.cpu().tolist()
-
-    def gather(values):
-        t = torch.tensor(values, dtype=torch.float64, device=reduce_device)
-        if dist is None:
-            return [t.tolist()]
-        out = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(out, t)
-        return [o.cpu().tolist() for o in out]
-
-    def teardown():
-        if dist is not None:
-            try:
-                dist.barrier()
-            finally:
-                dist.destroy_process_group()
+    comm = RankComm(args.dist_backend if (world > 1 or os.environ.get('ENV2048_BENCH_FORCE_DIST') == '1') else None, device)
+    barrier, teardown = comm.barrier, comm.teardown
 
     def body():
         n = args.boards
@@ -524,18 +612,15 @@ def run_rank(args) -> None:
         run_steps(W)
         torch.cuda.synchronize()
         # how many blocks: cover --min-ms of GPU time (the same count on every rank: calibrate on the max over ranks)
-        calib = reduce_max([timed_block(K)[1]])[0]
+        calib = comm.reduce_max([timed_block(K)[1]])[0]
         blocks = int(min(args.max_blocks, max(3, math.ceil(args.min_ms * 1e-3 / max(calib, 1e-7)))))
         walls, events = [], []
         for _ in range(blocks):
             walls.append(timed_block(K, with_events=False)[0])
             events.append(timed_block(K, with_events=True)[1])
         barrier()
-        walls_max = reduce_max(walls)      # per block: the slowest rank
-        events_max = reduce_max(events)
-        per_rank = gather([statistics.median(events) / K * 1e6, statistics.median(walls) / K * 1e6])
-        wall = statistics.median(walls_max)
-        launch_s = statistics.median(events_max) / K
+        timings = reduce_timings(comm, walls, events, K)
+        launch_s = timings['launch_s']
 
         # ---- HBM-cold leg: same launch size, round-robin over disjoint buffer sets that exceed the Infinity Cache -------
         cold = None
@@ -548,59 +633,12 @@ def run_rank(args) -> None:
             other = other_configs(torch, lib, device, device_index, h)
 
         if rank == 0:
-            total_steps = float(n) * K * world
-            value = total_steps / wall
             roofline = build_roofline(args, lib, n, flags, launch_s, obs_bytes)
             if cold is not None:
                 roofline['hbm_cold'] = cold
-            out = {
-                'metric': 'env_board_steps_per_sec',
-                'value': value,
-                'unit': 'board-steps/s',
-                'n_gpus': world,
-                'steps': K,
-                'warmup': W,
-                'ms_per_step': wall * 1e3 / K,
-                'higher_is_better': True,
-                'scaling': 'weak',
-                'vs_baseline': None,
-                'dtype': 'u8',
-                'data': 'synthetic',
-                'config': {
-                    'workload': workload_text(n),
-                    'boards_per_gpu': n,
-                    'global_boards': n * world,
-                    'launch_mode': 'env2048_step_sequence: the K steps enqueued from C by one call (two half-batch chains of K launches each when the '
-                               'library plans it so: roofline.launch_plan)',
-                    'sharding': 'contiguous env-index slices, one process per GPU, no collective on the hot path',
-                    'outputs': 'board,reward,done' + (f',legal,obs({args.obs_dtype})' if args.extras else ''),
-                },
-                'timing': {
-                    'blocks': blocks,
-                    'block_steps': K,
-                    'wall_us_per_step': {'median': wall / K * 1e6, 'min': min(walls_max) / K * 1e6, 'max': max(walls_max) / K * 1e6},
-                    'event_us_per_step': {'median': launch_s * 1e6, 'min': min(events_max) / K * 1e6, 'max': max(events_max) / K * 1e6},
-                    'per_rank_us_per_step': [{'rank': r, 'event': v[0], 'wall': v[1]} for r, v in enumerate(per_rank)],
-                    'host_enqueue_us_per_launch': statistics.median(enqueue_times) * 1e6,  # rank 0; meaningful while the launch queue has room (small K)
-                    'note': 'value = boards x K x ranks / median over blocks of (max over ranks of the block wall time); wall-clock blocks '
-                        'and HIP-event blocks alternate (an event-timed block is not wall-timed: recording events is itself host work)',
-                },
-                'roofline': roofline,
-            }
-            if rehearsal:
-                out['config']['rehearsal'] = (f'{world} gloo ranks SHARING one GPU: exercises the multi-rank code path only; '
-                                              f'not a scaling measurement')
-            if other is not None:
-                out['other_configs'] = other
-            if boards_midgame is not None:
-                out['cpu_baseline'] = cpu_baseline(boards_midgame, args.cpu_seconds)
-            elif world > 1:
-                out['cpu_baseline'] = None
-                out['cpu_baseline_note'] = 'timed on rank 0 of the N = 1 run only (the contract); run bench.py --gpus 1 for it'
-            elif args.no_cpu_baseline:
-                out['cpu_baseline'] = None
-                out['cpu_baseline_note'] = 'skipped by --no-cpu-baseline'
-            emit(json.dumps(out))
+            cpu = cpu_baseline(boards_midgame, args.cpu_seconds) if boards_midgame is not None else None
+            emit(json.dumps(assemble_result(args, world, n, timings, blocks, statistics.median(enqueue_times) * 1e6, roofline,
+                                            rehearsal=rehearsal, other=other, cpu=cpu)))
 
     try:
         body()
@@ -890,6 +928,127 @@ def other_configs(torch, lib, device, device_index, h) -> dict:
         'statistics': {'mean_episode_length': n4 * T / max(eps_roll, 1), 'invalid_move_fraction': 1.0 - valid_roll / (n4 * T),
                        'zero_reward_nonterminal_fraction': invalid},
     }
+    del a, b
+    out['configs[2]_long_sequence'] = long_sequence_leg(torch, lib, device, device_index, h)
+    out['configs[2]_with_legal_obs'] = legal_obs_leg(torch, lib, device, device_index, h)
+    return out
+
+
+def _timed_sequence(torch, lib, stream, device_index, h, env, table, K, flags, step0, legal=None, obs=None, reps=5):
+    """Median (wall s, event s) of one env2048_step_sequence call of K steps on `env` (after one untimed call of the same shape)."""
+    times = []
+    for rep in range(reps + 1):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        lib.step_sequence(device_index, h, env.num_envs, env.env_base, env.boards.data_ptr(), table, env.reward.data_ptr(), env.done.data_ptr(),
+                          legal, obs, 0, SEED, step0 + rep * K, K, flags)
+        ev1.record(stream)
+        torch.cuda.synchronize()
+        if rep:
+            times.append((time.perf_counter() - t0, ev0.elapsed_time(ev1) * 1e-3))
+    return sorted(times)[len(times) // 2]
+
+
+def _midgame_env(torch, device, n, **kw):
+    from simulate_2048_amd.batch import BatchedEnv2048
+
+    env = BatchedEnv2048(n, SEED, device=device, auto_reset=True, **kw)
+    env.reset()
+    for _ in range(64):
+        env.step(None)
+    gen = torch.Generator(device='cpu').manual_seed(1)
+    pool = [torch.randint(0, 4, (n,), generator=gen, dtype=torch.uint8).to(device) for _ in range(8)]
+    return env, pool
+
+
+def long_sequence_leg(torch, lib, device, device_index, h, n: int = 1 << 20, K: int = 200) -> dict:
+    """The headline workload (BASELINE configs[2]) as ONE env2048_step_sequence call of K = 200 steps -- long enough for the
+    library to run the batch as two half-batch chains (from K = 32), which the driver's --steps 20 headline never does -- next
+    to the same call with ENV2048_FLAG_SINGLE_CHAIN, and what the library's helper thread cost over a K = 2000 call."""
+    from simulate_2048_amd import capi
+
+    env, pool = _midgame_env(torch, device, n)
+    stream = torch.cuda.current_stream(device)
+    table = (ctypes.c_void_p * K)(*[pool[t & 7].data_ptr() for t in range(K)])
+    out = {'workload': workload_text(n) + f'; one env2048_step_sequence call of K = {K} steps', 'K': K}
+    for name, extra in (('two_chains_default', 0), ('single_chain', capi.FLAG_SINGLE_CHAIN)):
+        flags = env.flags | extra
+        wall, ev = _timed_sequence(torch, lib, stream, device_index, h, env, table, K, flags, 1000 + 7 * K * (1 if extra else 0))
+        gbs = ALGO_BYTES_PER_STEP * n / (ev / K) / 1e9
+        out[name] = {'launch_plan': lib.step_sequence_plan(n, K, flags), 'event_us_per_step': ev / K * 1e6, 'wall_us_per_step': wall / K * 1e6,
+                     'value': n * K / wall, 'unit': 'board-steps/s',
+                     'roofline': {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
+                                  'regime': 'cache-resident equivalent (algorithmic bytes / event time per step; see roofline.regime)'}}
+    out['two_chains_speedup'] = out['single_chain']['event_us_per_step'] / out['two_chains_default']['event_us_per_step']
+    # the helper thread that enqueues the second chain: CPU time it consumed over a K = 2000 call (its poll window included)
+    K2 = 2000
+    table2 = (ctypes.c_void_p * K2)(*[pool[t & 7].data_ptr() for t in range(K2)])
+    before = lib.helper_stats(device_index)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    lib.step_sequence(device_index, h, n, env.env_base, env.boards.data_ptr(), table2, env.reward.data_ptr(), env.done.data_ptr(), None, None, 0,
+                      SEED, 50_000, K2, env.flags)
+    enqueued = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    wall2 = time.perf_counter() - t0
+    time.sleep(0.002)  # let the helper's poll window (default 300 us) run out so that its cost is in the sample
+    after = lib.helper_stats(device_index)
+    out['helper_thread'] = {
+        'K': K2, 'wall_ms': wall2 * 1e3, 'caller_enqueue_ms': enqueued * 1e3, 'us_per_step_wall': wall2 / K2 * 1e6,
+        'helper_cpu_ms': (after['cpu_ns'] - before['cpu_ns']) * 1e-6, 'helper_jobs': after['jobs'] - before['jobs'], 'spin_us': after['spin_us'],
+        'note': 'CPU time of the library\'s helper thread (CLOCK_THREAD_CPUTIME_ID, env2048_helper_stats) over one two-chain call of K steps: it '
+                'enqueues the second chain (K launches) and then polls for ENV2048_HELPER_SPIN_US before sleeping; one hardware thread per '
+                'device while a stepping loop is running, nothing while idle (include/env2048.h, "The helper thread")'}
+    return out
+
+
+def legal_obs_leg(torch, lib, device, device_index, h, n: int = 1 << 20, K: int = 200) -> dict:
+    """What the reference's caller needs EVERY move (reinforce/training/self_play.py:316-317,354): transition + legal mask +
+    observation of the new boards, from the EXTRAS variant of the step kernel in the same launch -- with float32 and with
+    bfloat16 observations (the same values: e/16 is exact in both)."""
+    out = {'workload': workload_text(n) + f'; legal mask + observation written by the same launch; one env2048_step_sequence call of K = {K} steps',
+           'K': K, 'replaces': 'batched_step + batched_get_observation + batched_get_legal_actions, reinforce/game/env.py:193-245'}
+    stream = torch.cuda.current_stream(device)
+    for name, dtype, obs_bytes in (('obs_f32', torch.float32, 4), ('obs_bf16', torch.bfloat16, 2)):
+        env, pool = _midgame_env(torch, device, n, with_legal=True, with_obs=True, obs_dtype=dtype)
+        table = (ctypes.c_void_p * K)(*[pool[t & 7].data_ptr() for t in range(K)])
+        wall, ev = _timed_sequence(torch, lib, stream, device_index, h, env, table, K, env.flags, 1000, legal=env.legal.data_ptr(),
+                                   obs=env.obs.data_ptr())
+        per_board = ALGO_BYTES_PER_STEP + 1 + 16 * obs_bytes
+        gbs = per_board * n / (ev / K) / 1e9
+        plan = lib.step_sequence_plan(n, K, env.flags)
+        out[name] = {'launch_plan': plan, 'event_us_per_step': ev / K * 1e6, 'wall_us_per_step': wall / K * 1e6, 'value': n * K / wall,
+                     'unit': 'board-steps/s',
+                     'roofline': {'bound': 'hbm', 'kernel': f'step_kernel<true, false, {plan["boards_per_lane"]}>',
+                                  'algorithmic_bytes_per_board_step': per_board, 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                  'frac': gbs / HBM_PEAK_GBS,
+                                  'regime': f'cache-resident equivalent: {n * (16 + 8 + 4 + 1 + 1 + 16 * obs_bytes) / 2**20:.0f} MiB working set < 256 MiB '
+                                            f'Infinity Cache (algorithmic bytes / event time per step)'}}
+        del env, pool
+    return out
+
+
+def assemble_single_process_result(args, walls, per_device_ms, roofline: dict) -> dict:
+    """The JSON object of a --single-process run: same contract, value = boards x K x devices / the median block's wall time."""
+    G, n, K, W = args.gpus, args.boards, args.steps, args.warmup
+    wall = statistics.median(walls)
+    out = {
+        'metric': 'env_board_steps_per_sec', 'value': float(n) * G * K / wall, 'unit': 'board-steps/s', 'n_gpus': G, 'steps': K, 'warmup': W,
+        'ms_per_step': wall * 1e3 / K, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u8', 'data': 'synthetic',
+        'config': {'workload': workload_text(n), 'boards_per_gpu': n, 'global_boards': n * G,
+                   'launch_mode': 'single process: ShardedEnv2048, one worker thread + one stream per device, each enqueuing its K launches '
+                                  'through one env2048_step_sequence call',
+                   'sharding': 'contiguous env-index slices, no collective, no torch.distributed', 'outputs': 'board,reward,done'},
+        'timing': {'blocks': len(walls), 'block_steps': K,
+                   'wall_us_per_step': {'median': wall / K * 1e6, 'min': min(walls) / K * 1e6, 'max': max(walls) / K * 1e6},
+                   'per_device_event_us_per_step': [m * 1e3 / K for m in per_device_ms]},
+        'roofline': roofline,
+        'cpu_baseline': None, 'cpu_baseline_note': 'timed by the default (rank-per-GPU, N = 1) run only',
+    }
+    if args.shards_on_device_0:
+        out['config']['rehearsal'] = f'{G} shards SHARING device 0: exercises the single-process fan-out only; not a scaling measurement'
     return out
 
 
@@ -945,23 +1104,8 @@ def run_single_process(args) -> None:
         g if not rehearsal else 0, torch.cuda.current_stream(devices[g]).cuda_stream, env.shards[g].num_envs, env.shards[g].env_base,
         env.shards[g].boards.data_ptr(), tables_for(K, 0)[g], env.shards[g].reward.data_ptr(), env.shards[g].done.data_ptr(), None, None, 0,
         SEED, 10_000_000, K, env.shards[g].flags))
-    wall = statistics.median(walls)
     launch_s = statistics.median(per_device_ms) * 1e-3 / K
-    out = {
-        'metric': 'env_board_steps_per_sec', 'value': float(n) * G * K / wall, 'unit': 'board-steps/s', 'n_gpus': G, 'steps': K, 'warmup': W,
-        'ms_per_step': wall * 1e3 / K, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u8', 'data': 'synthetic',
-        'config': {'workload': workload_text(n), 'boards_per_gpu': n, 'global_boards': n * G,
-                   'launch_mode': 'single process: ShardedEnv2048, one worker thread + one stream per device, each enqueuing its K launches '
-                                  'through one env2048_step_sequence call',
-                   'sharding': 'contiguous env-index slices, no collective, no torch.distributed', 'outputs': 'board,reward,done'},
-        'timing': {'blocks': blocks, 'block_steps': K,
-                   'wall_us_per_step': {'median': wall / K * 1e6, 'min': min(walls) / K * 1e6, 'max': max(walls) / K * 1e6},
-                   'per_device_event_us_per_step': [m * 1e3 / K for m in per_device_ms]},
-        'roofline': build_roofline(args, lib, n, env.shards[0].flags, launch_s, 4),
-        'cpu_baseline': None, 'cpu_baseline_note': 'timed by the default (rank-per-GPU, N = 1) run only',
-    }
-    if rehearsal:
-        out['config']['rehearsal'] = f'{G} shards SHARING device 0: exercises the single-process fan-out only; not a scaling measurement'
+    out = assemble_single_process_result(args, walls, per_device_ms, build_roofline(args, lib, n, env.shards[0].flags, launch_s, 4))
     env.close()
     os.write(result_fd, (json.dumps(out) + '\n').encode())
 

@@ -288,7 +288,8 @@ class BatchedEnv2048:
         ``mode``: 'replay' = one env2048_replay launch (no per-step launch: the small-batch answer), 'launches' = K step
         launches enqueued by one env2048_step_sequence call, 'auto' = replay up to ``REPLAY_MAX_ENVS`` environments when only
         reward / done rows are wanted (the env was built without legal / obs outputs), launches otherwise.
-        Returns ``(boards, reward_rows, done_rows)``."""
+        Returns ``(boards, reward_rows, done_rows)``; afterwards ``env.reward`` / ``env.done`` (and ``env.legal`` / ``env.obs``)
+        hold the values of the LAST of the K moves, as after ``step``."""
         if actions.dtype != torch.uint8 or actions.dim() != 2 or actions.shape[1] != self.num_envs or not actions.is_contiguous() \
                 or actions.device != self.boards.device:
             raise ValueError(f'actions must be a contiguous uint8 (K, {self.num_envs}) tensor on {self.boards.device}')
@@ -318,6 +319,9 @@ class BatchedEnv2048:
                                    self.seed, self._step_index, K, self.flags)
             if self.legal is not None or self.obs is not None:  # the persistent legal / obs describe the LAST boards
                 self.describe(self.legal, self.obs)
+        # the persistent reward / done describe the LAST move, as after step() (they were left stale)
+        self.reward.copy_(reward[K - 1])
+        self.done.copy_(done[K - 1])
         self._step_index += K
         return self.boards, reward, done
 

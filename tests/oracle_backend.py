@@ -29,6 +29,7 @@ class OracleLibrary:
 
     def __init__(self):
         self.calls = []  # (name, n) log, handy for asserting launch counts in host-logic tests
+        self.launches = []  # (name, device, stream, env_base, n) of the batch entry points: which device / stream a slice went to
 
     def abi_version(self):
         return 2
@@ -41,6 +42,7 @@ class OracleLibrary:
 
     def reset(self, device, stream, n, env_base, boards, done, seed, step_index):
         self.calls.append(('reset', n))
+        self.launches.append(('reset', device, stream, env_base, n))
         b, _ = oracle.reset_batch(n, seed, step_index, env_base=env_base)
         _view(boards, n * 16, np.uint8)[:] = b.reshape(-1)
         if done is not None:
@@ -48,6 +50,7 @@ class OracleLibrary:
 
     def step(self, device, stream, n, env_base, boards, actions, reward, done, legal, obs, seed, step_index, flags, max_exp=None):
         self.calls.append(('step', n))
+        self.launches.append(('step', device, stream, env_base, n))
         b = _view(boards, n * 16, np.uint8)
         a = None if actions is None else _view(actions, n, np.uint8).copy()
         res = oracle.step_batch_ex(b.reshape(n, 16), a, seed, step_index, env_base=env_base, flags=flags & 3)
@@ -180,6 +183,7 @@ class OracleLibrary:
 
     def rollout(self, device, stream, n, env_base, boards, seed, step0, T, return_sum, episodes, valid_moves, flags):
         self.calls.append(('rollout', n))
+        self.launches.append(('rollout', device, stream, env_base, n))
         b = _view(boards, n * 16, np.uint8)
         res = oracle.rollout_batch(b.reshape(n, 16), seed, step0, T, env_base=env_base, flags=flags)
         b[:] = res['boards'].reshape(-1)

@@ -96,7 +96,7 @@ def test_profile_table_is_keyed_by_kernel_source():
         assert set(table) >= {'kernel_source_sha', 'entries'}
         for key, entry in table['entries'].items():
             leg, boards = key.split(':')
-            assert leg in ('resident', 'cold', 'cold_separate') and int(boards) > 0
+            assert leg in ('resident', 'resident_one_chain', 'cold', 'cold_separate') and int(boards) > 0
             assert entry['fabric_bytes_per_launch'] > 0 and (REPO / entry['source']).exists()
         prof = bench.load_step_profile(1 << 20, 'resident')
         assert prof is None or prof['stale'] == (table['kernel_source_sha'] != sha)
@@ -140,3 +140,96 @@ def test_step_sequence_and_step_many_host_logic():
     np.testing.assert_array_equal(b2, oracle.step_batch(start[:100], None, seed, 5, env_base=8, flags=3)['boards'])
     assert ctypes.sizeof(capi.StepArgs) == 104  # the C struct of include/env2048.h: 2 u64 + 6 pointers + 2 u64 + 2 u32 + 2 pointers
     assert ctypes.sizeof(capi.Episode) == 24
+
+
+# ---- multi-GPU readiness without the hardware ------------------------------------------------------------
+def _validate_contract_line(out: dict, n_gpus: int) -> None:
+    """The driver's contract for one bench line (what SCALE_rNN.json is computed from) at N = n_gpus."""
+    assert out['metric'] == 'env_board_steps_per_sec' and out['unit'] == 'board-steps/s' and out['higher_is_better'] is True
+    assert out['n_gpus'] == n_gpus and out['scaling'] == 'weak' and out['vs_baseline'] is None and out['dtype'] == 'u8' and out['data'] == 'synthetic'
+    assert out['config']['boards_per_gpu'] == 1 << 20 and out['config']['global_boards'] == n_gpus << 20
+    assert out['config']['workload'].startswith('BASELINE configs[2]') and 'model' not in out['config']
+    assert out['cpu_baseline'] is None and 'N = 1' in out['cpu_baseline_note']
+    assert out['roofline']['bound'] == 'hbm' and out['roofline']['peak'] == 8000.0 and out['roofline']['unit'] == 'GB/s'
+    assert abs(out['roofline']['frac'] - out['roofline']['achieved'] / 8000.0) < 1e-12
+
+
+def test_eight_ranks_reduce_their_timings_and_emit_the_contract_line(tmp_path, capfd):
+    """`python bench.py --gpus 8` without the GPUs: eight gloo ranks started by bench.py's own launcher run the benchmark's
+    own reduction code (RankComm: barrier, max over ranks per block, gather of the per-rank medians) on synthetic block times
+    -- rank r is (1 + r/100) times slower than rank 0 -- and rank 0 assembles the line with bench.assemble_result.
+    value must be the WHOLE-JOB rate at the pace of the slowest rank; global_boards = 8 x 2^20 = BASELINE configs[3]."""
+    cmd = _worker(tmp_path, f'''
+        import json, os, sys
+        sys.path.insert(0, {str(REPO)!r})
+        import bench
+        args = bench.parse_args(["--gpus", "8", "--steps", "20", "--warmup", "5", "--dist-backend", "gloo"])
+        rank = int(os.environ["RANK"])
+        comm = bench.RankComm("gloo")
+        assert comm.world == 8
+        comm.barrier()
+        slow = 1.0 + rank / 100.0
+        walls = [20 * 8.8e-6 * slow * (1.0 + 0.01 * b) for b in range(7)]      # seconds per 20-step block
+        events = [20 * 7.9e-6 * slow * (1.0 + 0.01 * b) for b in range(7)]
+        timings = bench.reduce_timings(comm, walls, events, args.steps)
+        if rank == 0:
+            roofline = dict(bound="hbm", achieved=38 * 2**20 / timings["launch_s"] / 1e9, peak=8000.0, unit="GB/s")
+            roofline["frac"] = roofline["achieved"] / roofline["peak"]
+            print(json.dumps(bench.assemble_result(args, comm.world, args.boards, timings, 7, 3.5, roofline)))
+        comm.teardown()
+    ''')
+    rc = bench.spawn_ranks(8, cmd, timeout=600)
+    captured = capfd.readouterr()
+    assert rc == 0, captured.out + captured.err
+    lines = [l for l in captured.out.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    _validate_contract_line(out, 8)
+    assert out['steps'] == 20 and out['warmup'] == 5
+    per_rank = out['timing']['per_rank_us_per_step']
+    assert [e['rank'] for e in per_rank] == list(range(8))
+    assert all(abs(e['event'] - 7.9 * (1 + r / 100) * 1.03) < 1e-6 for r, e in enumerate(per_rank))  # each rank's own median block
+    slowest_wall = 20 * 8.8e-6 * 1.07 * 1.03  # median block of the slowest rank
+    assert abs(out['ms_per_step'] - slowest_wall * 1e3 / 20) < 1e-9
+    assert abs(out['value'] - 8 * 2**20 * 20 / slowest_wall) / out['value'] < 1e-9
+    assert abs(out['timing']['event_us_per_step']['median'] - 7.9 * 1.07 * 1.03) < 1e-6
+
+
+def test_single_process_line_for_eight_devices():
+    """`bench.py --single-process --gpus 8`: the same contract from ONE process (ShardedEnv2048; its fan-out over 8 devices is
+    covered by tests/test_sharded.py) -- the line assembled from synthetic per-device times."""
+    args = bench.parse_args(['--single-process', '--gpus', '8', '--steps', '20', '--warmup', '5'])
+    walls = [20 * 9.0e-6 * (1 + 0.02 * b) for b in range(9)]
+    roofline = dict(bound='hbm', achieved=5000.0, peak=8000.0, unit='GB/s', frac=5000.0 / 8000.0)
+    out = bench.assemble_single_process_result(args, walls, [0.16 + 0.001 * g for g in range(8)], roofline)
+    _validate_contract_line(out, 8)
+    assert len(out['timing']['per_device_event_us_per_step']) == 8 and out['timing']['blocks'] == 9
+    median_wall = sorted(walls)[4]
+    assert abs(out['value'] - 8 * 2**20 * 20 / median_wall) / out['value'] < 1e-12
+    assert 'rehearsal' not in out['config']
+    args.shards_on_device_0 = True
+    assert 'not a scaling measurement' in bench.assemble_single_process_result(args, walls, [0.16] * 8, roofline)['config']['rehearsal']
+
+
+def test_roofline_object_is_the_hbm_fraction_with_the_valu_analysis_beside_it():
+    """SURVEY 8(d): top-level roofline = algorithmic bytes / launch time against 8 TB/s (labelled cache-resident at 2^20
+    boards); the instruction-issue analysis sits under roofline.valu; counters come from the profile of the TIMED shape
+    (one chain for the driver's --steps 20, two chains from K = 32)."""
+
+    class Lib:
+        def step_sequence_plan(self, n, count, flags):
+            return capi.Library().step_sequence_plan(n, count, flags)
+
+    for steps, leg, chains in ((20, 'resident_one_chain', 1), (200, 'resident', 2)):
+        args = bench.parse_args(['--steps', str(steps)])
+        r = bench.build_roofline(args, Lib(), 1 << 20, capi.FLAG_AUTO_RESET, 8.0e-6, 4)
+        assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0
+        assert abs(r['achieved'] - 38 * 2**20 / 8.0e-6 / 1e9) < 1e-6 and abs(r['frac'] - r['achieved'] / 8000.0) < 1e-12
+        assert 'cache-resident' in r['regime'] and r['launch_plan']['chains'] == chains and r['launches_per_step'] == chains
+        assert r['algorithmic_bytes_per_launch'] == 38 << 20
+        if r['traffic_source'] is not None:  # a committed counter table: it must be the table of the timed shape
+            assert r['traffic_source']['leg'] == leg and 0.9 < r['traffic'] / r['algorithmic_bytes_per_launch'] < 1.3
+        if 'valu' in r:
+            assert r['valu']['unit'] == 'G wave-instr/s' and 0 < r['valu']['frac'] < 1
+    big = bench.build_roofline(bench.parse_args(['--boards', str(1 << 24)]), Lib(), 1 << 24, capi.FLAG_AUTO_RESET, 1.0e-4, 4)
+    assert big['regime'].startswith('HBM') and 'valu' not in big

@@ -5,6 +5,8 @@ stand-in with three "devices" (host logic, CPU) and on the GPU with two shards o
 Partitioning rule restated from SURVEY 8(e): slice g = global indices [g * ceil(N / G), ...), Philox counters carry the GLOBAL index.
 """
 
+import threading
+
 import numpy as np
 import pytest
 import torch
@@ -80,3 +82,55 @@ def test_worker_errors_reach_the_caller(backend):
         sharded.close()
     with pytest.raises(ValueError):
         ShardedEnv2048(64, 1, devices=backend['devices'], lib=backend['lib'], device_step_counter=True)
+
+
+def test_eight_shards_each_on_its_own_device_and_stream(monkeypatch):
+    """G = 8 (fake) devices and an odd total -- every C-ABI call that touches shard g's slice is made with
+    device ordinal g and shard g's stream, never another's.  There is no 8-GPU box here, so the devices are faked where the
+    product reads them: ``batch._stream_handle`` (device ordinal + current stream of the CALLING thread) answers for the worker
+    thread it is called on, which is exactly what makes the real thing correct -- worker g has device g and its stream current,
+    and shard g's methods run only there.  The oracle-backed stand-in records (device, stream, env_base, n) of every call."""
+    from simulate_2048_amd import batch
+    from simulate_2048_amd import sharded as sharded_module
+
+    G, n, seed, base = 8, 100_003, 21, 5
+    lib = OracleLibrary()
+
+    def fake_handle(device):
+        name = threading.current_thread().name
+        assert name.startswith('env2048-shard-'), f'a C-ABI call for a shard was made from thread {name!r}, not from a shard worker'
+        g = int(name.rsplit('-', 1)[1])
+        return g, 0xA000 + g
+
+    monkeypatch.setattr(batch, '_stream_handle', fake_handle)
+    monkeypatch.setattr(sharded_module, '_stream_handle', fake_handle)  # (imported by name there)
+    sharded = ShardedEnv2048(n, seed, devices=['cpu'] * G, env_base=base, auto_reset=True, lib=lib)
+    try:
+        assert sharded.num_shards == G and sum(c for _, c in sharded.ranges) == n
+        assert all(lo % 4 == 0 for lo, _ in sharded.ranges) and sharded.ranges[-1][1] < sharded.ranges[0][1]  # Philox-block aligned, short tail
+        sharded.reset()
+        sharded.step(None)
+        rng = np.random.default_rng(1)
+        acts = torch.from_numpy(rng.integers(0, 4, size=n).astype(np.uint8))
+        sharded.step(sharded.split(acts))
+        sharded.step_sequence(3)
+        sharded.rollout(5)
+        whole = BatchedEnv2048(n, seed, device='cpu', env_base=base, auto_reset=True, lib=OracleLibrary())
+        monkeypatch.setattr(batch, '_stream_handle', lambda device: (-1, None))
+        whole.reset()
+        whole.step(None)
+        whole.step(acts)
+        for _ in range(3):
+            whole.step(None)
+        whole.rollout(5)
+        assert torch.equal(sharded.gather('boards'), whole.boards)  # and the 8 slices are the unsharded batch, byte for byte
+    finally:
+        sharded.close()
+    by_shard = {base + lo: (g, c) for g, (lo, c) in enumerate(sharded.ranges)}
+    seen = set()
+    assert len(lib.launches) >= G * 7
+    for name, device, stream, env_base, count in lib.launches:
+        g, c = by_shard[env_base]  # every call starts at a shard boundary ...
+        assert count == c and device == g and stream == 0xA000 + g, (name, device, stream, env_base, count)  # ... and is that shard's own
+        seen.add((name, g))
+    assert {g for _, g in seen} == set(range(G)) and {name for name, _ in seen} >= {'reset', 'step', 'rollout'}

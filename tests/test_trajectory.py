@@ -433,6 +433,8 @@ def test_step_many_staged_moves_equal_single_steps(make_env, n):
         rows[mode] = (r, d)
         assert envs[mode].step_index == envs['steps'].step_index
         assert torch.equal(envs[mode].boards, envs['steps'].boards) and torch.equal(r, ref_r) and torch.equal(d, ref_d)
+        # the persistent reward / done describe the last move, as after step()
+        assert torch.equal(envs[mode].reward, ref_r[K - 1]) and torch.equal(envs[mode].done, ref_d[K - 1])
         if calls is not None:  # host logic: which entry point was used
             names = [c[0] for c in calls[mark:]]
             assert names == (['replay'] if mode in ('auto', 'replay') else ['step_sequence'] if 'step_sequence' in names else names)

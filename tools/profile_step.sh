@@ -16,7 +16,7 @@ COLD="python3 $R/bench.py --no-cpu-baseline --only-cold"
 # kernel stats over the SAME step counts as the default bench run, so that the averages are comparable
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_resident -- $RES > $O/stats_resident.json 2> $O/stats_resident.err
 echo "stats resident rc=$?"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_resident_one -- $RES --single-chain > $O/stats_resident_one.json 2> $O/stats_resident_one.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_onechain -- $RES --single-chain > $O/stats_onechain.json 2> $O/stats_onechain.err
 echo "stats resident (one chain) rc=$?"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cold -- $COLD > $O/stats_cold.json 2> $O/stats_cold.err
 echo "stats cold rc=$?"
@@ -24,6 +24,12 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_I
   name=$(echo $set | tr " " "_" | cut -c1-32)
   rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc_resident_$name -- $RES --steps 300 --warmup 100 --max-blocks 3 > $O/pmc_resident_$name.json 2> $O/pmc_resident_$name.err || echo "PMC pass failed: resident $set"
   echo "pmc resident $name done"
+done
+# the one-chain shape (whole-batch launches): what the driver's --steps 20 run times (K < 32 never splits)
+for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU" "TCC_HIT_sum TCC_MISS_sum"; do
+  name=$(echo $set | tr " " "_" | cut -c1-32)
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc_onechain_$name -- $RES --single-chain --steps 300 --warmup 100 --max-blocks 3 > $O/pmc_onechain_$name.json 2> $O/pmc_onechain_$name.err || echo "PMC pass failed: one chain $set"
+  echo "pmc onechain $name done"
 done
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_VALU"; do
   name=$(echo $set | tr " " "_" | cut -c1-32)
