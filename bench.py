@@ -934,20 +934,22 @@ def other_configs(torch, lib, device, device_index, h) -> dict:
     return out
 
 
-def _timed_sequence(torch, lib, stream, device_index, h, env, table, K, flags, step0, legal=None, obs=None, reps=5):
-    """Median (wall s, event s) of one env2048_step_sequence call of K steps on `env` (after one untimed call of the same shape)."""
+def _timed_sequence(torch, lib, stream, device_index, h, env, table, K, flags, step0, legal=None, obs=None, reps=5, calls=1):
+    """Median (wall s, event s) PER CALL of `calls` consecutive env2048_step_sequence calls of K steps on `env`, timed as one region
+    (after one untimed region of the same shape)."""
     times = []
     for rep in range(reps + 1):
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         ev0.record(stream)
-        lib.step_sequence(device_index, h, env.num_envs, env.env_base, env.boards.data_ptr(), table, env.reward.data_ptr(), env.done.data_ptr(),
-                          legal, obs, 0, SEED, step0 + rep * K, K, flags)
+        for c in range(calls):
+            lib.step_sequence(device_index, h, env.num_envs, env.env_base, env.boards.data_ptr(), table, env.reward.data_ptr(),
+                              env.done.data_ptr(), legal, obs, 0, SEED, step0 + (rep * calls + c) * K, K, flags)
         ev1.record(stream)
         torch.cuda.synchronize()
         if rep:
-            times.append((time.perf_counter() - t0, ev0.elapsed_time(ev1) * 1e-3))
+            times.append(((time.perf_counter() - t0) / calls, ev0.elapsed_time(ev1) * 1e-3 / calls))
     return sorted(times)[len(times) // 2]
 
 
@@ -975,10 +977,14 @@ def long_sequence_leg(torch, lib, device, device_index, h, n: int = 1 << 20, K: 
     out = {'workload': workload_text(n) + f'; one env2048_step_sequence call of K = {K} steps', 'K': K}
     for name, extra in (('two_chains_default', 0), ('single_chain', capi.FLAG_SINGLE_CHAIN)):
         flags = env.flags | extra
-        wall, ev = _timed_sequence(torch, lib, stream, device_index, h, env, table, K, flags, 1000 + 7 * K * (1 if extra else 0))
+        wall1, ev1 = _timed_sequence(torch, lib, stream, device_index, h, env, table, K, flags, 1000 + 100 * K * (1 if extra else 0))
+        wall, ev = _timed_sequence(torch, lib, stream, device_index, h, env, table, K, flags, 50_000 + 100 * K * (1 if extra else 0), calls=5)
         gbs = ALGO_BYTES_PER_STEP * n / (ev / K) / 1e9
         out[name] = {'launch_plan': lib.step_sequence_plan(n, K, flags), 'event_us_per_step': ev / K * 1e6, 'wall_us_per_step': wall / K * 1e6,
-                     'value': n * K / wall, 'unit': 'board-steps/s',
+                     'value': n * K / wall, 'unit': 'board-steps/s', 'timed_region': f'5 consecutive calls of K = {K} steps between two synchronisations',
+                     'one_call_between_synchronisations': {'event_us_per_step': ev1 / K * 1e6, 'wall_us_per_step': wall1 / K * 1e6,
+                                                           'note': 'a single 1.5 ms call from an idle GPU: fork / join of the second chain '
+                                                                   'and the clock ramp are not amortised'},
                      'roofline': {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
                                   'regime': 'cache-resident equivalent (algorithmic bytes / event time per step; see roofline.regime)'}}
     out['two_chains_speedup'] = out['single_chain']['event_us_per_step'] / out['two_chains_default']['event_us_per_step']

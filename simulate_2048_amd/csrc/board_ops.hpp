@@ -712,4 +712,47 @@ ENV2048_DEV void transition_oriented(Board &pl, const OrientStep &s, uint32_t wo
     pl = q;
 }
 
+// ---- merge scores PER LINE (search kernels) ----------------------------------------------------------------------------------
+// The merge part of slide_merge_planes() without the board it leaves behind: for four independent lines (byte lane j of the
+// planes a..d = line j, plane a nearest the wall) the merged exponents of the at most two merges of every line --
+// v1 = exponent of the merge at the wall end (0 in a lane without one), v2 = exponent of a second merge (cd after ab) -- so that
+// line j scores (1 << v1[j]) + (1 << v2[j]) with an absent merge contributing nothing (`line_score`).  Same compaction and the
+// same greedy pairing from the wall outward [ref: twentyfortyeight/core/gameboard.py:23-69 merge_column].  The expectimax
+// leaf evaluator needs scores line by line: a spawned tile changes ONE row and ONE column of an afterstate, so the best
+// move reward of a successor is (sum over rows) - old row + new row against (sum over columns) - old column + new column.
+ENV2048_DEV void line_merge_terms(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t &v1, uint32_t &v2)
+{
+    const uint32_t na = nzmask(a), nb0 = nzmask(b), nc0 = nzmask(c), nd0 = nzmask(d);
+    const uint32_t one_abc = ENV2048_BITOP3(na, nb0, nc0, 0x16);
+    const uint32_t two_abc = ENV2048_BITOP3(na, nb0, nc0, 0x68);
+    const uint32_t all_abc = ENV2048_BITOP3(na, nb0, nc0, 0x80);
+    const uint32_t maj_abc = ENV2048_BITOP3(na, nb0, nc0, 0xE8);
+    const uint32_t oa = ENV2048_BFI(na, a, ENV2048_BFI(nb0, b, ENV2048_BFI(nc0, c, d)));
+    const uint32_t ob = ENV2048_AND_OR(d, one_abc, ENV2048_BITOP3(b, na, nb0, 0x80)) | ENV2048_BITOP3(c, na, nb0, 0x60);
+    const uint32_t oc = ENV2048_AND_OR(c, all_abc, d & two_abc);
+    const uint32_t od = d & all_abc;
+    const uint32_t nb = ENV2048_AND_OR(one_abc, nd0, maj_abc), nc = ENV2048_AND_OR(two_abc, nd0, all_abc), nd = all_abc & nd0;
+    const uint32_t d_ab = nzmask(oa ^ ob), d_bc = nzmask(ob ^ oc), d_cd = nzmask(oc ^ od);
+    const uint32_t m_ab = ENV2048_BITOP3(d_ab, nb, nb, 0x0C);
+    const uint32_t m_bc = ENV2048_BITOP3(d_bc, nc, m_ab, 0x04);
+    const uint32_t m_cd = ENV2048_BITOP3(d_cd, nd, m_bc, 0x04);
+    // merged exponent = exponent + 1 in the lanes that merge, 0 elsewhere (the masks are 0x00 / 0xFF per byte)
+    v1 = ENV2048_AND_OR(ob + K01, m_bc, (oa + K01) & m_ab);
+    v2 = (oc + K01) & m_cd;
+}
+
+// Score of the line in byte lane `shift / 8` of a (v1, v2) pair: 2^v1 + 2^v2, a zero exponent meaning "no merge" (a merged
+// exponent is at least 2, so bit 0 of 1 << v is set exactly when there was none).
+ENV2048_DEV uint32_t line_score(uint32_t v1, uint32_t v2, uint32_t shift)
+{
+    const uint32_t e1 = (v1 >> shift) & 0xFFu, e2 = (v2 >> shift) & 0xFFu;
+    return ((1u << (e1 & 31u)) & ~1u) + ((1u << (e2 & 31u)) & ~1u);
+}
+
+// Sum of the four line scores of a (v1, v2) pair == what slide_merge_planes() returns for the same planes.
+ENV2048_DEV uint32_t line_score_sum(uint32_t v1, uint32_t v2)
+{
+    return (line_score(v1, v2, 0u) + line_score(v1, v2, 8u)) + (line_score(v1, v2, 16u) + line_score(v1, v2, 24u));
+}
+
 }  // namespace env2048

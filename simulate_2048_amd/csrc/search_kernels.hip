@@ -213,10 +213,12 @@ __global__ __launch_bounds__(PLY_BLOCK) void expectimax_ply_kernel(uint64_t n, c
 // board it/2 and the 32 lanes of a half-wave add up their best rewards separately for the tile-2 and the tile-4 outcomes
 // (four xor-shuffles: the sums are INTEGERS, so the result does not depend on the order); phase 3, one board per lane
 // again: Q2 = r + (0.9 * S2 + 0.1 * S4) / n_empty as an exact fraction, arg-max, outputs.  Pure VALU work: 16 B in, 89 B out per board.
-struct D2After {  // one (board, action) entry of the LDS strip: 24 bytes
-    uint32_t r0, r1, r2, r3;  // the afterstate
-    uint32_t empties;         // cell mask of the afterstate's empty cells; 0 = action illegal
-    int32_t reward;
+struct D2After {  // one (board, action) entry of the LDS strip: 48 bytes, read as three 16-byte words
+    uint32_t r0, r1, r2, r3;      // the afterstate
+    uint32_t hv1, hv2, vv1, vv2;  // per-line merge exponents (line_merge_terms): rows as lines (byte j = row j), columns as lines
+    uint32_t empties;             // cell mask of the afterstate's empty cells; 0 = action illegal
+    uint32_t h_sum, v_sum;        // merge score of a horizontal / a vertical move on the afterstate (sum over its four lines)
+    uint32_t reward;              // merge score of the move that led here (0 for an illegal action)
 };
 
 // best reward over the legal moves of one board (0 if it has none): one byte transpose shared by the four slides
@@ -234,74 +236,104 @@ __device__ __forceinline__ int32_t best_move_reward(const Board &bd)
     return max(horizontal, vertical);  // all-zero = no merge anywhere: 0 either way
 }
 
-constexpr int D2_BLOCK = 256;
+// Inclusive max-scan over the 64 lanes of a wave (values >= 0, identity 0): four row-local DPP shifts, then the last lane
+// of rows 0 / 2 into rows 1 / 3 and the last lane of row 1 into rows 2 / 3 (the gfx9 row_bcast forms).
+__device__ __forceinline__ uint32_t wave_scan_max(uint32_t v)
+{
+#define ENV2048_SCAN_STEP(CTRL, ROWS) v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWS, 0xF, false))
+    ENV2048_SCAN_STEP(0x111, 0xF);  // row_shr:1
+    ENV2048_SCAN_STEP(0x112, 0xF);  // row_shr:2
+    ENV2048_SCAN_STEP(0x114, 0xF);  // row_shr:4
+    ENV2048_SCAN_STEP(0x118, 0xF);  // row_shr:8
+    ENV2048_SCAN_STEP(0x142, 0xA);  // row_bcast:15 -> rows 1, 3
+    ENV2048_SCAN_STEP(0x143, 0xC);  // row_bcast:31 -> rows 2, 3
+#undef ENV2048_SCAN_STEP
+    return v;
+}
 
+constexpr int D2_BLOCK = 256;
+// A wave owns 32 boards, two lanes per board in phase 1.  Phase 2 is where the time goes and it runs with all 64 lanes whatever
+// a wave owns; what the number sets is the LDS a wave needs (58 B per (board, action) entry), i.e. how many waves a CU holds
+// to hide the LDS round trips of phase 2.  Measured on 4.5 M leaf boards: 64 boards per wave (8 waves per CU) 1080 us, 32 boards
+// (20 waves per CU by LDS, then limited by registers) 829 us, 16 boards 1069 us (phase 1 half empty twice over).
+constexpr int D2_WAVE_BOARDS = 32;
+constexpr int D2_ENTRIES = 4 * D2_WAVE_BOARDS;
+constexpr int D2_BLOCK_BOARDS = D2_WAVE_BOARDS * (D2_BLOCK / 64);
+
+// Phase 2 works on CELLS, not successors: the tile-2 and the tile-4 successor of one empty cell of an afterstate differ from
+// the afterstate in the same row and the same column only, and a move's merge score is a sum over its four lines -- so
+//     best reward of a successor = max(h_sum - old row + new row,  v_sum - old column + new column)
+// with the line scores of the afterstate computed once per (board, action) entry in phase 1 (line_merge_terms on the rows and
+// on the columns) and the FOUR new lines of a cell (row and column, with a 2 and with a 4) scored by ONE four-line evaluation.
+// That is one line evaluation per two successors instead of two whole-board slides per successor.
 __global__ __launch_bounds__(D2_BLOCK) void expectimax_depth2_kernel(uint64_t n, const uint8_t *boards, int32_t *terms, float *q,
                                                                       uint8_t *best_action, float *value, double *value64)
 {
-    __shared__ __attribute__((aligned(16))) D2After strip_lds[D2_BLOCK / 64][64 * 4];
-    __shared__ int32_t sums_lds[D2_BLOCK / 64][64 * 4][2];   // per (board, action): S2, S4
-    __shared__ uint16_t first_lds[D2_BLOCK / 64][64 * 4 + 4];  // exclusive prefix sum of the successor counts (+ the total)
+    __shared__ __attribute__((aligned(16))) D2After strip_lds[D2_BLOCK / 64][D2_ENTRIES];
+    __shared__ int32_t sums_lds[D2_BLOCK / 64][D2_ENTRIES][2];  // per (board, action): S2, S4
+    __shared__ uint16_t head_lds[D2_BLOCK / 64][64];            // per 64-cell chunk: entry + 1 that STARTS at this position
+    __shared__ uint16_t first_lds[D2_BLOCK / 64][D2_ENTRIES];   // first work item of every entry
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint64_t board0 = ((uint64_t)blockIdx.x * (D2_BLOCK / 64) + wave) * 64u;
+    const uint64_t board0 = ((uint64_t)blockIdx.x * (D2_BLOCK / 64) + wave) * (uint64_t)D2_WAVE_BOARDS;
     if (board0 >= n) return;  // wave-uniform
     D2After *strip = strip_lds[wave];
     int32_t(*sums)[2] = sums_lds[wave];
-    uint16_t *first = first_lds[wave];
+    uint16_t *head = head_lds[wave];
+    uint16_t *first_of = first_lds[wave];
 
-    // phase 1: one board per lane -> four afterstates
-    const uint64_t mine = board0 + lane;
-    uint32_t mine_count = 0u, c0 = 0u, c1 = 0u, c2 = 0u;  // successors of my board, and of its first three actions
-    if (mine < n) {
+    // phase 1: TWO lanes per board -- lane b takes the horizontal moves (actions 0 and 2: the transposed board as planes),
+    // lane b + 32 the vertical ones (1 and 3: the rows as planes) -> per action the afterstate, its line scores, its empty cells
+    const uint32_t b = lane & 31u;
+    const bool vertical = lane >= 32u;
+    const uint64_t mine = board0 + b;
+    const bool has_board = mine < n;
+    const uint32_t e_first = 4u * b + (vertical ? 1u : 0u), e_second = e_first + 2u;  // my two entries
+    uint32_t my_cells[2] = {0u, 0u};
+    if (has_board) {
         const Board bd = load_board(boards, mine);
         uint32_t t0, t1, t2, t3;
         transpose4x4(bd.r0, bd.r1, bd.r2, bd.r3, t0, t1, t2, t3);
-        Board after[4];
-        int32_t rewards[4];
-        uint32_t legal = 0u, changed;
-        {
-            uint32_t a = t0, b = t1, c = t2, d = t3;
-            rewards[0] = (int32_t)slide_merge_planes(a, b, c, d, changed);
-            transpose4x4(a, b, c, d, after[0].r0, after[0].r1, after[0].r2, after[0].r3);
-            legal |= changed != 0u ? 1u : 0u;
-        }
-        {
-            uint32_t a = bd.r0, b = bd.r1, c = bd.r2, d = bd.r3;
-            rewards[1] = (int32_t)slide_merge_planes(a, b, c, d, changed);
-            after[1] = Board{a, b, c, d};
-            legal |= changed != 0u ? 2u : 0u;
-        }
-        {
-            uint32_t a = t3, b = t2, c = t1, d = t0;
-            rewards[2] = (int32_t)slide_merge_planes(a, b, c, d, changed);
-            transpose4x4(d, c, b, a, after[2].r0, after[2].r1, after[2].r2, after[2].r3);
-            legal |= changed != 0u ? 4u : 0u;
-        }
-        {
-            uint32_t a = bd.r3, b = bd.r2, c = bd.r1, d = bd.r0;
-            rewards[3] = (int32_t)slide_merge_planes(a, b, c, d, changed);
-            after[3] = Board{d, c, b, a};
-            legal |= changed != 0u ? 8u : 0u;
-        }
-        uint32_t count[4];
+        // the planes of my first action (0: columns, 1: rows); my second action (2, 3) takes them in reverse order
+        const uint32_t x0 = vertical ? bd.r0 : t0, x1 = vertical ? bd.r1 : t1, x2 = vertical ? bd.r2 : t2, x3 = vertical ? bd.r3 : t3;
 #pragma unroll
-        for (uint32_t act = 0; act < 4u; ++act) {
-            const bool is_legal = ((legal >> act) & 1u) != 0u;
-            const uint32_t empt = is_legal ? empty_mask(after[act]) : 0u;  // a legal move always leaves an empty cell
-            strip[4u * lane + act] = D2After{after[act].r0, after[act].r1, after[act].r2, after[act].r3, empt, is_legal ? rewards[act] : 0};
-            sums[4u * lane + act][0] = 0;
-            sums[4u * lane + act][1] = 0;
-            count[act] = 2u * ENV2048_POPC(empt);  // successors of this afterstate: a 2 and a 4 in every empty cell
+        for (uint32_t second = 0; second < 2u; ++second) {
+            uint32_t pa = second ? x3 : x0, pb = second ? x2 : x1, pc = second ? x1 : x2, pd = second ? x0 : x3, changed;
+            const int32_t reward = (int32_t)slide_merge_planes(pa, pb, pc, pd, changed);
+            const uint32_t y0 = second ? pd : pa, y1 = second ? pc : pb, y2 = second ? pb : pc, y3 = second ? pa : pd;  // planes in board order
+            uint32_t u0, u1, u2, u3;
+            transpose4x4(y0, y1, y2, y3, u0, u1, u2, u3);
+            // afterstate as rows (as) and as columns (ac): for a vertical move the planes ARE the rows
+            const Board as{vertical ? y0 : u0, vertical ? y1 : u1, vertical ? y2 : u2, vertical ? y3 : u3};
+            const Board ac{vertical ? u0 : y0, vertical ? u1 : y1, vertical ? u2 : y2, vertical ? u3 : y3};
+            const bool is_legal = changed != 0u;
+            const uint32_t empt = is_legal ? empty_mask(as) : 0u;  // a legal move always leaves an empty cell
+            uint32_t hv1, hv2, vv1, vv2;
+            line_merge_terms(ac.r0, ac.r1, ac.r2, ac.r3, hv1, hv2);  // rows as lines: plane k = column k
+            line_merge_terms(as.r0, as.r1, as.r2, as.r3, vv1, vv2);  // columns as lines: plane k = row k
+            const uint32_t e = second ? e_second : e_first;
+            strip[e] = D2After{as.r0, as.r1, as.r2, as.r3, hv1, hv2, vv1, vv2, empt, line_score_sum(hv1, hv2), line_score_sum(vv1, vv2),
+                               is_legal ? (uint32_t)reward : 0u};
+            sums[e][0] = 0;
+            sums[e][1] = 0;
+            my_cells[second] = ENV2048_POPC(empt);
         }
-        mine_count = count[0] + count[1] + count[2] + count[3];
-        c0 = count[0];
-        c1 = count[1];
-        c2 = count[2];
+    } else {
+        strip[e_first].empties = 0u;  // (the scan below reads the cell masks of all 128 entries)
+        strip[e_second].empties = 0u;
     }
-    // successors are WORK ITEMS numbered densely over the wave's 256 (board, action) entries: entry e owns items
-    // [first[e], first[e + 1]).  On mid-game boards 34 of the 128 slots per board hold a successor, so walking the slots
-    // would leave three quarters of the lanes idle.  Exclusive scan of the per-board counts over the wave (six shuffles).
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // strip, sums, head and first_of are wave-private: LDS ops of a wave are ordered
+    __builtin_amdgcn_wave_barrier();
+    // empty cells are WORK ITEMS numbered densely over the wave's 128 (board, action) entries: entry e owns items
+    // [first_of[e], first_of[e] + cells[e]).  On mid-game boards 17 of the 64 (action, cell) slots per board hold one, so
+    // walking the slots would leave three quarters of the lanes idle.  Lane b (< 32) counts board b's four entries; exclusive
+    // scan over the wave (the upper lanes contribute nothing).
+    uint32_t cells[4] = {0u, 0u, 0u, 0u};
+    if (!vertical) {
+#pragma unroll
+        for (uint32_t act = 0; act < 4u; ++act) cells[act] = ENV2048_POPC(strip[4u * b + act].empties);
+    }
+    const uint32_t mine_count = cells[0] + cells[1] + cells[2] + cells[3];
     uint32_t scan = mine_count;
 #pragma unroll
     for (uint32_t d = 1; d < 64u; d <<= 1) {
@@ -309,39 +341,66 @@ __global__ __launch_bounds__(D2_BLOCK) void expectimax_depth2_kernel(uint64_t n,
         scan += lane >= d ? up : 0u;
     }
     const uint32_t total = __shfl(scan, 63);
-    const uint32_t before = scan - mine_count;
-    first[4u * lane + 0u] = (uint16_t)before;
-    first[4u * lane + 1u] = (uint16_t)(before + c0);
-    first[4u * lane + 2u] = (uint16_t)(before + c0 + c1);
-    first[4u * lane + 3u] = (uint16_t)(before + c0 + c1 + c2);
-    if (lane == 63u) first[256] = (uint16_t)total;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // strip, sums and first are wave-private: LDS ops of a wave are ordered
+    if (!vertical) {
+        const uint32_t f0 = scan - mine_count, f1 = f0 + cells[0], f2 = f1 + cells[1], f3 = f2 + cells[2];
+        first_of[4u * b + 0u] = (uint16_t)f0;
+        first_of[4u * b + 1u] = (uint16_t)f1;
+        first_of[4u * b + 2u] = (uint16_t)f2;
+        first_of[4u * b + 3u] = (uint16_t)f3;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    const uint32_t my_first[2] = {first_of[e_first], first_of[e_second]};  // where my two entries start (for the heads below)
 
-    // phase 2: 64 successors per iteration
+    // phase 2: 64 cells per iteration.  Which entry an item belongs to: every entry that STARTS inside the chunk drops its
+    // number at its first position, a max-scan over the lanes spreads it to the items behind it, and items in front of the
+    // chunk's first start belong to the entry the previous chunk ended in (`carry`).  Entry numbers grow with the item
+    // number, entries without cells start nowhere.
+    uint32_t carry = 0u;
     for (uint32_t w0 = 0; w0 < total; w0 += 64u) {
+        head[lane] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (uint32_t second = 0; second < 2u; ++second) {
+            const uint32_t at = my_first[second] - w0;  // (wraps for entries in front of the chunk: >= 64 then)
+            if (my_cells[second] != 0u && at < 64u) head[at] = (uint16_t)((second ? e_second : e_first) + 1u);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t started = wave_scan_max(head[lane]);
+        const uint32_t entry1 = max(started, carry);  // entry + 1 of this lane's item
+        carry = __builtin_amdgcn_readlane(entry1, 63);
         const uint32_t w = w0 + lane;
         if (w < total) {
-            uint32_t lo = 0u, hi = 256u;  // the LAST entry whose first item is <= w (entries without successors are skipped by that)
-#pragma unroll
-            for (int step = 0; step < 8; ++step) {
-                const uint32_t mid = (lo + hi) >> 1;
-                const bool right = first[mid] <= w;
-                lo = right ? mid : lo;
-                hi = right ? hi : mid;
-            }
-            const D2After a = strip[lo];
-            const uint32_t slot = w - first[lo];
-            Board bd{a.r0, a.r1, a.r2, a.r3};
-            place_tile(bd, kth_empty(a.empties, slot >> 1), (slot & 1u) != 0u);
-            atomicAdd(&sums[lo][slot & 1u], best_move_reward(bd));  // integer sums: the order of the adds does not matter
+            const uint32_t e = entry1 - 1u;
+            const uint4 rows = reinterpret_cast<const uint4 *>(&strip[e])[0];
+            const uint4 lines = reinterpret_cast<const uint4 *>(&strip[e])[1];
+            const uint4 rest = reinterpret_cast<const uint4 *>(&strip[e])[2];
+            const uint32_t bit = kth_empty(rest.x, w - first_of[e]);  // my cell: the (w - first item of my entry)-th empty one
+            const uint32_t pos = (uint32_t)ENV2048_FFS(bit) - 1u;  // 8 * column + {5, 6, 7, 4}[row]
+            const uint32_t col8 = pos & 24u, row = (pos - 5u) & 3u, row8 = 8u * row;
+            const uint32_t old_row = row == 0u ? rows.x : row == 1u ? rows.y : row == 2u ? rows.z : rows.w;
+            const uint32_t sel = 0x0C0C0400u + 0x0101u * (pos >> 3);  // byte `column` of a low and of a high dword
+            const uint32_t old_col = byte_perm(byte_perm(rows.w, rows.z, sel), byte_perm(rows.y, rows.x, sel), 0x05040100u);
+            // the afterstate's own score on these two lines, and the four new lines: (row, column) x (tile 2, tile 4)
+            const uint32_t h_base = rest.y - line_score(lines.x, lines.y, row8);
+            const uint32_t v_base = rest.z - line_score(lines.z, lines.w, col8);
+            const uint32_t l0 = old_row | (1u << col8), l1 = old_col | (1u << row8), l2 = old_row | (2u << col8), l3 = old_col | (2u << row8);
+            uint32_t p0, p1, p2, p3, v1, v2;
+            transpose4x4(l0, l1, l2, l3, p0, p1, p2, p3);  // plane k = element k of the four lines
+            line_merge_terms(p0, p1, p2, p3, v1, v2);
+            const uint32_t best2 = max(h_base + line_score(v1, v2, 0u), v_base + line_score(v1, v2, 8u));
+            const uint32_t best4 = max(h_base + line_score(v1, v2, 16u), v_base + line_score(v1, v2, 24u));
+            atomicAdd(&sums[e][0], (int32_t)best2);  // integer sums: the order of the adds does not matter
+            atomicAdd(&sums[e][1], (int32_t)best4);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
-    // phase 3: one board per lane again
-    if (mine >= n) return;
+    // phase 3: one board per lane again (lanes 0 .. 31)
+    if (vertical || !has_board) return;
     // Q2 = r + (0.9 S2 + 0.1 S4) / n = X / D with the INTEGERS X = 10 n r + 9 S2 + S4 and D = 10 n: the arg-max compares the
     // fractions exactly (cross-multiplied in 64 bits; a tie keeps the smaller action) and the float outputs are ONE correctly
     // rounded double division each -- so device and oracle agree bit for bit, independent of fma contraction or summation order
@@ -351,11 +410,11 @@ __global__ __launch_bounds__(D2_BLOCK) void expectimax_depth2_kernel(uint64_t n,
     int4 t[4];
 #pragma unroll
     for (uint32_t act = 0; act < 4u; ++act) {
-        const D2After a = strip[4u * lane + act];
-        const int32_t s2 = sums[4u * lane + act][0], s4 = sums[4u * lane + act][1], n_empty = (int32_t)ENV2048_POPC(a.empties);
-        t[act] = make_int4(a.reward, s2, s4, n_empty);
-        if (a.empties != 0u) {
-            const int64_t d = 10 * (int64_t)n_empty, x = d * (int64_t)a.reward + 9 * (int64_t)s2 + (int64_t)s4;
+        const int32_t s2 = sums[4u * b + act][0], s4 = sums[4u * b + act][1], n_empty = (int32_t)cells[act];
+        const int32_t reward = (int32_t)strip[4u * b + act].reward;
+        t[act] = make_int4(reward, s2, s4, n_empty);
+        if (n_empty != 0) {
+            const int64_t d = 10 * (int64_t)n_empty, x = d * (int64_t)reward + 9 * (int64_t)s2 + (int64_t)s4;
             q4[act] = (float)((double)x / (double)d);
             if (best_a == 255u || x * best_d > best_x * d) {
                 best_x = x;
@@ -681,7 +740,7 @@ int env2048_expectimax_depth2(int device, void *stream, uint64_t n, const uint8_
     if (int rc = check_count(n)) return rc;
     DeviceScope scope(device);
     if (scope.rc) return scope.rc;
-    hipLaunchKernelGGL(expectimax_depth2_kernel, dim3((unsigned)((n + D2_BLOCK - 1) / D2_BLOCK)), dim3(D2_BLOCK), 0, (hipStream_t)stream, n,
+    hipLaunchKernelGGL(expectimax_depth2_kernel, dim3((unsigned)((n + D2_BLOCK_BOARDS - 1) / D2_BLOCK_BOARDS)), dim3(D2_BLOCK), 0, (hipStream_t)stream, n,
                        boards, terms, q, best_action, value, static_cast<double *>(nullptr));
     return launched("env2048_expectimax_depth2 launch");
 }
@@ -694,7 +753,7 @@ int env2048_expectimax_depth2_f64(int device, void *stream, uint64_t n, const ui
     if (int rc = check_count(n)) return rc;
     DeviceScope scope(device);
     if (scope.rc) return scope.rc;
-    hipLaunchKernelGGL(expectimax_depth2_kernel, dim3((unsigned)((n + D2_BLOCK - 1) / D2_BLOCK)), dim3(D2_BLOCK), 0, (hipStream_t)stream, n,
+    hipLaunchKernelGGL(expectimax_depth2_kernel, dim3((unsigned)((n + D2_BLOCK_BOARDS - 1) / D2_BLOCK_BOARDS)), dim3(D2_BLOCK), 0, (hipStream_t)stream, n,
                        boards, static_cast<int32_t *>(nullptr), static_cast<float *>(nullptr), static_cast<uint8_t *>(nullptr),
                        static_cast<float *>(nullptr), value);
     return launched("env2048_expectimax_depth2_f64 launch");

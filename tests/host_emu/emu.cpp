@@ -172,4 +172,21 @@ void emu_max_exponent(uint64_t n, const uint8_t *boards, uint8_t *out)
     for (uint64_t i = 0; i < n; ++i) out[i] = (uint8_t)max_exponent(load(boards + 16 * i));
 }
 
+// per-line merge scores (line_merge_terms / line_score): `lines` holds n_lines x 4 exponent bytes (element 0 nearest the wall),
+// four consecutive lines are evaluated together (byte lane j of the planes = line j); scores[i] = score of line i.
+void emu_line_scores(uint64_t n_lines, const uint8_t *lines, uint32_t *scores, uint32_t *group_sums, uint32_t *group_slide_scores)
+{
+    for (uint64_t g = 0; 4 * g < n_lines; ++g) {
+        uint32_t plane[4] = {0u, 0u, 0u, 0u};
+        for (uint32_t j = 0; j < 4 && 4 * g + j < n_lines; ++j)
+            for (uint32_t k = 0; k < 4; ++k) plane[k] |= (uint32_t)lines[4 * (4 * g + j) + k] << (8 * j);
+        uint32_t v1, v2;
+        line_merge_terms(plane[0], plane[1], plane[2], plane[3], v1, v2);
+        for (uint32_t j = 0; j < 4 && 4 * g + j < n_lines; ++j) scores[4 * g + j] = line_score(v1, v2, 8 * j);
+        group_sums[g] = line_score_sum(v1, v2);
+        uint32_t a = plane[0], b = plane[1], c = plane[2], d = plane[3], changed;
+        group_slide_scores[g] = slide_merge_planes(a, b, c, d, changed);
+    }
+}
+
 }  // extern "C"

@@ -92,6 +92,34 @@ def test_rows_exhaustive(emu, golden, mode):
         np.testing.assert_array_equal(changed, g['can_move'])
 
 
+def test_line_scores_exhaustive(emu, golden):
+    """line_merge_terms / line_score (the per-line scores the expectimax leaf evaluator is built on): every one of the 18^4
+    exponent rows scores what the reference's merge_column scored it (rows.npz), as any of the four lines of a group; the sum
+    over a group equals slide_merge_planes' score; exponents up to 30 (merging into 2^31) are covered by random lines against the same slide."""
+    g = golden['rows']
+    base = int(g['max_e']) + 1
+    idx = np.arange(base**4)
+    rows = np.stack([(idx // base**3) % base, (idx // base**2) % base, (idx // base) % base, idx % base], axis=1).astype(np.uint8)
+    rng = np.random.default_rng(5)
+    big = rng.integers(0, 31, size=(40_000, 4)).astype(np.uint8) * (rng.random((40_000, 4)) < 0.7)  # (a merge of two 2^31 tiles is outside the domain)
+    eq = rng.random(40_000) < 0.6
+    big[eq, 1] = big[eq, 0]
+    eq2 = rng.random(40_000) < 0.4
+    big[eq2, 3] = big[eq2, 2]
+    for lines, want in ((rows, g['score'].astype(np.uint32)), (rows[rng.permutation(rows.shape[0])], None), (big.astype(np.uint8), None)):
+        lines = np.ascontiguousarray(lines)
+        n = lines.shape[0]
+        scores = np.zeros(n, dtype=np.uint32)
+        sums = np.zeros((n + 3) // 4, dtype=np.uint32)
+        slides = np.zeros((n + 3) // 4, dtype=np.uint32)
+        emu.emu_line_scores(ctypes.c_uint64(n), u8(lines), ptr(scores, ctypes.c_uint32), ptr(sums, ctypes.c_uint32), ptr(slides, ctypes.c_uint32))
+        if want is not None:
+            np.testing.assert_array_equal(scores, want)
+        np.testing.assert_array_equal(sums, slides)
+        padded = np.concatenate([scores, np.zeros((-n) % 4, dtype=np.uint32)]).reshape(-1, 4)
+        np.testing.assert_array_equal(padded.sum(axis=1, dtype=np.uint32), sums)
+
+
 def test_status_and_spawn(emu, golden):
     g = golden['afterstates']
     boards = np.ascontiguousarray(g['boards'])
