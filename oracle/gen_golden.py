@@ -368,44 +368,58 @@ def gen_expectimax_d2():
     return n, int((best == 255).sum()), float(np.nanmax(np.where(np.isfinite(q), q, np.nan)))
 
 
-def gen_expectimax_d3(count: int = 36):
+def _ref_legal(state, a):
+    return bool(ref_move.can_move(np.rot90(state, k=a)))
+
+
+def _ref_value(state, depth):
+    """V_depth(state) by plain recursion over the reference's own functions (see gen_expectimax_d3)."""
+    best = None
+    for a in range(4):
+        if not _ref_legal(state, a):
+            continue
+        after, r = ref_board.latent_state(state, a)
+        q = float(r)
+        if depth > 1:
+            q += sum(pr * _ref_value(o, depth - 1) for o, pr in ref_board.after_state(after))
+        best = q if best is None or q > best else best
+    return 0.0 if best is None else best
+
+
+def _ref_q3(exps):
+    """(q (4,), best, value) of one board at depth 3."""
+    state = to_values(exps).reshape(4, 4)
+    q = np.full(4, -np.inf, dtype=np.float64)
+    for a in range(4):
+        if _ref_legal(state, a):
+            after, r = ref_board.latent_state(state, a)
+            q[a] = float(r) + sum(pr * _ref_value(o, 2) for o, pr in ref_board.after_state(after))
+    if np.isfinite(q).any():
+        best = int(np.argmax(q))  # first maximum
+        return q, best, q[best]
+    return q, 255, 0.0
+
+
+def gen_expectimax_d3(count: int = 512):
     """Depth-3 expectimax composed LITERALLY from the reference's functions (latent_state, after_state with ITS probabilities,
     can_move), by plain recursion, float64, outcomes in after_state's order: Q3(s, a) = r + sum P(o) * V2(o),
     V2(o) = max over legal a' of [r' + sum P(o') * best legal latent_state reward of o'].  Pins oracle_expectimax_depth /
     the device back-up chain to ~1e-12 relative (the build sums 0.9 * S2 + 0.1 * S4 and divides once; the reference's
-    per-outcome products round differently) and the arg-max wherever it is not a near-tie."""
+    per-outcome products round differently) and the arg-max wherever it is not a near-tie.  512 boards spread evenly over the
+    chance_outcomes set (random-play states of all depths, terminal boards included); about two seconds of reference time per
+    board, so the boards are farmed out to a process pool (the result does not depend on the pool: one board per task)."""
+    import multiprocessing as mp
+    import os
+
     boards = np.load(OUT / 'chance_outcomes.npz')['boards']
     pick = np.linspace(0, boards.shape[0] - 1, count).astype(int)
     boards = boards[pick]
-
-    def legal(state, a):
-        return bool(ref_move.can_move(np.rot90(state, k=a)))
-
-    def value(state, depth):
-        best = None
-        for a in range(4):
-            if not legal(state, a):
-                continue
-            after, r = ref_board.latent_state(state, a)
-            q = float(r)
-            if depth > 1:
-                q += sum(pr * value(o, depth - 1) for o, pr in ref_board.after_state(after))
-            best = q if best is None or q > best else best
-        return 0.0 if best is None else best
-
     n = boards.shape[0]
-    q = np.full((n, 4), -np.inf, dtype=np.float64)
-    best = np.full(n, 255, dtype=np.uint8)
-    val = np.zeros(n, dtype=np.float64)
-    for i in range(n):
-        state = to_values(boards[i]).reshape(4, 4)
-        for a in range(4):
-            if legal(state, a):
-                after, r = ref_board.latent_state(state, a)
-                q[i, a] = float(r) + sum(pr * value(o, 2) for o, pr in ref_board.after_state(after))
-        if np.isfinite(q[i]).any():
-            best[i] = int(np.argmax(q[i]))
-            val[i] = q[i, best[i]]
+    with mp.get_context('fork').Pool(min(8, os.cpu_count() or 1)) as pool:
+        results = pool.map(_ref_q3, [boards[i] for i in range(n)], chunksize=4)
+    q = np.stack([r[0] for r in results]).astype(np.float64)
+    best = np.array([r[1] for r in results], dtype=np.uint8)
+    val = np.array([r[2] for r in results], dtype=np.float64)
     np.savez_compressed(OUT / 'expectimax_d3.npz', boards=boards, q=q, best=best, value=val)
     return n, int((best == 255).sum()), float(val.max())
 
@@ -438,8 +452,19 @@ def gen_random_play_stats(games: int = 3000):
     return games, float(length.mean()), float(total.mean()), float(invalid.sum() / length.sum())
 
 
+def write_checksums():
+    with open(OUT / 'SHA256SUMS', 'w') as fh:
+        for p in sorted(OUT.glob('*.npz')):
+            fh.write(f'{hashlib.sha256(p.read_bytes()).hexdigest()}  {p.name}\n')
+            print(p.name, p.stat().st_size)
+
+
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
+    if len(sys.argv) > 2 and sys.argv[1] == '--only':  # regenerate ONE fixture set (each is a deterministic function of its inputs)
+        print(sys.argv[2], globals()['gen_' + sys.argv[2]]())
+        write_checksums()
+        return
     rng = np.random.default_rng(20480)
     print('rows', gen_rows())
     print('afterstates', gen_afterstates(rng))
@@ -451,10 +476,7 @@ def main():
     print('expectimax_d2', gen_expectimax_d2())
     print('expectimax_d3', gen_expectimax_d3())
     print('random_play_stats', gen_random_play_stats())
-    with open(OUT / 'SHA256SUMS', 'w') as fh:
-        for p in sorted(OUT.glob('*.npz')):
-            fh.write(f'{hashlib.sha256(p.read_bytes()).hexdigest()}  {p.name}\n')
-            print(p.name, p.stat().st_size)
+    write_checksums()
 
 
 if __name__ == '__main__':

@@ -119,6 +119,7 @@ PROTOTYPES = {
     'env2048_expectimax_ply': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
     'env2048_expectimax_depth2': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr, _ptr]),
     'env2048_expand_count': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr]),
+    'env2048_expand_offsets': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr, _u64]),
     'env2048_expand': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr, _ptr]),
     'env2048_expectimax_depth2_f64': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr]),
     'env2048_expectimax_backup': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
@@ -305,6 +306,9 @@ class Library:
 
     def expand_count(self, device, stream, n, boards, counts) -> None:
         self._check(self._dll.env2048_expand_count(device, stream, n, boards, counts))
+
+    def expand_offsets(self, device, stream, n, boards, offsets, scratch, host_total=None, sequence_value=0) -> None:
+        self._check(self._dll.env2048_expand_offsets(device, stream, n, boards, offsets, scratch, host_total, sequence_value))
 
     def expand(self, device, stream, n, boards, offsets, children, reward, n_empty) -> None:
         self._check(self._dll.env2048_expand(device, stream, n, boards, offsets, children, reward, n_empty))

@@ -492,6 +492,83 @@ __global__ __launch_bounds__(BLOCK) void expand_count_kernel(uint64_t n, const u
     counts[i] = count;
 }
 
+// ---- offsets of a level on the device: count, scan, total -- no host round trip per level ---------------------------------
+// expand_offsets_kernel: children of every board of a block of BLOCK boards + the exclusive scan inside the block (wave scan
+// by DPP-free shuffles, then the eight wave totals through LDS): offsets[i] = children of the block's boards before i,
+// block_total[block] = children of the block.
+__global__ __launch_bounds__(BLOCK) void expand_offsets_kernel(uint64_t n, const uint8_t *boards, uint64_t *offsets, uint64_t *block_total)
+{
+    __shared__ uint32_t wave_total[WAVES_PER_BLOCK];
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t count = 0u;
+    if (i < n) {
+        Board after[4];
+        int32_t rewards[4];
+        uint32_t legal;
+        four_afterstates(load_board(boards, i), after, rewards, legal);
+#pragma unroll
+        for (uint32_t act = 0; act < 4u; ++act)
+            if ((legal >> act) & 1u) count += 2u * ENV2048_POPC(empty_mask(after[act]));
+    }
+    uint32_t scan = count;
+#pragma unroll
+    for (uint32_t d = 1; d < 64u; d <<= 1) {
+        const uint32_t up = __shfl_up(scan, d);
+        scan += lane >= d ? up : 0u;
+    }
+    if (lane == 63u) wave_total[wave] = scan;
+    __syncthreads();
+    uint32_t before = 0u, all = 0u;
+#pragma unroll
+    for (uint32_t w = 0; w < (uint32_t)WAVES_PER_BLOCK; ++w) {
+        const uint32_t t = wave_total[w];
+        before += w < wave ? t : 0u;
+        all += t;
+    }
+    if (i < n) offsets[i] = (uint64_t)(before + scan - count);
+    if (threadIdx.x == 0u) block_total[blockIdx.x] = all;
+}
+
+// One workgroup: exclusive scan of the block totals in place (-> the first child of every block), the grand total behind
+// them, and -- for a host that has to size the next frontier -- the total + a completion word in pinned host memory.
+__global__ __launch_bounds__(1024) void scan_block_totals_kernel(uint64_t blocks, uint64_t *block_total, uint64_t *host_total, uint64_t sequence_value)
+{
+    __shared__ uint64_t part[1024];
+    const uint64_t per = (blocks + 1023u) / 1024u, lo = min(blocks, (uint64_t)threadIdx.x * per), hi = min(blocks, lo + per);
+    uint64_t sum = 0;
+    for (uint64_t k = lo; k < hi; ++k) sum += block_total[k];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024u; d <<= 1) {  // Hillis-Steele inclusive scan of the 1024 partial sums
+        const uint64_t add = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint64_t run = part[threadIdx.x] - sum;  // children before my chunk
+    for (uint64_t k = lo; k < hi; ++k) {
+        const uint64_t t = block_total[k];
+        block_total[k] = run;
+        run += t;
+    }
+    if (threadIdx.x == 1023u) {
+        const uint64_t total = part[1023];
+        block_total[blocks] = total;
+        if (host_total) {
+            host_total[0] = total;
+            __threadfence_system();
+            __hip_atomic_store(host_total + 1, sequence_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void add_block_base_kernel(uint64_t n, uint64_t *offsets, const uint64_t *block_base)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) offsets[i] += block_base[blockIdx.x];
+}
+
 __global__ __launch_bounds__(BLOCK) void expand_kernel(uint64_t n, const uint8_t *boards, const uint64_t *offsets, uint8_t *children,
                                                        int32_t *reward, uint8_t *n_empty)
 {
@@ -769,6 +846,23 @@ int env2048_expand_count(int device, void *stream, uint64_t n, const uint8_t *bo
     if (scope.rc) return scope.rc;
     hipLaunchKernelGGL(expand_count_kernel, grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, n, boards, counts);
     return launched("env2048_expand_count launch");
+}
+
+int env2048_expand_offsets(int device, void *stream, uint64_t n, const uint8_t *boards, uint64_t *offsets, uint64_t *scratch,
+                           uint64_t *host_total, uint64_t sequence_value)
+{
+    if (n == 0) return ENV2048_OK;
+    if (!boards || !offsets || !scratch) return fail(ENV2048_ERR_INVALID_ARG, "env2048_expand_offsets: boards, offsets and scratch are required");
+    if (misaligned(boards, 16) || misaligned(offsets, 8) || misaligned(scratch, 8) || misaligned(host_total, 8))
+        return fail(ENV2048_ERR_ALIGNMENT, "env2048_expand_offsets: boards must be 16-byte, offsets / scratch / host_total 8-byte aligned");
+    if (int rc = check_count(n)) return rc;
+    DeviceScope scope(device);
+    if (scope.rc) return scope.rc;
+    const uint64_t blocks = (n + BLOCK - 1) / BLOCK;
+    hipLaunchKernelGGL(expand_offsets_kernel, grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, n, boards, offsets, scratch);
+    hipLaunchKernelGGL(scan_block_totals_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, blocks, scratch, host_total, sequence_value);
+    hipLaunchKernelGGL(add_block_base_kernel, grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, n, offsets, scratch);
+    return launched("env2048_expand_offsets launch");
 }
 
 int env2048_expand(int device, void *stream, uint64_t n, const uint8_t *boards, const uint64_t *offsets, uint8_t *children, int32_t *reward,

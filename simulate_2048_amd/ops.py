@@ -6,6 +6,8 @@ is asynchronous on torch's current stream (reading a result back synchronises as
 
 from __future__ import annotations
 
+import threading
+
 import numpy as np
 import torch
 
@@ -160,24 +162,46 @@ def expectimax_depth2(boards: torch.Tensor, *, want_terms: bool = False, rt=None
     return out
 
 
+_slots = threading.local()
+
+
+def _total_slot(rt):
+    """This thread's two-word host slot for env2048_expand_offsets (total, completion word) -- pinned on a HIP runtime -- and
+    the next completion value to use with it."""
+    entry = getattr(_slots, 'entry', None)
+    if entry is None or entry[0] != rt.device:
+        slot = torch.zeros((2,), dtype=torch.int64)
+        if rt.device.type == 'cuda':
+            slot = slot.pin_memory()
+        entry = _slots.entry = [rt.device, slot, slot.numpy(), slot.data_ptr(), 0]
+    entry[4] += 1
+    return entry
+
+
 def expand(boards: torch.Tensor, rt=None) -> dict:
     """One level of the search tree, densely: the children of every board (the (empty cell, tile) outcomes of its legal
     afterstates, in the order action / cell rank / tile 2, 4) as the next frontier.  -> dict(children (total, 16) u8,
     offsets (n,) int64 = first child of every board, reward (n, 4) i32, n_empty (n, 4) u8 (0 = illegal action)).
-    env2048_expand_count -> exclusive prefix sum -> env2048_expand; reading the total back is the one synchronisation."""
+    env2048_expand_offsets (count + scan on the device; the total arrives in pinned host memory behind a completion word, so
+    sizing the frontier costs a few microseconds of polling instead of a stream synchronisation and a copy) -> env2048_expand."""
     rt = rt or runtime.current()
     n = boards.shape[0]
     if n == 0:
         return {'children': torch.empty((0, 16), dtype=torch.uint8, device=rt.device), 'offsets': torch.empty((0,), dtype=torch.int64, device=rt.device),
                 'reward': torch.empty((0, 4), dtype=torch.int32, device=rt.device), 'n_empty': torch.empty((0, 4), dtype=torch.uint8, device=rt.device)}
     dev, stream = rt.handles()
-    counts = torch.empty((n,), dtype=torch.int32, device=rt.device)
-    rt.lib.expand_count(dev, stream, n, _p(boards), _p(counts))
-    ends = torch.cumsum(counts, dim=0, dtype=torch.int64)
-    offsets = ends - counts
-    total = int(ends[-1])
-    out = {'children': torch.empty((total, 16), dtype=torch.uint8, device=rt.device), 'offsets': offsets,
-           'reward': torch.empty((n, 4), dtype=torch.int32, device=rt.device), 'n_empty': torch.empty((n, 4), dtype=torch.uint8, device=rt.device)}
+    offsets = torch.empty((n,), dtype=torch.int64, device=rt.device)
+    scratch = torch.empty(((n + 511) // 512 + 1,), dtype=torch.int64, device=rt.device)
+    _, slot, words, address, serial = _total_slot(rt)
+    rt.lib.expand_offsets(dev, stream, n, _p(boards), _p(offsets), _p(scratch), address, serial)
+    out = {'offsets': offsets, 'reward': torch.empty((n, 4), dtype=torch.int32, device=rt.device),
+           'n_empty': torch.empty((n, 4), dtype=torch.uint8, device=rt.device)}  # (allocated while the device counts)
+    if not rt.lib.wait_sequence(address + 8, serial, 200):  # (a 2^20-board level counts for ~100 us; beyond the window: the general way)
+        rt.synchronize()
+        if int(words[1]) != serial:
+            raise RuntimeError('env2048_expand_offsets: the completion word did not arrive')
+    total = int(words[0])
+    out['children'] = torch.empty((total, 16), dtype=torch.uint8, device=rt.device)
     rt.lib.expand(dev, stream, n, _p(boards), _p(offsets), _p(out['children']) if total else None, _p(out['reward']), _p(out['n_empty']))
     return out
 

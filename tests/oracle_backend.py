@@ -336,6 +336,26 @@ class OracleLibrary:
             c += (2 * after[a]['changed'].astype(np.uint32) * (after[a]['boards'] == 0).sum(axis=1).astype(np.uint32))
         _view(counts, n, np.uint32)[:] = c
 
+    def expand_offsets(self, device, stream, n, boards, offsets, scratch, host_total=None, sequence_value=0):
+        self.calls.append(('expand_offsets', n))
+        counts = np.zeros(n, dtype=np.uint32)
+        self.expand_count(device, stream, n, boards, counts.ctypes.data)
+        self.calls.pop()
+        ends = np.cumsum(counts.astype(np.int64))
+        _view(offsets, n, np.int64)[:] = ends - counts
+        blocks = (n + 511) // 512
+        block_sums = np.add.reduceat(counts.astype(np.int64), np.arange(0, n, 512))
+        sc = _view(scratch, blocks + 1, np.int64)
+        sc[:blocks] = np.cumsum(block_sums) - block_sums
+        sc[blocks] = int(ends[-1])
+        if host_total is not None:
+            words = _view(host_total, 2, np.int64)
+            words[0] = int(ends[-1])
+            words[1] = sequence_value
+
+    def wait_sequence(self, host_sequence, value, timeout_us):
+        return int(_view(host_sequence, 1, np.uint64)[0]) == value
+
     def expand(self, device, stream, n, boards, offsets, children, reward, n_empty):
         self.calls.append(('expand', n))
         _, after = self._afterstates(boards, n)

@@ -137,3 +137,34 @@ def test_all_terminal_roots_have_empty_frontiers(api_runtime):
     assert out['frontier'] == [5, 0, 0]
     assert (out['best'].cpu().numpy() == 255).all() and not out['value'].cpu().numpy().any()
     assert np.isneginf(out['q'].cpu().numpy()).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n', [1, 511, 512, 513, 70_001, 700_003])
+def test_expand_offsets_on_the_device_equal_count_and_cumsum(n):
+    """env2048_expand_offsets (block scan, scan of the block totals by ONE workgroup -- 700 003 boards = 1368 blocks, more than
+    its 1024 threads --, add) against env2048_expand_count + a host prefix sum; the total arrives in pinned host memory behind
+    its completion word, and in scratch[blocks]."""
+    lib = capi.library()
+    s = torch.cuda.current_stream().cuda_stream
+    boards = torch.zeros((n, 16), dtype=torch.uint8, device='cuda')
+    lib.reset(0, s, n, 5, boards.data_ptr(), None, 31, 0)
+    lib.rollout(0, s, n, 5, boards.data_ptr(), 31, 0, 60 + n % 90, None, None, None, 3)
+    counts = torch.zeros((n,), dtype=torch.int32, device='cuda')
+    lib.expand_count(0, s, n, boards.data_ptr(), counts.data_ptr())
+    want = np.cumsum(counts.cpu().numpy().astype(np.int64))
+    offsets = torch.full((n,), -1, dtype=torch.int64, device='cuda')
+    blocks = (n + 511) // 512
+    scratch = torch.full((blocks + 1,), -1, dtype=torch.int64, device='cuda')
+    slot = torch.zeros((2,), dtype=torch.int64).pin_memory()
+    lib.expand_offsets(0, s, n, boards.data_ptr(), offsets.data_ptr(), scratch.data_ptr(), slot.data_ptr(), 4242)
+    assert lib.wait_sequence(slot.data_ptr() + 8, 4242, 2_000_000)
+    assert int(slot[0]) == int(want[-1])  # visible as soon as the word is (no synchronisation in between)
+    torch.cuda.synchronize()
+    assert np.array_equal(offsets.cpu().numpy(), want - counts.cpu().numpy())
+    assert int(scratch[blocks]) == int(want[-1])
+    lib.expand_offsets(0, s, n, boards.data_ptr(), offsets.data_ptr(), scratch.data_ptr(), None, 0)  # without the host slot
+    torch.cuda.synchronize()
+    assert np.array_equal(offsets.cpu().numpy(), want - counts.cpu().numpy())
+    with pytest.raises(capi.Env2048Error):
+        lib.expand_offsets(0, s, n, boards.data_ptr(), offsets.data_ptr(), None, None, 0)
