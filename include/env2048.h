@@ -628,6 +628,43 @@ ENV2048_EXPORT int env2048_expectimax_backup(int device, void *stream, uint64_t 
                                              uint8_t *best_action);
 
 /*
+ * Boards of any size: S x S cells, 2 <= S <= ENV2048_NXN_MAX_SIZE, ONE BYTE PER CELL (the same log2 code), row-major,
+ * n * S * S bytes per batch, no alignment requirement.  The reference's core functions take boards of any shape and its env
+ * has a `size` argument (twentyfortyeight/envs/twentyfortyeight.py:21; its timing script runs sizes 4, 6 and 8,
+ * tests/test_perf_utils.py:47); these entry points are what the API mirrors call for S != 4.  Same semantics, flags
+ * (AUTO_RESET, RANDOM_ACTIONS only), action coding and RNG contract as the packed 4 x 4 entry points of the same name --
+ * the step word of (seed, env_base + i, step_index) picks the spawn (cell rank over the board's empty cells in row-major
+ * order), a fresh board takes two sequential spawns from the reset block with cell ranks floor(r0 * S*S / 2^32) and
+ * floor(r2 * (S*S - 1) / 2^32) -- so for S = 4 they return exactly what env2048_afterstate / _step / _status / _reset /
+ * _spawn_random / _chance_outcomes return.  A general, loop-based kernel (one board per lane, the board in LDS): a
+ * compatibility path for single boards and small batches, not the throughput path.  Scores are int32: exponents above 30
+ * are outside the domain, as for the packed path.
+ *     env2048_nxn_afterstate     latent_state: slide + merge, no spawn; reward, changed (== can_move(rot90(board, action)))
+ *     env2048_nxn_step           next_state + is_done (+ legal mask of the board written back), in place
+ *     env2048_nxn_status         is_done, legal-action bitmask, number of empty cells, log2(max tile)
+ *     env2048_nxn_reset          zeros + two spawned tiles
+ *     env2048_nxn_spawn_random   fill_cells(number_tile = count): `count` sequential single spawns (steps step_index ...)
+ *     env2048_nxn_chance_outcomes  after_state: out_boards = n x (2 S S) slots of S S bytes, (cell in row-major rank, tile 2
+ *                                then 4); out_count[i] = outcomes (1 = the board itself when it is full); unused slots zero
+ * [replaces: twentyfortyeight/core/gameboard.py:23-129,132-171,247-348, gamemove.py:45-164,
+ *            twentyfortyeight/envs/twentyfortyeight.py:84-133 for size != 4]
+ */
+#define ENV2048_NXN_MAX_SIZE 8
+ENV2048_EXPORT int env2048_nxn_afterstate(int device, void *stream, uint64_t n, uint32_t size, const uint8_t *boards_in, const uint8_t *actions,
+                                          uint8_t *boards_out, int32_t *reward, uint8_t *changed);
+ENV2048_EXPORT int env2048_nxn_step(int device, void *stream, uint64_t n, uint32_t size, uint64_t env_base, uint8_t *boards,
+                                    const uint8_t *actions, int32_t *reward, uint8_t *done, uint8_t *legal, uint64_t seed, uint64_t step_index,
+                                    uint32_t flags);
+ENV2048_EXPORT int env2048_nxn_status(int device, void *stream, uint64_t n, uint32_t size, const uint8_t *boards, uint8_t *done, uint8_t *legal,
+                                      uint8_t *n_empty, uint8_t *max_exp);
+ENV2048_EXPORT int env2048_nxn_reset(int device, void *stream, uint64_t n, uint32_t size, uint64_t env_base, uint8_t *boards, uint8_t *done,
+                                     uint64_t seed, uint64_t step_index);
+ENV2048_EXPORT int env2048_nxn_spawn_random(int device, void *stream, uint64_t n, uint32_t size, uint64_t env_base, uint8_t *boards, uint64_t seed,
+                                            uint64_t step_index, uint32_t count);
+ENV2048_EXPORT int env2048_nxn_chance_outcomes(int device, void *stream, uint64_t n, uint32_t size, const uint8_t *boards, uint8_t *out_boards,
+                                               uint8_t *out_count);
+
+/*
  * Read-only board status; every output may be NULL.
  *     done / legal / obs as in env2048_step;  max_exp[i] = log2(max tile);  n_empty[i] = #zeros
  * [replaces: twentyfortyeight/core/gameboard.py:328-348 is_done;

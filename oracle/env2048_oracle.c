@@ -859,3 +859,283 @@ ORACLE_API int oracle_openmp_enabled(void)
     return 0;
 #endif
 }
+
+/* ==================================================================================== */
+/* Boards of any size S x S, 2 <= S <= 8  [ref: twentyfortyeight/envs/twentyfortyeight.py:21  */
+/* `size`; the reference's core functions are written for any shape and its own timing script */
+/* runs 4 / 6 / 8, tests/test_perf_utils.py:47].  One byte per cell, row-major, exponents.     */
+/* The same restatement as above with the length as a parameter -- and the same RNG contract:  */
+/* the step word of (seed, env, step), two sequential spawns from the reset block.  For S = 4   */
+/* every function here equals its 4x4 counterpart (tests/test_nxn.py).                          */
+/* ==================================================================================== */
+#define NXN_MAX 8
+
+/* [ref: gameboard.py:23-69 merge_column] for a line of `len` cells. */
+ORACLE_API int64_t oracle_nxn_merge_column(const uint8_t *column, int len, uint8_t *out, int *out_len)
+{
+    uint8_t non_zero[NXN_MAX];
+    int n = 0;
+    for (int i = 0; i < len; ++i)
+        if (column[i] != 0) non_zero[n++] = column[i];          /* :46 */
+    int64_t score = 0;
+    int m = 0, i = 0;
+    if (n <= 1) {                                                /* :47-48 */
+        for (i = 0; i < n; ++i) out[i] = non_zero[i];
+        *out_len = n;
+        return 0;
+    }
+    while (i < n - 1) {                                          /* :56 */
+        if (non_zero[i] == non_zero[i + 1]) {                    /* :57 */
+            const uint8_t merged = (uint8_t)(non_zero[i] + 1);
+            out[m++] = merged;
+            score += (int64_t)1 << merged;                       /* :60 */
+            i += 2;
+        } else {
+            out[m++] = non_zero[i];
+            i += 1;
+        }
+    }
+    if (i == n - 1) out[m++] = non_zero[n - 1];                  /* :66-67 */
+    *out_len = m;
+    return score;
+}
+
+/* [ref: gameboard.py:72-102 slide_and_merge] */
+ORACLE_API int64_t oracle_nxn_slide_and_merge(const uint8_t *board, int S, uint8_t *out)
+{
+    int64_t score = 0;
+    memset(out, 0, (size_t)(S * S));
+    for (int r = 0; r < S; ++r) {
+        uint8_t merged[NXN_MAX];
+        int len = 0;
+        score += oracle_nxn_merge_column(board + S * r, S, merged, &len);
+        for (int c = 0; c < len; ++c) out[S * r + c] = merged[c];
+    }
+    return score;
+}
+
+/* numpy.rot90(m, k) for an S x S array. */
+ORACLE_API void oracle_nxn_rot90(const uint8_t *in, int S, int k, uint8_t *out)
+{
+    uint8_t cur[NXN_MAX * NXN_MAX], nxt[NXN_MAX * NXN_MAX];
+    memcpy(cur, in, (size_t)(S * S));
+    k = ((k % 4) + 4) % 4;
+    for (int t = 0; t < k; ++t) {
+        for (int i = 0; i < S; ++i)
+            for (int j = 0; j < S; ++j)
+                nxt[S * i + j] = cur[S * j + (S - 1 - i)];       /* one CCW turn */
+        memcpy(cur, nxt, (size_t)(S * S));
+    }
+    memcpy(out, cur, (size_t)(S * S));
+}
+
+/* [ref: gameboard.py:105-129 latent_state] */
+ORACLE_API int64_t oracle_nxn_latent_state(const uint8_t *board, int S, int action, uint8_t *out)
+{
+    uint8_t rotated[NXN_MAX * NXN_MAX], updated[NXN_MAX * NXN_MAX];
+    oracle_nxn_rot90(board, S, action, rotated);
+    const int64_t reward = oracle_nxn_slide_and_merge(rotated, S, updated);
+    oracle_nxn_rot90(updated, S, -action, out);
+    return reward;
+}
+
+/* [ref: gamemove.py:132-164 can_move] */
+ORACLE_API int oracle_nxn_can_move(const uint8_t *board, int S)
+{
+    for (int r = 0; r < S; ++r)
+        for (int c = 0; c < S - 1; ++c) {
+            const uint8_t left = board[S * r + c], right = board[S * r + c + 1];
+            if (left == 0 && right != 0) return 1;
+            if (left != 0 && left == right) return 1;
+        }
+    return 0;
+}
+
+/* [ref: gamemove.py:45-83 legal_actions_mask] */
+ORACLE_API uint8_t oracle_nxn_legal_actions_mask(const uint8_t *board, int S)
+{
+    int h_merge = 0, v_merge = 0, left = 0, right = 0, up = 0, down = 0;
+    for (int r = 0; r < S; ++r)
+        for (int c = 0; c < S - 1; ++c) {
+            const uint8_t l = board[S * r + c], rr = board[S * r + c + 1];
+            if (l != 0 && l == rr) h_merge = 1;
+            if (l == 0 && rr != 0) left = 1;
+            if (rr == 0 && l != 0) right = 1;
+        }
+    for (int r = 0; r < S - 1; ++r)
+        for (int c = 0; c < S; ++c) {
+            const uint8_t t = board[S * r + c], b = board[S * (r + 1) + c];
+            if (t != 0 && t == b) v_merge = 1;
+            if (t == 0 && b != 0) up = 1;
+            if (b == 0 && t != 0) down = 1;
+        }
+    return (uint8_t)(((left | h_merge) << 0) | ((up | v_merge) << 1) | ((right | h_merge) << 2) | ((down | v_merge) << 3));
+}
+
+/* [ref: gameboard.py:328-348 is_done] */
+ORACLE_API int oracle_nxn_is_done(const uint8_t *board, int S)
+{
+    for (int i = 0; i < S * S; ++i)
+        if (board[i] == 0) return 0;
+    for (int r = 0; r < S - 1; ++r)
+        for (int c = 0; c < S; ++c)
+            if (board[S * r + c] == board[S * (r + 1) + c]) return 0;
+    for (int r = 0; r < S; ++r)
+        for (int c = 0; c < S - 1; ++c)
+            if (board[S * r + c] == board[S * r + c + 1]) return 0;
+    return 1;
+}
+
+static int nxn_count_empty(const uint8_t *board, int S)
+{
+    int n = 0;
+    for (int i = 0; i < S * S; ++i) n += (board[i] == 0);
+    return n;
+}
+
+/* k-th empty cell in argwhere order [ref: gameboard.py:275,287]. */
+ORACLE_API int oracle_nxn_fill_cell_kv(uint8_t *board, int S, int k, uint8_t e)
+{
+    int seen = 0;
+    for (int i = 0; i < S * S; ++i)
+        if (board[i] == 0) {
+            if (seen == k) { board[i] = e; return i; }
+            ++seen;
+        }
+    return -1;
+}
+
+/* Fresh board: two sequential single spawns from ONE reset block, (r0, r1) among the S*S empties, (r2, r3) among the
+ * remaining S*S - 1  [ref: twentyfortyeight.py:100-101]. */
+ORACLE_API void oracle_nxn_reset_board(uint64_t seed, uint64_t env, uint64_t step, int S, uint8_t *board)
+{
+    uint32_t r[4];
+    env_block(seed, env, step, 1u, r);
+    memset(board, 0, (size_t)(S * S));
+    oracle_nxn_fill_cell_kv(board, S, spawn_rank(r[0], S * S), spawn_exponent(r[1]));
+    oracle_nxn_fill_cell_kv(board, S, spawn_rank(r[2], S * S - 1), spawn_exponent(r[3]));
+}
+
+/* [ref: gameboard.py:291-325 next_state + twentyfortyeight.py:132-133] one transition of one board in place. */
+static int64_t nxn_step_one(uint8_t *board, int S, int action, uint64_t seed, uint64_t env, uint64_t step, uint32_t flags,
+                            uint32_t word, int *done_out)
+{
+    uint8_t rotated[NXN_MAX * NXN_MAX];
+    int64_t reward = 0;
+    action &= 3;
+    oracle_nxn_rot90(board, S, action, rotated);                 /* :316 */
+    if (oracle_nxn_can_move(rotated, S)) {                       /* :317 */
+        uint8_t updated[NXN_MAX * NXN_MAX];
+        reward = oracle_nxn_slide_and_merge(rotated, S, updated);
+        oracle_nxn_rot90(updated, S, -action, board);
+        int k, e, unused;
+        oracle_spawn_from_word(word, nxn_count_empty(board, S), &k, &e, &unused);
+        oracle_nxn_fill_cell_kv(board, S, k, (uint8_t)e);        /* :323 */
+    }
+    const int done = oracle_nxn_is_done(board, S);
+    if (done && (flags & FLAG_AUTO_RESET)) oracle_nxn_reset_board(seed, env, step, S, board);
+    *done_out = done;
+    return reward;
+}
+
+ORACLE_API int oracle_nxn_step_batch(uint64_t n, int S, uint64_t env_base, uint8_t *boards, const uint8_t *actions, int32_t *reward,
+                                     uint8_t *done, uint8_t *legal, uint64_t seed, uint64_t step, uint32_t flags)
+{
+    if (S < 2 || S > NXN_MAX) return -1;
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint64_t env = env_base + i;
+        const uint32_t word = step_word(seed, env, step);
+        const int action = (flags & FLAG_RANDOM_ACTIONS) ? (int)(word & 3u) : (int)actions[i];
+        int d = 0;
+        const int64_t r = nxn_step_one(boards + (size_t)S * S * i, S, action, seed, env, step, flags, word, &d);
+        if (reward) reward[i] = (int32_t)r;
+        done[i] = (uint8_t)d;
+        if (legal) legal[i] = oracle_nxn_legal_actions_mask(boards + (size_t)S * S * i, S);
+    }
+    return 0;
+}
+
+ORACLE_API int oracle_nxn_afterstate_batch(uint64_t n, int S, const uint8_t *boards, const uint8_t *actions, uint8_t *out, int32_t *reward,
+                                           uint8_t *changed)
+{
+    if (S < 2 || S > NXN_MAX) return -1;
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint8_t *b = boards + (size_t)S * S * i;
+        uint8_t *o = out + (size_t)S * S * i;
+        const int64_t r = oracle_nxn_latent_state(b, S, actions[i] & 3, o);
+        if (reward) reward[i] = (int32_t)r;
+        if (changed) changed[i] = (uint8_t)(memcmp(b, o, (size_t)(S * S)) != 0);
+    }
+    return 0;
+}
+
+ORACLE_API int oracle_nxn_status_batch(uint64_t n, int S, const uint8_t *boards, uint8_t *done, uint8_t *legal, uint8_t *n_empty,
+                                       uint8_t *max_exp)
+{
+    if (S < 2 || S > NXN_MAX) return -1;
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint8_t *b = boards + (size_t)S * S * i;
+        if (done) done[i] = (uint8_t)oracle_nxn_is_done(b, S);
+        if (legal) legal[i] = oracle_nxn_legal_actions_mask(b, S);
+        if (n_empty) n_empty[i] = (uint8_t)nxn_count_empty(b, S);
+        if (max_exp) {
+            uint8_t m = 0;
+            for (int c = 0; c < S * S; ++c) m = b[c] > m ? b[c] : m;
+            max_exp[i] = m;
+        }
+    }
+    return 0;
+}
+
+ORACLE_API int oracle_nxn_reset_batch(uint64_t n, int S, uint64_t env_base, uint8_t *boards, uint64_t seed, uint64_t step)
+{
+    if (S < 2 || S > NXN_MAX) return -1;
+    for (uint64_t i = 0; i < n; ++i) oracle_nxn_reset_board(seed, env_base + i, step, S, boards + (size_t)S * S * i);
+    return 0;
+}
+
+/* `count` sequential single spawns per board from the step words of (seed, env, step .. step + count - 1)
+ * [ref: gameboard.py:247-288 fill_cells: number_tile tiles on distinct empty cells]. */
+ORACLE_API int oracle_nxn_spawn_random_batch(uint64_t n, int S, uint64_t env_base, uint8_t *boards, uint64_t seed, uint64_t step,
+                                             uint32_t count)
+{
+    if (S < 2 || S > NXN_MAX) return -1;
+    for (uint64_t i = 0; i < n; ++i) {
+        uint8_t *b = boards + (size_t)S * S * i;
+        for (uint32_t t = 0; t < count; ++t) {
+            const int ne = nxn_count_empty(b, S);
+            if (ne == 0) break;
+            int k, e, unused;
+            oracle_spawn_from_word(step_word(seed, env_base + i, step + t), ne, &k, &e, &unused);
+            oracle_nxn_fill_cell_kv(b, S, k, (uint8_t)e);
+        }
+    }
+    return 0;
+}
+
+/* [ref: gameboard.py:132-171 after_state] every (empty cell, value) outcome, cells in argwhere order, value 2 then 4;
+ * out = n x (2 S S) boards, count[i] = number of outcomes (1 = the board itself when it is full). */
+ORACLE_API int oracle_nxn_chance_outcomes(uint64_t n, int S, const uint8_t *boards, uint8_t *out, uint8_t *count)
+{
+    if (S < 2 || S > NXN_MAX) return -1;
+    const size_t cells = (size_t)S * S;
+    memset(out, 0, n * 2 * cells * cells);
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint8_t *b = boards + cells * i;
+        uint8_t *o = out + 2 * cells * cells * i;
+        const int ne = nxn_count_empty(b, S);
+        if (ne == 0) {                                           /* :156-157 */
+            memcpy(o, b, cells);
+            count[i] = 1;
+            continue;
+        }
+        for (int k = 0; k < ne; ++k)
+            for (int e = 1; e <= 2; ++e) {
+                uint8_t *slot = o + cells * (size_t)(2 * k + (e - 1));
+                memcpy(slot, b, cells);
+                oracle_nxn_fill_cell_kv(slot, S, k, (uint8_t)e);
+            }
+        count[i] = (uint8_t)(2 * ne);
+    }
+    return 0;
+}

@@ -22,6 +22,8 @@ Fixture sets:
   transforms.npz        encode_flatten(...,31) one-hot observations and normalize_reward values
   chance_outcomes.npz   after_state(board): every (empty cell, value) outcome in the reference's order + float64 probabilities
   expectimax_d2.npz     depth-2 expectimax (Q2, exact integer terms, best action) composed from latent_state / after_state / can_move
+  nxn.npz               boards of sizes 2, 3, 5, 6, 8: latent_state / can_move / legal mask / is_done / merge_column / after_state and
+                        Philox-driven whole games replayed by the reference's functions (the `size` argument of the env)
   random_play_stats.npz per-game length / total reward / max tile of 3000 uniformly-random games played by the REFERENCE engine
                         with its own NumPy RNG: the distribution the build's Philox-driven play must reproduce
 """
@@ -214,9 +216,9 @@ def ref_spawn(state: np.ndarray, r_cell: int, r_val: int | None = None) -> np.nd
     return new_state
 
 
-def ref_reset(seed: int, env: int, step: int) -> np.ndarray:
+def ref_reset(seed: int, env: int, step: int, size: int = 4) -> np.ndarray:
     r = oracle.env_block(seed, env, step, 1)
-    state = np.zeros((4, 4), dtype=np.int64)
+    state = np.zeros((size, size), dtype=np.int64)
     state = ref_spawn(state, int(r[0]), int(r[1]))
     state = ref_spawn(state, int(r[2]), int(r[3]))
     return state
@@ -424,6 +426,108 @@ def gen_expectimax_d3(count: int = 512):
     return n, int((best == 255).sum()), float(val.max())
 
 
+NXN_SIZES = (2, 3, 5, 6, 8)
+
+
+def gen_nxn():
+    """Boards of other sizes than 4 (the reference's functions take any shape; its env has a `size` argument,
+    twentyfortyeight.py:21, and its timing script runs 4 / 6 / 8): per size S -- states of the reference engine's own random
+    play + random / dense boards -> latent_state x 4 (board, reward), can_move(rot90) x 4, legal_actions_mask, is_done;
+    merge_column on random lines of length S; after_state outcomes of a few boards; and whole games driven by the build's
+    Philox contract through the reference's functions (reset, step with injected spawn, auto-reset), as in trajectories.npz."""
+    rng = np.random.default_rng(2048_8)
+    out = {'sizes': np.array(NXN_SIZES, dtype=np.int32)}
+    total = 0
+    for S in NXN_SIZES:
+        cells = S * S
+        boards = []
+        seed = 77_000 + 1000 * S
+        while len(boards) < 150:  # the reference engine's own random play at this size
+            state = ref_board.fill_cells(state=np.zeros((S, S), dtype=np.int64), number_tile=2, seed=seed)
+            seed += 1
+            for _ in range(400):
+                if rng.random() < 0.1:
+                    boards.append(to_exps(state).reshape(cells))
+                if ref_board.is_done(state):
+                    boards.append(to_exps(state).reshape(cells))
+                    break
+                state, _ = ref_board.next_state(state.copy(), int(rng.integers(0, 4)), seed=seed)
+                seed += 1
+        boards = boards[:150]
+        for _ in range(80):  # uniform small exponents, many empties
+            boards.append(rng.integers(0, 6, size=cells).astype(np.uint8))
+        for _ in range(80):  # dense: few distinct exponents, 0-2 empties (merges everywhere, near-terminal)
+            b = rng.integers(1, 4, size=cells).astype(np.uint8)
+            for _ in range(int(rng.integers(0, 3))):
+                b[int(rng.integers(0, cells))] = 0
+            boards.append(b)
+        checker = (np.indices((S, S)).sum(axis=0) % 2 + 1).astype(np.uint8).reshape(cells)
+        boards += [np.zeros(cells, dtype=np.uint8), checker, np.full(cells, 3, dtype=np.uint8)]
+        boards = np.stack(boards).astype(np.uint8)
+        n = boards.shape[0]
+        after = np.zeros((n, 4, cells), dtype=np.uint8)
+        reward = np.zeros((n, 4), dtype=np.int32)
+        valid = np.zeros((n, 4), dtype=np.uint8)
+        legal = np.zeros(n, dtype=np.uint8)
+        done = np.zeros(n, dtype=np.uint8)
+        for i in range(n):
+            state = to_values(boards[i]).reshape(S, S)
+            for a in range(4):
+                new_state, r = ref_board.latent_state(state, a)
+                after[i, a] = to_exps(new_state).reshape(cells)
+                reward[i, a] = int(r)
+                valid[i, a] = int(ref_move.can_move(np.rot90(state, k=a)))
+            mask = ref_move.legal_actions_mask(state)
+            legal[i] = sum(int(bool(m)) << a for a, m in enumerate(mask))
+            done[i] = int(ref_board.is_done(state))
+        lines = (rng.integers(0, 5, size=(400, S)) * (rng.random((400, S)) < 0.75)).astype(np.uint8)
+        merged = np.zeros((400, S), dtype=np.uint8)
+        merged_len = np.zeros(400, dtype=np.uint8)
+        line_score = np.zeros(400, dtype=np.int32)
+        for i in range(400):
+            sc, m = ref_board.merge_column(to_values(lines[i]))
+            merged[i, :len(m)] = to_exps(np.asarray(m))
+            merged_len[i] = len(m)
+            line_score[i] = int(sc)
+        # after_state outcomes of 12 boards (incl. the full checkerboard): the reference's enumeration order
+        pick = list(range(0, 140, 14)) + [n - 2, n - 3]
+        outcomes = np.zeros((len(pick), 2 * cells, cells), dtype=np.uint8)
+        outcome_count = np.zeros(len(pick), dtype=np.uint8)
+        for j, i in enumerate(pick):
+            res = ref_board.after_state(to_values(boards[i]).reshape(S, S))
+            outcome_count[j] = len(res)
+            for t, (o, _) in enumerate(res):
+                outcomes[j, t] = to_exps(o).reshape(cells)
+        # whole games under the build's Philox contract, replayed by the reference's functions
+        n_env, T, tseed, env_base, step0 = 6, 160, 0x5000 + S, 101 + S, 3
+        t_boards = np.zeros((T + 1, n_env, cells), dtype=np.uint8)
+        t_actions = np.zeros((T, n_env), dtype=np.uint8)
+        t_reward = np.zeros((T, n_env), dtype=np.int32)
+        t_done = np.zeros((T, n_env), dtype=np.uint8)
+        for j in range(n_env):
+            env = env_base + j
+            state = ref_reset(tseed, env, step0, S)
+            t_boards[0, j] = to_exps(state).reshape(cells)
+            for t in range(T):
+                word = oracle.step_word(tseed, env, step0 + 1 + t)
+                action = int(rng.integers(0, 4))
+                state, r = ref_step(state, action, word)
+                finished = bool(ref_board.is_done(state))
+                if finished:  # auto-reset: a fresh board from the reset block of the same (env, step)
+                    state = ref_reset(tseed, env, step0 + 1 + t, S)
+                t_actions[t, j], t_reward[t, j], t_done[t, j] = action, int(r), int(finished)
+                t_boards[t + 1, j] = to_exps(state).reshape(cells)
+        out.update({f's{S}_boards': boards, f's{S}_after': after, f's{S}_reward': reward, f's{S}_valid': valid, f's{S}_legal': legal,
+                    f's{S}_done': done, f's{S}_lines': lines, f's{S}_merged': merged, f's{S}_merged_len': merged_len,
+                    f's{S}_line_score': line_score, f's{S}_outcome_pick': np.array(pick, dtype=np.int32), f's{S}_outcomes': outcomes,
+                    f's{S}_outcome_count': outcome_count, f's{S}_traj_boards': t_boards, f's{S}_traj_actions': t_actions,
+                    f's{S}_traj_reward': t_reward, f's{S}_traj_done': t_done,
+                    f's{S}_traj_meta': np.array([tseed, env_base, step0], dtype=np.int64)})
+        total += n
+    np.savez_compressed(OUT / 'nxn.npz', **out)
+    return total, int(sum(out[f's{S}_traj_done'].sum() for S in NXN_SIZES))
+
+
 def gen_random_play_stats(games: int = 3000):
     """Whole games of the reference engine under uniformly random actions with ITS OWN spawn RNG (seeded per step):
     the bitstream cannot be reproduced, the DISTRIBUTION of game length / score / max tile can -- it pins
@@ -476,6 +580,7 @@ def main():
     print('expectimax_d2', gen_expectimax_d2())
     print('expectimax_d3', gen_expectimax_d3())
     print('random_play_stats', gen_random_play_stats())
+    print('nxn', gen_nxn())
     write_checksums()
 
 

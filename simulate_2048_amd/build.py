@@ -16,7 +16,7 @@ PKG = Path(__file__).resolve().parent
 REPO = PKG.parent
 CSRC = PKG / 'csrc'
 SOURCES = [CSRC / name for name in ('step_kernels.hip', 'rollout_kernels.hip', 'state_i32_kernels.hip', 'search_kernels.hip',
-                                    'transform_kernels.hip')]
+                                    'transform_kernels.hip', 'nxn_kernels.hip')]
 HEADERS = sorted(CSRC.glob('*.hpp')) + [REPO / 'include' / 'env2048.h']
 LIB = PKG / 'lib' / 'libenv2048.so'
 ARCH = 'gfx950'

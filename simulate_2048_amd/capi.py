@@ -67,6 +67,7 @@ EPISODES_REWARD_F32 = 2
 ROLLOUT_STATS_WORDS = 40
 SIGNAL_MAX_ENVS = 512
 INLINE_MAX_ENVS = 64
+NXN_MAX_SIZE = 8
 
 # name -> (restype, argtypes): exactly the prototypes of include/env2048.h
 PROTOTYPES = {
@@ -123,6 +124,12 @@ PROTOTYPES = {
     'env2048_expand': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr, _ptr]),
     'env2048_expectimax_depth2_f64': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr]),
     'env2048_expectimax_backup': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    'env2048_nxn_afterstate': (_c_int, [_c_int, _ptr, _u64, _u32, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    'env2048_nxn_step': (_c_int, [_c_int, _ptr, _u64, _u32, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _u64, _u64, _u32]),
+    'env2048_nxn_status': (_c_int, [_c_int, _ptr, _u64, _u32, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    'env2048_nxn_reset': (_c_int, [_c_int, _ptr, _u64, _u32, _u64, _ptr, _ptr, _u64, _u64]),
+    'env2048_nxn_spawn_random': (_c_int, [_c_int, _ptr, _u64, _u32, _u64, _ptr, _u64, _u64, _u32]),
+    'env2048_nxn_chance_outcomes': (_c_int, [_c_int, _ptr, _u64, _u32, _ptr, _ptr, _ptr]),
     'env2048_status': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
     'env2048_encode_onehot': (_c_int, [_c_int, _ptr, _u64, _ptr, _u32, _ptr]),
     'env2048_pack_i32': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr]),
@@ -362,6 +369,25 @@ class Library:
     def expectimax_ply(self, device, stream, n, boards, succ_boards, succ_prob, succ_status, succ_count, after_reward, legal) -> None:
         self._check(self._dll.env2048_expectimax_ply(device, stream, n, boards, succ_boards, succ_prob, succ_status, succ_count,
                                                      after_reward, legal))
+
+    # -- boards of any size S x S (one byte per cell): the general form behind the mirrors for size != 4 ------------------------
+    def nxn_afterstate(self, device, stream, n, size, boards_in, actions, boards_out, reward, changed) -> None:
+        self._check(self._dll.env2048_nxn_afterstate(device, stream, n, size, boards_in, actions, boards_out, reward, changed))
+
+    def nxn_step(self, device, stream, n, size, env_base, boards, actions, reward, done, legal, seed, step_index, flags) -> None:
+        self._check(self._dll.env2048_nxn_step(device, stream, n, size, env_base, boards, actions, reward, done, legal, seed, step_index, flags))
+
+    def nxn_status(self, device, stream, n, size, boards, done, legal, n_empty, max_exp) -> None:
+        self._check(self._dll.env2048_nxn_status(device, stream, n, size, boards, done, legal, n_empty, max_exp))
+
+    def nxn_reset(self, device, stream, n, size, env_base, boards, done, seed, step_index) -> None:
+        self._check(self._dll.env2048_nxn_reset(device, stream, n, size, env_base, boards, done, seed, step_index))
+
+    def nxn_spawn_random(self, device, stream, n, size, env_base, boards, seed, step_index, count) -> None:
+        self._check(self._dll.env2048_nxn_spawn_random(device, stream, n, size, env_base, boards, seed, step_index, count))
+
+    def nxn_chance_outcomes(self, device, stream, n, size, boards, out_boards, out_count) -> None:
+        self._check(self._dll.env2048_nxn_chance_outcomes(device, stream, n, size, boards, out_boards, out_count))
 
     def encode_onehot(self, device, stream, n, boards, width, out) -> None:
         self._check(self._dll.env2048_encode_onehot(device, stream, n, boards, width, out))

@@ -47,6 +47,8 @@ class ScalarOps:
         self._ptr_legal = self._flags_ptr + 1
         self._ptr_changed = self._flags_ptr + 2
         self._ptr_count = self._flags_ptr + 3
+        # boards of other sizes than 4 x 4 (one byte per cell, up to 8 x 8): created on first use
+        self._nxn = None
 
     # -- host-side value <-> exponent conversion (same mapping as env2048_pack_i64 / unpack_i64) -----
     def load(self, values) -> None:
@@ -109,6 +111,81 @@ class ScalarOps:
         self._sync()
         count = int(self.flags[3])
         return self.values(self.outcomes[:count], dtype), count
+
+
+    # -- boards of any size S x S, 2 <= S <= 8 (env2048_nxn_*): the same five operations, one byte per cell ------------------------
+    def _nxn_buffers(self):
+        if self._nxn is None:
+            pin = self.rt.device.type == 'cuda'
+
+            def buf(shape, dtype):
+                t = torch.zeros(shape, dtype=dtype, pin_memory=pin)
+                return t, t.numpy(), t.data_ptr()
+
+            self._nxn = {'board': buf((64,), torch.uint8), 'out': buf((64,), torch.uint8), 'outcomes': buf((128 * 64,), torch.uint8)}
+        return self._nxn
+
+    @staticmethod
+    def _size_of(values) -> int:
+        arr = np.asarray(values)
+        if arr.ndim != 2 or arr.shape[0] != arr.shape[1] or not 2 <= arr.shape[0] <= capi.NXN_MAX_SIZE:
+            raise ValueError(f'board: the MI355X engine handles square boards of size 2 ... {capi.NXN_MAX_SIZE}, got shape {arr.shape}')
+        return int(arr.shape[0])
+
+    def _load_nxn(self, values) -> int:
+        size = self._size_of(values)
+        board = self._nxn_buffers()['board'][1]
+        for i, v in enumerate(np.asarray(values).reshape(-1).tolist()):
+            board[i] = (int(v).bit_length() - 1) & 0xFF if v > 0 else 0
+        return size
+
+    @staticmethod
+    def values_nxn(packed: np.ndarray, size: int, dtype) -> np.ndarray:
+        e = packed[..., :size * size].astype(np.int64)
+        return np.where(e > 0, np.left_shift(np.int64(1), e), 0).astype(dtype, copy=False).reshape(e.shape[:-1] + (size, size))
+
+    def afterstate_nxn(self, values, action: int, dtype):
+        size = self._load_nxn(values)
+        nb = self._nxn_buffers()
+        self.action[0] = action & 3
+        dev, stream = self.rt.handles()
+        self.rt.lib.nxn_afterstate(dev, stream, 1, size, nb['board'][2], self._action, nb['out'][2], self._reward, self._ptr_changed)
+        self._sync()
+        return self.values_nxn(nb['out'][1], size, dtype), int(self.reward[0]), bool(self.flags[2])
+
+    def step_nxn(self, values, action: int, seed: int, step_index: int, dtype):
+        size = self._load_nxn(values)
+        nb = self._nxn_buffers()
+        self.action[0] = action & 3
+        dev, stream = self.rt.handles()
+        self.rt.lib.nxn_step(dev, stream, 1, size, 0, nb['board'][2], self._action, self._reward, self._ptr_done, None, seed, step_index, 0)
+        self._sync()
+        return self.values_nxn(nb['board'][1], size, dtype), int(self.reward[0]), bool(self.flags[0])
+
+    def status_nxn(self, values):
+        size = self._load_nxn(values)
+        dev, stream = self.rt.handles()
+        self.rt.lib.nxn_status(dev, stream, 1, size, self._nxn_buffers()['board'][2], self._ptr_done, self._ptr_legal, None, None)
+        self._sync()
+        return bool(self.flags[0]), int(self.flags[1])
+
+    def spawn_random_nxn(self, values, seed: int, step_index: int, count: int, dtype) -> np.ndarray:
+        size = self._load_nxn(values)
+        nb = self._nxn_buffers()
+        dev, stream = self.rt.handles()
+        self.rt.lib.nxn_spawn_random(dev, stream, 1, size, 0, nb['board'][2], seed, step_index, count)
+        self._sync()
+        return self.values_nxn(nb['board'][1], size, dtype)
+
+    def chance_outcomes_nxn(self, values, dtype):
+        size = self._load_nxn(values)
+        nb = self._nxn_buffers()
+        dev, stream = self.rt.handles()
+        self.rt.lib.nxn_chance_outcomes(dev, stream, 1, size, nb['board'][2], nb['outcomes'][2], self._ptr_count)
+        self._sync()
+        count = int(self.flags[3])
+        cells = size * size
+        return self.values_nxn(nb['outcomes'][1][:2 * cells * cells].reshape(2 * cells, cells)[:count], size, dtype), count
 
 
 _per_thread = threading.local()

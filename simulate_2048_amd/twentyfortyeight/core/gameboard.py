@@ -3,8 +3,10 @@ Core 2048 board functions.  Mirror of ``twentyfortyeight/core/gameboard.py``: sa
 meaning, return shapes/dtypes and error behaviour; the arithmetic runs in the HIP kernels
 (afterstate / spawn / status / step) through the C-ABI.  Reference lines are cited per function.
 
-Differences that cannot be avoided: boards must be 4x4; the random stream is
-Philox (``seed`` selects a reproducible stream, ``None`` an OS-entropy one) instead of NumPy PCG64.
+Boards: 4 x 4 takes the packed kernels; any other square size from 2 to 8 takes the general kernels (``env2048_nxn_*``: the
+reference's functions take any shape, its env has a ``size`` argument, its timing script runs 4 / 6 / 8).  The one difference that
+cannot be avoided: the random stream is Philox (``seed`` selects a reproducible stream, ``None`` an
+OS-entropy one) instead of NumPy PCG64.
 """
 
 from __future__ import annotations
@@ -13,7 +15,7 @@ import numpy as np
 from numpy import argwhere, ndarray
 
 from ... import scalar
-from ._device import require_4x4, rng_for
+from ._device import MAX_SIZE, is_4x4, rng_for
 
 # ##>: Tile spawn probabilities (90% for 2, 10% for 4) [ref gameboard.py:13].
 TILE_SPAWN_PROBS: dict[int, float] = {2: 0.9, 4: 0.1}
@@ -25,11 +27,13 @@ def merge_column(column: ndarray) -> tuple[int, ndarray]:
     Returns (score, merged column WITHOUT padding) like the reference.
     """
     column = np.asarray(column)
-    if column.ndim != 1 or column.shape[0] != 4:
-        raise ValueError(f'merge_column: the MI355X engine handles columns of length 4, got shape {column.shape}')
-    board = np.zeros((4, 4), dtype=np.int64)
+    if column.ndim != 1 or not 2 <= column.shape[0] <= MAX_SIZE:
+        raise ValueError(f'merge_column: the MI355X engine handles columns of length 2 ... {MAX_SIZE}, got shape {column.shape}')
+    size = column.shape[0]
+    board = np.zeros((size, size), dtype=np.int64)
     board[0] = column
-    after, reward, _ = scalar.current().afterstate(board, 0, column.dtype)
+    ops = scalar.current()
+    after, reward, _ = ops.afterstate(board, 0, column.dtype) if size == 4 else ops.afterstate_nxn(board, 0, column.dtype)
     row = after[0]
     return reward, row[row != 0]
 
@@ -37,16 +41,16 @@ def merge_column(column: ndarray) -> tuple[int, ndarray]:
 def slide_and_merge(board: ndarray) -> tuple[float, ndarray]:
     """[ref gameboard.py:72-102] slide every row left and merge; score is a float like the reference."""
     board = np.asarray(board)
-    require_4x4(board, 'board')
-    after, reward, _ = scalar.current().afterstate(board, 0, board.dtype)
+    ops = scalar.current()
+    after, reward, _ = ops.afterstate(board, 0, board.dtype) if is_4x4(board, 'board') else ops.afterstate_nxn(board, 0, board.dtype)
     return 0.0 + float(reward), after
 
 
 def latent_state(state: ndarray, action: int) -> tuple[ndarray, float]:
     """[ref gameboard.py:105-129] afterstate of `action` (0 left, 1 up, 2 right, 3 down), no new tile."""
     state = np.asarray(state)
-    require_4x4(state, 'board')
-    after, reward, _ = scalar.current().afterstate(state, int(action), state.dtype)
+    ops = scalar.current()
+    after, reward, _ = (ops.afterstate if is_4x4(state, 'board') else ops.afterstate_nxn)(state, int(action), state.dtype)
     return after, 0.0 + float(reward)
 
 
@@ -57,8 +61,8 @@ def after_state(state: ndarray) -> list[tuple[ndarray, float]]:
     num_empty_cells = int((state == 0).sum())
     if num_empty_cells == 0:
         return [(state, 1.0)]
-    require_4x4(state, 'board')
-    values, count = scalar.current().chance_outcomes(state, state.dtype)
+    ops = scalar.current()
+    values, count = (ops.chance_outcomes if is_4x4(state, 'board') else ops.chance_outcomes_nxn)(state, state.dtype)
     # ##>: probabilities in float64 exactly as the reference computes them (TILE_SPAWN_PROBS[v] / n)
     return [(values[i], TILE_SPAWN_PROBS[2 if i % 2 == 0 else 4] / num_empty_cells) for i in range(count)]
 
@@ -85,9 +89,10 @@ def fill_cells(state: ndarray, number_tile: int, seed: int | None = None) -> nda
     if num_available == 0:
         return state
     number_tile = min(int(number_tile), num_available)
-    require_4x4(np.asarray(state), 'board')
+    ops = scalar.current()
+    spawn = ops.spawn_random if is_4x4(np.asarray(state), 'board') else ops.spawn_random_nxn
     stream_seed, step = rng_for(seed, number_tile)
-    state[...] = scalar.current().spawn_random(state, stream_seed, step, number_tile, state.dtype)
+    state[...] = spawn(state, stream_seed, step, number_tile, state.dtype)
     return state
 
 
@@ -105,13 +110,14 @@ def next_state(state: ndarray, action: int, seed: int | None = None) -> tuple[nd
 def _transition(state: ndarray, action: int, seed: int | None):
     """One launch of the step kernel on one board: (new values, reward int, done bool)."""
     arr = np.asarray(state)
-    require_4x4(arr, 'board')
+    ops = scalar.current()
+    step_fn = ops.step if is_4x4(arr, 'board') else ops.step_nxn
     stream_seed, step = rng_for(seed)
-    return scalar.current().step(arr, int(action), stream_seed, step, arr.dtype)
+    return step_fn(arr, int(action), stream_seed, step, arr.dtype)
 
 
 def is_done(state: ndarray) -> bool:
     """[ref gameboard.py:328-348] no empty cell and no equal horizontal / vertical neighbours."""
     state = np.asarray(state)
-    require_4x4(state, 'board')
-    return scalar.current().status(state)[0]
+    ops = scalar.current()
+    return (ops.status if is_4x4(state, 'board') else ops.status_nxn)(state)[0]

@@ -8,13 +8,13 @@ from __future__ import annotations
 from numpy import asarray, ndarray, rot90
 
 from ... import scalar
-from ._device import require_4x4
+from ._device import is_4x4
 
 
 def _legal_bits(state: ndarray) -> int:
     state = asarray(state)
-    require_4x4(state, 'board')
-    return scalar.current().status(state)[1]
+    ops = scalar.current()
+    return (ops.status if is_4x4(state, 'board') else ops.status_nxn)(state)[1]
 
 
 def _can_move_direction(board: ndarray, direction: int) -> bool:

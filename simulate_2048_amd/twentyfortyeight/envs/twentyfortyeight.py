@@ -2,7 +2,8 @@
 Single-board environment object with the public surface of the reference's
 ``twentyfortyeight/envs/twentyfortyeight.py`` (class ``TwentyFortyEight``), backed by the HIP kernels.
 
-Surface kept (reference lines in brackets): constructor flags ``size / encoded / normalize`` [:21],
+Surface kept (reference lines in brackets): constructor flags ``size / encoded / normalize`` [:21] (size 4: the packed
+kernels; 2 ... 8: the general ``env2048_nxn_*`` kernels),
 ``ACTIONS`` [:19], ``reset(seed)`` [:84-104], ``step(action)`` [:106-133], the properties
 ``observation`` [:56-68], ``reward`` [:70-82], ``is_finished`` [:44-54], ``render()`` [:135-140] and the
 two attributes callers are known to poke, ``_current_state`` (int64 4x4 values) and
@@ -23,12 +24,12 @@ class TwentyFortyEight:
     ACTIONS = {'left': 0, 'up': 1, 'right': 2, 'down': 3}
 
     def __init__(self, size: int = 4, encoded: bool = False, normalize: bool = False):
-        if size != 4:
-            raise ValueError(f'TwentyFortyEight: the MI355X engine supports size=4 only, got size={size}')
-        self.size = size
+        if not isinstance(size, (int, np.integer)) or not 2 <= size <= 8:
+            raise ValueError(f'TwentyFortyEight: the MI355X engine supports size = 2 ... 8, got size={size}')
+        self.size = int(size)
         self._encoded = bool(encoded)
         self._normalize = bool(normalize)
-        self._current_state = np.zeros((4, 4), dtype=np.int64)
+        self._current_state = np.zeros((self.size, self.size), dtype=np.int64)
         self._current_reward = 0.0
         self.reset()
 

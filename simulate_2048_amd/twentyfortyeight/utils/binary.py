@@ -11,11 +11,12 @@ from ... import ops
 def encode(state: ndarray, encodage_size: int) -> ndarray:
     """[ref binary.py:11-50] eye(encodage_size)[log2(state)] (0 stays index 0): shape (state.size, size)."""
     flat = np.asarray(state).reshape(-1).astype(np.int64)
-    if flat.size % 16:
-        raise ValueError(f'encode: the MI355X engine encodes whole 4x4 boards (16 cells), got {flat.size} cells')
+    cells = flat.size
+    if cells % 16:  # the kernel encodes 16 cells per record: pad (boards of other sizes than 4 x 4), trim below
+        flat = np.concatenate([flat, np.zeros(-cells % 16, dtype=np.int64)])
     packed = ops.pack(flat.reshape(-1, 16))
     out = ops.onehot(packed, int(encodage_size)).cpu().numpy()
-    return out.reshape(flat.size, int(encodage_size)).astype(int64)
+    return out.reshape(flat.size, int(encodage_size))[:cells].astype(int64)
 
 
 def encode_flatten(state: ndarray, encodage_size: int) -> ndarray:

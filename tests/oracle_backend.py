@@ -14,6 +14,7 @@ import ctypes
 import numpy as np
 
 import oracle
+from oracle import nxn as nxn_oracle
 
 
 def _view(ptr, count, dtype):
@@ -269,6 +270,54 @@ class OracleLibrary:
             _view(reward, n, np.int32)[:] = res['reward']
         if changed is not None:
             _view(changed, n, np.uint8)[:] = res['changed']
+
+    # -- boards of any size (env2048_nxn_*) ------------------------------------------------------------------------------------
+    def nxn_afterstate(self, device, stream, n, size, boards_in, actions, boards_out, reward, changed):
+        self.calls.append(('nxn_afterstate', n))
+        cells = size * size
+        res = nxn_oracle.afterstate_batch(_view(boards_in, n * cells, np.uint8).copy(), size, _view(actions, n, np.uint8).copy())
+        _view(boards_out, n * cells, np.uint8)[:] = res['boards'].reshape(-1)
+        if reward is not None:
+            _view(reward, n, np.int32)[:] = res['reward']
+        if changed is not None:
+            _view(changed, n, np.uint8)[:] = res['changed']
+
+    def nxn_step(self, device, stream, n, size, env_base, boards, actions, reward, done, legal, seed, step_index, flags):
+        self.calls.append(('nxn_step', n))
+        b = _view(boards, n * size * size, np.uint8)
+        res = nxn_oracle.step_batch(b.copy(), size, None if actions is None else _view(actions, n, np.uint8).copy(), seed, step_index,
+                                    env_base=env_base, flags=flags, want_legal=legal is not None)
+        b[:] = res['boards'].reshape(-1)
+        if reward is not None:
+            _view(reward, n, np.int32)[:] = res['reward']
+        _view(done, n, np.uint8)[:] = res['done']
+        if legal is not None:
+            _view(legal, n, np.uint8)[:] = res['legal']
+
+    def nxn_status(self, device, stream, n, size, boards, done, legal, n_empty, max_exp):
+        self.calls.append(('nxn_status', n))
+        res = nxn_oracle.status_batch(_view(boards, n * size * size, np.uint8).copy(), size)
+        for ptr, key in ((done, 'done'), (legal, 'legal'), (n_empty, 'n_empty'), (max_exp, 'max_exp')):
+            if ptr is not None:
+                _view(ptr, n, np.uint8)[:] = res[key]
+
+    def nxn_reset(self, device, stream, n, size, env_base, boards, done, seed, step_index):
+        self.calls.append(('nxn_reset', n))
+        _view(boards, n * size * size, np.uint8)[:] = nxn_oracle.reset_batch(n, size, seed, step_index, env_base=env_base).reshape(-1)
+        if done is not None:
+            _view(done, n, np.uint8)[:] = 0
+
+    def nxn_spawn_random(self, device, stream, n, size, env_base, boards, seed, step_index, count):
+        self.calls.append(('nxn_spawn_random', n))
+        b = _view(boards, n * size * size, np.uint8)
+        b[:] = nxn_oracle.spawn_random_batch(b.copy(), size, seed, step_index, count, env_base=env_base).reshape(-1)
+
+    def nxn_chance_outcomes(self, device, stream, n, size, boards, out_boards, out_count):
+        self.calls.append(('nxn_chance_outcomes', n))
+        cells = size * size
+        out, count = nxn_oracle.chance_outcomes(_view(boards, n * cells, np.uint8).copy(), size)
+        _view(out_boards, n * 2 * cells * cells, np.uint8)[:] = out.reshape(-1)
+        _view(out_count, n, np.uint8)[:] = count
 
     def afterstates4(self, device, stream, n, boards, out_boards, out_reward, out_legal):
         self.calls.append(('afterstates4', n))

@@ -165,12 +165,15 @@ def test_fill_cells_mutates_in_place():
 
 
 def test_unsupported_sizes_raise():
+    """Sizes 2 ... 8 are served (tests/test_nxn.py); beyond that, and non-square boards, are refused loudly."""
     with pytest.raises(ValueError):
-        TwentyFortyEight(size=6)
+        TwentyFortyEight(size=9)
     with pytest.raises(ValueError):
-        slide_and_merge(np.zeros((6, 6), dtype=np.int64))
+        slide_and_merge(np.zeros((9, 9), dtype=np.int64))
     with pytest.raises(ValueError):
-        merge_column(np.array([2, 2, 2]))
+        slide_and_merge(np.zeros((4, 6), dtype=np.int64))
+    with pytest.raises(ValueError):
+        merge_column(np.array([2] * 9))
 
 
 # ------------------------------------------------------------------ the env class
