@@ -375,6 +375,11 @@ ENV2048_EXPORT int env2048_step_state_i32_keyed_signalled(int device, void *stre
                                                           int32_t *max_tile, float *obs, uint8_t *legal4, int64_t host_mirror_delta,
                                                           uint64_t *host_sequence, uint64_t sequence_value);
 ENV2048_EXPORT int env2048_wait_sequence(const uint64_t *host_sequence, uint64_t value, uint32_t timeout_us);
+/* The same completion word for ANY work: the device stores `value` into the pinned host word once everything enqueued on
+ * `stream` before this call has completed (one stream memory operation, no kernel); poll it with env2048_wait_sequence.
+ * What the single-board API mirrors do instead of synchronising the stream after their one launch
+ * (twentyfortyeight/envs/twentyfortyeight.py:106-133 step, twentyfortyeight/core/gameboard.py, gamemove.py). */
+ENV2048_EXPORT int env2048_stream_signal(int device, void *stream, uint64_t *host_word, uint64_t value);
 
 /*
  * env2048_step_state_i32_keyed_signalled for at most ENV2048_INLINE_MAX_ENVS environments with the per-move INPUTS TAKEN FROM

@@ -103,6 +103,7 @@ PROTOTYPES = {
     'env2048_step_state_i32_keyed_signalled': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
                                                          _ptr, _ptr, _ptr, _ptr, ctypes.c_int64, _ptr, _u64]),
     'env2048_wait_sequence': (_c_int, [_ptr, _u64, _u32]),
+    'env2048_stream_signal': (_c_int, [_c_int, _ptr, _ptr, _u64]),
     'env2048_step_state_i32_keyed_inline': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
                                                       _ptr, _ptr, _ptr, _ptr, ctypes.c_int64, _ptr, _u64]),
     'env2048_status_i32': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr]),
@@ -297,6 +298,9 @@ class Library:
                                                                   step_count_in, step_count_out, done_in, done_out, total_in, total_out,
                                                                   reward, max_tile, obs, legal4, host_mirror_delta, host_sequence,
                                                                   sequence_value))
+
+    def stream_signal(self, device, stream, host_word, value) -> None:
+        self._check(self._dll.env2048_stream_signal(device, stream, host_word, value))
 
     def wait_sequence(self, host_sequence, value, timeout_us) -> bool:
         """Poll the completion word of a *_signalled launch: True once it holds ``value``, False after ``timeout_us``."""

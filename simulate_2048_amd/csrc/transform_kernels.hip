@@ -160,6 +160,17 @@ int env2048_abi_version(void) { return ENV2048_ABI_VERSION; }
 
 const char *env2048_last_error(void) { return g_error; }
 
+// A completion word for ANY work on a stream: hipStreamWriteValue64 makes the device store `value` into the caller's pinned host
+// word once everything enqueued on `stream` before this call has completed; env2048_wait_sequence polls it.
+int env2048_stream_signal(int device, void *stream, uint64_t *host_word, uint64_t value)
+{
+    if (!host_word || misaligned(host_word, 8)) return fail(ENV2048_ERR_INVALID_ARG, "env2048_stream_signal: host_word is NULL or misaligned");
+    DeviceScope scope(device);
+    if (scope.rc) return scope.rc;
+    const hipError_t e = hipStreamWriteValue64((hipStream_t)stream, host_word, value, 0);
+    return e == hipSuccess ? ENV2048_OK : hip_fail(e, "env2048_stream_signal: hipStreamWriteValue64");
+}
+
 int env2048_device_count(void)
 {
     hipError_t e = hipSuccess;

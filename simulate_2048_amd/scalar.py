@@ -49,6 +49,10 @@ class ScalarOps:
         self._ptr_count = self._flags_ptr + 3
         # boards of other sizes than 4 x 4 (one byte per cell, up to 8 x 8): created on first use
         self._nxn = None
+        # completion word of this thread's calls (see _sync)
+        self._word_t, self._word, self._word_ptr = buf((2,), torch.int64)
+        self._serial = 0
+        self._signal_ok = pin
 
     # -- host-side value <-> exponent conversion (same mapping as env2048_pack_i64 / unpack_i64) -----
     def load(self, values) -> None:
@@ -65,8 +69,23 @@ class ScalarOps:
         return np.where(e > 0, np.left_shift(np.int64(1), e), 0).astype(dtype, copy=False).reshape(packed.shape[:-1] + (4, 4))
 
     def _sync(self) -> None:
-        if self.rt.device.type == 'cuda':
-            torch.cuda.current_stream(self.rt.device).synchronize()
+        """Wait for the call's one launch.  A stream synchronisation is an interrupt-driven wake-up (11-12 us around a 4 us
+        kernel); instead the device is asked to store a serial into a pinned host word once the stream has drained
+        (env2048_stream_signal: one stream memory operation) and the host polls that word (launch + signal + wait 12.7 us
+        against 16.3 us, profiles/r04_i_move_latency_breakdown.json).  Falls back to synchronising when the word does not
+        show up within 200 us, and for good when the stream operation is not available."""
+        if self.rt.device.type != 'cuda':
+            return
+        if self._signal_ok:
+            try:
+                self._serial += 1
+                dev, stream = self.rt.handles()
+                self.rt.lib.stream_signal(dev, stream, self._word_ptr, self._serial)
+                if self.rt.lib.wait_sequence(self._word_ptr, self._serial, 200):
+                    return
+            except (capi.Env2048Error, AttributeError):
+                self._signal_ok = False
+        torch.cuda.current_stream(self.rt.device).synchronize()
 
     # -- operations ----------------------------------------------------------------------------------
     def afterstate(self, values, action: int, dtype):

@@ -62,7 +62,10 @@ def main():
             t1 = time.perf_counter()
             ok = lib.wait_sequence(b.seq_ptr, serial, 1000)
             t2 = time.perf_counter()
-            assert ok
+            if not ok:
+                torch.cuda.synchronize()
+                word = int(b.mirror.numpy()[-16:-8].view(np.uint64)[0])
+                raise AssertionError(f'{label} rep {r}: completion word {word:#x}, expected {serial:#x} (after a synchronize)')
             lat.append((t1 - t0, t2 - t1))
         lat = np.array(lat[reps // 10:]) * 1e6
         out[f'launch_call_us_{label}'] = float(np.median(lat[:, 0]))
@@ -78,6 +81,22 @@ def main():
         s.synchronize()
         lat.append(time.perf_counter() - t1)
     out['stream_synchronize_after_launch_us'] = float(np.median(lat) * 1e6)
+    # 3b. a generic completion word: any launch + env2048_stream_signal (hipStreamWriteValue64) + poll
+    word = torch.zeros((2,), dtype=torch.int64).pin_memory()
+    lat = []
+    ok_all = True
+    for r in range(reps):
+        serial += 1
+        t0 = time.perf_counter()
+        launch(a, b, 0, kp, ap) if False else lib.step_state_i32_keyed_mirrored(dev, stream, n, kp, a.ptr['board'], b.ptr['board'], ap, a.ptr['step_count'], b.ptr['step_count'], a.ptr['done'], b.ptr['done'], a.ptr['total'], b.ptr['total'], b.ptr['reward'], b.ptr['max_tile'], b.ptr['obs'], b.ptr['legal'], b.mirror_delta)
+        t1 = time.perf_counter()
+        lib.stream_signal(dev, stream, word.data_ptr(), serial)
+        t2 = time.perf_counter()
+        ok_all &= lib.wait_sequence(word.data_ptr(), serial, 2000)
+        lat.append((t1 - t0, t2 - t1, time.perf_counter() - t2))
+    lat = np.array(lat[reps // 10:]) * 1e6
+    out['generic_signal'] = {'launch_call_us': float(np.median(lat[:, 0])), 'stream_signal_call_us': float(np.median(lat[:, 1])),
+                             'wait_us': float(np.median(lat[:, 2])), 'all_seen': bool(ok_all)}
     # 4. an empty ctypes call / the wait call alone
     t0 = time.perf_counter()
     for r in range(reps):
