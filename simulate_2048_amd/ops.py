@@ -165,15 +165,21 @@ def expectimax_depth2(boards: torch.Tensor, *, want_terms: bool = False, rt=None
 _slots = threading.local()
 
 
-def _total_slot(rt):
-    """This thread's two-word host slot for env2048_expand_offsets (total, completion word) -- pinned on a HIP runtime -- and
-    the next completion value to use with it."""
-    entry = getattr(_slots, 'entry', None)
-    if entry is None or entry[0] != rt.device:
+def _total_slot(rt, stream):
+    """The calling thread's two-word host slot for env2048_expand_offsets on `stream` (total, completion word) -- pinned on a HIP
+    runtime -- and the next completion value to use with it.  One slot per (device, stream): calls on one stream are ordered,
+    so a slot is never written by two launches whose order is unknown."""
+    table = getattr(_slots, 'table', None)
+    if table is None:
+        table = _slots.table = {}
+    key = (rt.device, stream)
+    entry = table.get(key)
+    if entry is None:
+        # (never freed: a launch may still be writing a slot, and 16 bytes per stream a thread ever used is nothing)
         slot = torch.zeros((2,), dtype=torch.int64)
         if rt.device.type == 'cuda':
             slot = slot.pin_memory()
-        entry = _slots.entry = [rt.device, slot, slot.numpy(), slot.data_ptr(), 0]
+        entry = table[key] = [rt.device, slot, slot.numpy(), slot.data_ptr(), 0]
     entry[4] += 1
     return entry
 
@@ -192,7 +198,7 @@ def expand(boards: torch.Tensor, rt=None) -> dict:
     dev, stream = rt.handles()
     offsets = torch.empty((n,), dtype=torch.int64, device=rt.device)
     scratch = torch.empty(((n + 511) // 512 + 1,), dtype=torch.int64, device=rt.device)
-    _, slot, words, address, serial = _total_slot(rt)
+    _, slot, words, address, serial = _total_slot(rt, stream)
     rt.lib.expand_offsets(dev, stream, n, _p(boards), _p(offsets), _p(scratch), address, serial)
     out = {'offsets': offsets, 'reward': torch.empty((n, 4), dtype=torch.int32, device=rt.device),
            'n_empty': torch.empty((n, 4), dtype=torch.uint8, device=rt.device)}  # (allocated while the device counts)
