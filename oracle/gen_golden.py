@@ -402,6 +402,45 @@ def _ref_q3(exps):
     return q, 255, 0.0
 
 
+def _ref_q(exps, depth):
+    """(q (4,), best, value) of one board at `depth` by the same recursion."""
+    state = to_values(exps).reshape(4, 4)
+    q = np.full(4, -np.inf, dtype=np.float64)
+    for a in range(4):
+        if _ref_legal(state, a):
+            after, r = ref_board.latent_state(state, a)
+            q[a] = float(r) + sum(pr * _ref_value(o, depth - 1) for o, pr in ref_board.after_state(after))
+    if np.isfinite(q).any():
+        best = int(np.argmax(q))
+        return q, best, q[best]
+    return q, 255, 0.0
+
+
+def _ref_q4(exps):
+    return _ref_q(exps, 4)
+
+
+def gen_expectimax_d4(count: int = 24):
+    """Depth FOUR by the same literal recursion over the reference's functions, on the boards of the chance_outcomes set with the
+    fewest empty cells (1 ... 4: a depth-4 tree of a mid-game board has 10^6 leaves and would take minutes per board in Python;
+    these take seconds) -- pins the oracle's recursion, and through it the device's expand -> depth-2 -> back-up chain, one
+    level deeper than expectimax_d3.npz."""
+    import multiprocessing as mp
+    import os
+
+    boards = np.load(OUT / 'chance_outcomes.npz')['boards']
+    empties = (boards == 0).sum(axis=1)
+    pick = [int(i) for e in (1, 2, 3, 4) for i in np.flatnonzero(empties == e)[:count // 4]]  # six boards per number of empty cells
+    boards = boards[pick]
+    with mp.get_context('fork').Pool(min(8, os.cpu_count() or 1)) as pool:
+        results = pool.map(_ref_q4, [boards[i] for i in range(boards.shape[0])], chunksize=1)
+    q = np.stack([r[0] for r in results]).astype(np.float64)
+    best = np.array([r[1] for r in results], dtype=np.uint8)
+    val = np.array([r[2] for r in results], dtype=np.float64)
+    np.savez_compressed(OUT / 'expectimax_d4.npz', boards=boards, q=q, best=best, value=val)
+    return boards.shape[0], int((best == 255).sum()), float(val.max())
+
+
 def gen_expectimax_d3(count: int = 512):
     """Depth-3 expectimax composed LITERALLY from the reference's functions (latent_state, after_state with ITS probabilities,
     can_move), by plain recursion, float64, outcomes in after_state's order: Q3(s, a) = r + sum P(o) * V2(o),
@@ -579,6 +618,7 @@ def main():
     print('chance_outcomes', gen_chance_outcomes())
     print('expectimax_d2', gen_expectimax_d2())
     print('expectimax_d3', gen_expectimax_d3())
+    print('expectimax_d4', gen_expectimax_d4())
     print('random_play_stats', gen_random_play_stats())
     print('nxn', gen_nxn())
     write_checksums()
