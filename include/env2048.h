@@ -615,6 +615,7 @@ ENV2048_EXPORT int env2048_expectimax_depth2(int device, void *stream, uint64_t 
  *                          (sum of counts) x 16 bytes, plus per (board, action) the merge score reward[4i + a] (0 if illegal) and
  *                          n_empty[4i + a] = empty cells of the afterstate (0 = illegal action; a legal move always leaves one).
  *                          The children of (i, a) start at offsets[i] + 2 * (n_empty of the actions before a), cell k at + 2k.
+ *                          (reward must be 16-byte, n_empty 4-byte aligned: a board's four entries are stored as one word.)
  *   env2048_expectimax_depth2_f64   V_2 of every board as float64 (the deepest frontier's values).
  *   env2048_expectimax_backup       folds child values into the values of a level: value[i] = V (float64), optionally q (n x 4
  *                          float64, -inf for an illegal action) and best_action (255: terminal).  Sums run in child order and

@@ -569,70 +569,166 @@ __global__ __launch_bounds__(BLOCK) void add_block_base_kernel(uint64_t n, uint6
     if (i < n) offsets[i] += block_base[blockIdx.x];
 }
 
-__global__ __launch_bounds__(BLOCK) void expand_kernel(uint64_t n, const uint8_t *boards, const uint64_t *offsets, uint8_t *children,
-                                                       int32_t *reward, uint8_t *n_empty)
+// Children of a level, written the way a wave writes best: CONSECUTIVE lanes produce CONSECUTIVE children.  Phase 1, one
+// board per lane: the four afterstates and their empty-cell masks into a wave-private LDS strip, reward / n_empty out.  Phase 2,
+// 64 children per iteration (the dense numbering of the depth-2 kernel: every (board, action) entry that STARTS in the chunk
+// drops its number at its first position, a DPP max-scan spreads it): lane l builds child w0 + l of the wave -- k-th empty cell
+// of its entry's afterstate, tile 2 or 4 -- and stores its 16 bytes at the entry's global start + its rank there, so a store
+// instruction of the wave writes 1 KiB contiguous (round 3: one lane walked the children of one board: 16-byte stores 544 B
+// apart).  The global start of an entry comes from the caller's `offsets`, so any (even non-contiguous) offsets are honoured.
+constexpr int EXPAND_BLOCK = 256;
+struct ExpandEntry {  // 32 bytes
+    uint32_t r0, r1, r2, r3;  // the afterstate
+    uint32_t empties;         // its empty cells; 0 = illegal action
+    uint32_t first;           // first child of this entry in the wave's dense numbering
+    uint64_t start;           // global index of that child
+};
+
+__global__ __launch_bounds__(EXPAND_BLOCK) void expand_kernel(uint64_t n, const uint8_t *boards, const uint64_t *offsets, uint8_t *children,
+                                                              int32_t *reward, uint8_t *n_empty)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
-    Board after[4];
-    int32_t rewards[4];
-    uint32_t legal;
-    four_afterstates(load_board(boards, i), after, rewards, legal);
-    uint64_t at = offsets[i];
+    __shared__ __attribute__((aligned(16))) ExpandEntry strip_lds[EXPAND_BLOCK / 64][64 * 4];
+    __shared__ uint16_t head_lds[EXPAND_BLOCK / 64][64];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t board0 = ((uint64_t)blockIdx.x * (EXPAND_BLOCK / 64) + wave) * 64u;
+    if (board0 >= n) return;  // wave-uniform
+    ExpandEntry *strip = strip_lds[wave];
+    uint16_t *head = head_lds[wave];
+    const uint64_t mine = board0 + lane;
+    uint32_t count[4] = {0u, 0u, 0u, 0u};  // children of my board's four actions
+    uint32_t empt[4] = {0u, 0u, 0u, 0u};
+    Board after[4] = {};
+    uint64_t my_start = 0;
+    if (mine < n) {
+        int32_t rewards[4];
+        uint32_t legal;
+        four_afterstates(load_board(boards, mine), after, rewards, legal);
 #pragma unroll
-    for (uint32_t act = 0; act < 4u; ++act) {
-        const bool ok = ((legal >> act) & 1u) != 0u;
-        const uint32_t empt = ok ? empty_mask(after[act]) : 0u;  // a legal move always leaves an empty cell
-        const uint32_t ne = ENV2048_POPC(empt);
-        reward[4 * i + act] = ok ? rewards[act] : 0;
-        n_empty[4 * i + act] = (uint8_t)ne;  // 0 = illegal action
-        for (uint32_t k = 0; k < ne; ++k) {
-            const uint32_t bit = kth_empty(empt, k);
-            Board two = after[act], four = after[act];
-            place_tile(two, bit, false);
-            place_tile(four, bit, true);
-            store_board(children, at, two);
-            store_board(children, at + 1u, four);
-            at += 2u;
+        for (uint32_t act = 0; act < 4u; ++act) {
+            const bool ok = ((legal >> act) & 1u) != 0u;
+            empt[act] = ok ? empty_mask(after[act]) : 0u;  // a legal move always leaves an empty cell
+            count[act] = 2u * ENV2048_POPC(empt[act]);
+            rewards[act] = ok ? rewards[act] : 0;
+        }
+        reinterpret_cast<int4 *>(reward)[mine] = make_int4(rewards[0], rewards[1], rewards[2], rewards[3]);
+        reinterpret_cast<uint32_t *>(n_empty)[mine] = (count[0] >> 1) | ((count[1] >> 1) << 8) | ((count[2] >> 1) << 16) | ((count[3] >> 1) << 24);
+        my_start = offsets[mine];
+    }
+    const uint32_t mine_count = count[0] + count[1] + count[2] + count[3];
+    uint32_t scan = mine_count;
+#pragma unroll
+    for (uint32_t d = 1; d < 64u; d <<= 1) {
+        const uint32_t up = __shfl_up(scan, d);
+        scan += lane >= d ? up : 0u;
+    }
+    const uint32_t total = __shfl(scan, 63);
+    uint32_t first[4];
+    first[0] = scan - mine_count;
+    first[1] = first[0] + count[0];
+    first[2] = first[1] + count[1];
+    first[3] = first[2] + count[2];
+#pragma unroll
+    for (uint32_t act = 0; act < 4u; ++act)
+        strip[4u * lane + act] = ExpandEntry{after[act].r0, after[act].r1, after[act].r2, after[act].r3, empt[act], first[act],
+                                             my_start + (first[act] - first[0])};
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // strip and head are wave-private: LDS ops of a wave are ordered
+    __builtin_amdgcn_wave_barrier();
+    uint32_t carry = 0u;
+    for (uint32_t w0 = 0; w0 < total; w0 += 64u) {
+        head[lane] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (uint32_t act = 0; act < 4u; ++act) {
+            const uint32_t at = first[act] - w0;  // (wraps for entries in front of the chunk: >= 64 then)
+            if (count[act] != 0u && at < 64u) head[at] = (uint16_t)(4u * lane + act + 1u);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t entry1 = max(wave_scan_max(head[lane]), carry);
+        carry = __builtin_amdgcn_readlane(entry1, 63);
+        const uint32_t w = w0 + lane;
+        if (w < total) {
+            const uint4 rows = reinterpret_cast<const uint4 *>(&strip[entry1 - 1u])[0];
+            const uint4 rest = reinterpret_cast<const uint4 *>(&strip[entry1 - 1u])[1];  // empties, first, start (lo, hi)
+            const uint32_t j = w - rest.y;                                               // my rank among the entry's children
+            Board child{rows.x, rows.y, rows.z, rows.w};
+            place_tile(child, kth_empty(rest.x, j >> 1), (j & 1u) != 0u);
+            store_board(children, (((uint64_t)rest.w << 32) | rest.z) + j, child);
         }
     }
 }
 
+// Values of a level from the values of its children: Q(s, a) = r + (0.9 S2 + 0.1 S4) / num_empty with S2 / S4 summed IN CHILD
+// ORDER, every operation a separate correctly rounded double operation (the oracle's order of additions; fp contract off).
+// One lane per (board, action): four times the parallelism of a lane per board, a lane's (S2, S4) pair per cell is one 16-byte
+// load when the value array is 16-byte aligned (child ranges start at even indices), and the four lanes of a board sit in
+// one quad: the arg-max is four DPP reads.
+// the value lane A of my quad holds (DPP quad_perm broadcast; a double is two dwords)
+template <int A>
+__device__ __forceinline__ double quad_broadcast(double x)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), A * 0x55, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), A * 0x55, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+template <bool ALIGNED16>
 __global__ __launch_bounds__(BLOCK) void expectimax_backup_kernel(uint64_t n, const int32_t *reward, const uint8_t *n_empty,
                                                                   const uint64_t *offsets, const double *child_value, double *value,
                                                                   double *q, uint8_t *best_action)
 {
 #pragma clang fp contract(off)  // plain operators below, created under contract(off): no fma for 0.9 * S2 + 0.1 * S4 (HIP's __dmul_rn /
     // __dadd_rn are inline functions built under the default mode -- inlined, their multiply and add DO fuse)
-    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
-    uint64_t at = offsets[i];
-    double best_q = 0.0;
-    uint32_t best_a = 255u;
-#pragma unroll
-    for (uint32_t act = 0; act < 4u; ++act) {
-        const uint32_t ne = n_empty[4 * i + act];
-        double qa = -__builtin_inf();
+    const uint64_t t = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const uint64_t i = t >> 2;
+    const uint32_t act = (uint32_t)t & 3u;
+    const bool valid = i < n;
+    double qa = -__builtin_inf();
+    if (valid) {
+        const uint32_t ne4 = reinterpret_cast<const uint32_t *>(n_empty)[i];  // the four n_empty bytes of my board
+        const uint32_t ne = (ne4 >> (8u * act)) & 0xFFu;
+        const uint32_t before = act == 0u ? 0u : act == 1u ? (ne4 & 0xFFu) : act == 2u ? (ne4 & 0xFFu) + ((ne4 >> 8) & 0xFFu)
+                                                                                     : (ne4 & 0xFFu) + ((ne4 >> 8) & 0xFFu) + ((ne4 >> 16) & 0xFFu);
         if (ne) {
+            const double *at = child_value + offsets[i] + 2u * before;
             double s2 = 0.0, s4 = 0.0;
-            for (uint32_t k = 0; k < ne; ++k) {
-                s2 = s2 + child_value[at];
-                s4 = s4 + child_value[at + 1u];
-                at += 2u;
+            // (offsets that are prefix sums of child counts are even; a caller's odd offset takes the 8-byte loads, it never faults)
+            if (ALIGNED16 && (reinterpret_cast<uintptr_t>(at) & 15u) == 0u) {
+                for (uint32_t k = 0; k < ne; ++k) {
+                    const double2 pair = reinterpret_cast<const double2 *>(at)[k];
+                    s2 = s2 + pair.x;
+                    s4 = s4 + pair.y;
+                }
+            } else {
+                for (uint32_t k = 0; k < ne; ++k) {
+                    s2 = s2 + at[2u * k];
+                    s4 = s4 + at[2u * k + 1u];
+                }
             }
             const double t2 = 0.9 * s2, t4 = 0.1 * s4;
             const double mix = t2 + t4;
             const double mean = mix / (double)ne;
-            qa = (double)reward[4 * i + act] + mean;
-            if (best_a == 255u || qa > best_q) {
-                best_q = qa;
-                best_a = act;
-            }
+            qa = (double)reward[t] + mean;
         }
-        if (q) q[4 * i + act] = qa;
+        if (q) q[t] = qa;
     }
-    value[i] = best_a == 255u ? 0.0 : best_q;
-    if (best_action) best_action[i] = (uint8_t)best_a;
+    // the four actions of a board are the four lanes of a quad: first maximum over the legal ones (quad_perm broadcasts)
+    double best_q = 0.0;
+    uint32_t best_a = 255u;
+    const double of_action[4] = {quad_broadcast<0>(qa), quad_broadcast<1>(qa), quad_broadcast<2>(qa), quad_broadcast<3>(qa)};
+#pragma unroll
+    for (uint32_t a2 = 0; a2 < 4u; ++a2) {
+        if (of_action[a2] != -__builtin_inf() && (best_a == 255u || of_action[a2] > best_q)) {
+            best_q = of_action[a2];
+            best_a = a2;
+        }
+    }
+    if (valid && act == 0u) {
+        value[i] = best_a == 255u ? 0.0 : best_q;
+        if (best_action) best_action[i] = (uint8_t)best_a;
+    }
 }
 
 __global__ __launch_bounds__(BLOCK) void spawn_kernel(uint64_t n, uint8_t *boards, const uint8_t *spawn_k,
@@ -875,7 +971,9 @@ int env2048_expand(int device, void *stream, uint64_t n, const uint8_t *boards, 
     if (int rc = check_count(n)) return rc;
     DeviceScope scope(device);
     if (scope.rc) return scope.rc;
-    hipLaunchKernelGGL(expand_kernel, grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, n, boards, offsets, children, reward, n_empty);
+    if (misaligned(reward, 16) || misaligned(n_empty, 4)) return fail(ENV2048_ERR_ALIGNMENT, "env2048_expand: reward must be 16-byte, n_empty 4-byte aligned");
+    hipLaunchKernelGGL(expand_kernel, dim3((unsigned)((n + EXPAND_BLOCK - 1) / EXPAND_BLOCK)), dim3(EXPAND_BLOCK), 0, (hipStream_t)stream, n, boards,
+                       offsets, children, reward, n_empty);
     return launched("env2048_expand launch");
 }
 
@@ -889,8 +987,14 @@ int env2048_expectimax_backup(int device, void *stream, uint64_t n, const int32_
     if (int rc = check_count(n)) return rc;
     DeviceScope scope(device);
     if (scope.rc) return scope.rc;
-    hipLaunchKernelGGL(expectimax_backup_kernel, grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, n, reward, n_empty, offsets, child_value,
-                       value, q, best_action);
+    if (misaligned(n_empty, 4)) return fail(ENV2048_ERR_ALIGNMENT, "env2048_expectimax_backup: n_empty must be 4-byte aligned");
+    if (int rc = check_count(4 * n)) return rc;
+    if (misaligned(child_value, 16))
+        hipLaunchKernelGGL(expectimax_backup_kernel<false>, grid_for(4 * n), dim3(BLOCK), 0, (hipStream_t)stream, n, reward, n_empty, offsets,
+                           child_value, value, q, best_action);
+    else
+        hipLaunchKernelGGL(expectimax_backup_kernel<true>, grid_for(4 * n), dim3(BLOCK), 0, (hipStream_t)stream, n, reward, n_empty, offsets,
+                           child_value, value, q, best_action);
     return launched("env2048_expectimax_backup launch");
 }
 
