@@ -739,7 +739,7 @@ def other_configs(torch, lib, device, device_index, h) -> dict:
 
     out = {}
     # configs[0]: one board, 1000 random-action steps through the TwentyFortyEight env API (reset on done) -- the mirror runs
-    # every step as one kernel launch on pinned host operands + one stream synchronisation
+    # every step as one kernel launch on pinned host operands + one polled completion word
     import numpy as np
 
     from simulate_2048_amd.twentyfortyeight.envs.twentyfortyeight import TwentyFortyEight
@@ -757,7 +757,7 @@ def other_configs(torch, lib, device, device_index, h) -> dict:
     dt = time.perf_counter() - t0
     out['configs[0]'] = {
         'workload': 'single 4x4 board, 1000 random-action steps via the TwentyFortyEight env API (mirror on the GPU: one launch on pinned '
-                    'host operands + one synchronisation per step)',
+                    'host operands + one polled completion word per step)',
         'value': 1000 / dt, 'unit': 'board-steps/s', 'us_per_step': dt * 1e3,
         'reference': 'the reference NumPy env: 9.5-10.2e3 steps/s on one core of the build container (BASELINE.md section 2)',
     }
