@@ -720,7 +720,7 @@ ENV2048_DEV void transition_oriented(Board &pl, const OrientStep &s, uint32_t wo
 // same greedy pairing from the wall outward [ref: twentyfortyeight/core/gameboard.py:23-69 merge_column].  The expectimax
 // leaf evaluator needs scores line by line: a spawned tile changes ONE row and ONE column of an afterstate, so the best
 // move reward of a successor is (sum over rows) - old row + new row against (sum over columns) - old column + new column.
-ENV2048_DEV void line_merge_terms(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t &v1, uint32_t &v2)
+ENV2048_DEV void line_merge_terms_flags(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t &v1, uint32_t &v2, uint32_t &f1, uint32_t &f2)
 {
     const uint32_t na = nzmask(a), nb0 = nzmask(b), nc0 = nzmask(c), nd0 = nzmask(d);
     const uint32_t one_abc = ENV2048_BITOP3(na, nb0, nc0, 0x16);
@@ -739,6 +739,14 @@ ENV2048_DEV void line_merge_terms(uint32_t a, uint32_t b, uint32_t c, uint32_t d
     // merged exponent = exponent + 1 in the lanes that merge, 0 elsewhere (the masks are 0x00 / 0xFF per byte)
     v1 = ENV2048_AND_OR(ob + K01, m_bc, (oa + K01) & m_ab);
     v2 = (oc + K01) & m_cd;
+    f1 = (m_ab | m_bc) & K01;  // 0 / 1 per byte lane: the line has a merge at the wall end / a second one
+    f2 = m_cd & K01;
+}
+
+ENV2048_DEV void line_merge_terms(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t &v1, uint32_t &v2)
+{
+    uint32_t f1, f2;
+    line_merge_terms_flags(a, b, c, d, v1, v2, f1, f2);
 }
 
 // Score of the line in byte lane `shift / 8` of a (v1, v2) pair: 2^v1 + 2^v2, a zero exponent meaning "no merge" (a merged
@@ -747,6 +755,16 @@ ENV2048_DEV uint32_t line_score(uint32_t v1, uint32_t v2, uint32_t shift)
 {
     const uint32_t e1 = (v1 >> shift) & 0xFFu, e2 = (v2 >> shift) & 0xFFu;
     return ((1u << (e1 & 31u)) & ~1u) + ((1u << (e2 & 31u)) & ~1u);
+}
+
+// The four line scores at once, with compile-time byte lanes: one SDWA shift per term (the lane's merge flag -- 0 / 1 per
+// byte, from line_merge_terms_flags -- shifted by the lane's exponent), as in slide_merge_planes().
+ENV2048_DEV void line_scores4(uint32_t v1, uint32_t v2, uint32_t f1, uint32_t f2, uint32_t &s0, uint32_t &s1, uint32_t &s2, uint32_t &s3)
+{
+    s0 = shl_byte<0>(f1, v1) + shl_byte<0>(f2, v2);
+    s1 = shl_byte<1>(f1, v1) + shl_byte<1>(f2, v2);
+    s2 = shl_byte<2>(f1, v1) + shl_byte<2>(f2, v2);
+    s3 = shl_byte<3>(f1, v1) + shl_byte<3>(f2, v2);
 }
 
 // Sum of the four line scores of a (v1, v2) pair == what slide_merge_planes() returns for the same planes.

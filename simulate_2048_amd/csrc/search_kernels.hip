@@ -378,20 +378,23 @@ __global__ __launch_bounds__(D2_BLOCK) void expectimax_depth2_kernel(uint64_t n,
             const uint4 lines = reinterpret_cast<const uint4 *>(&strip[e])[1];
             const uint4 rest = reinterpret_cast<const uint4 *>(&strip[e])[2];
             const uint32_t bit = kth_empty(rest.x, w - first_of[e]);  // my cell: the (w - first item of my entry)-th empty one
-            const uint32_t pos = (uint32_t)ENV2048_FFS(bit) - 1u;  // 8 * column + {5, 6, 7, 4}[row]
+            const uint32_t pos = (uint32_t)__builtin_ctz(bit);  // 8 * column + {5, 6, 7, 4}[row]   (an entry with items has the bit)
             const uint32_t col8 = pos & 24u, row = (pos - 5u) & 3u, row8 = 8u * row;
-            const uint32_t old_row = row == 0u ? rows.x : row == 1u ? rows.y : row == 2u ? rows.z : rows.w;
+            // row `row` of the afterstate, branch-free (left to itself hipcc turns the four-way choice into three divergent branches)
+            const uint32_t odd = 0u - (row & 1u), upper = 0u - (row >> 1);
+            const uint32_t old_row = ENV2048_BFI(upper, ENV2048_BFI(odd, rows.w, rows.z), ENV2048_BFI(odd, rows.y, rows.x));
             const uint32_t sel = 0x0C0C0400u + 0x0101u * (pos >> 3);  // byte `column` of a low and of a high dword
             const uint32_t old_col = byte_perm(byte_perm(rows.w, rows.z, sel), byte_perm(rows.y, rows.x, sel), 0x05040100u);
             // the afterstate's own score on these two lines, and the four new lines: (row, column) x (tile 2, tile 4)
             const uint32_t h_base = rest.y - line_score(lines.x, lines.y, row8);
             const uint32_t v_base = rest.z - line_score(lines.z, lines.w, col8);
             const uint32_t l0 = old_row | (1u << col8), l1 = old_col | (1u << row8), l2 = old_row | (2u << col8), l3 = old_col | (2u << row8);
-            uint32_t p0, p1, p2, p3, v1, v2;
+            uint32_t p0, p1, p2, p3, v1, v2, f1, f2, s_row2, s_col2, s_row4, s_col4;
             transpose4x4(l0, l1, l2, l3, p0, p1, p2, p3);  // plane k = element k of the four lines
-            line_merge_terms(p0, p1, p2, p3, v1, v2);
-            const uint32_t best2 = max(h_base + line_score(v1, v2, 0u), v_base + line_score(v1, v2, 8u));
-            const uint32_t best4 = max(h_base + line_score(v1, v2, 16u), v_base + line_score(v1, v2, 24u));
+            line_merge_terms_flags(p0, p1, p2, p3, v1, v2, f1, f2);
+            line_scores4(v1, v2, f1, f2, s_row2, s_col2, s_row4, s_col4);
+            const uint32_t best2 = max(h_base + s_row2, v_base + s_col2);
+            const uint32_t best4 = max(h_base + s_row4, v_base + s_col4);
             atomicAdd(&sums[e][0], (int32_t)best2);  // integer sums: the order of the adds does not matter
             atomicAdd(&sums[e][1], (int32_t)best4);
         }

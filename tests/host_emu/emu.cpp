@@ -180,9 +180,13 @@ void emu_line_scores(uint64_t n_lines, const uint8_t *lines, uint32_t *scores, u
         uint32_t plane[4] = {0u, 0u, 0u, 0u};
         for (uint32_t j = 0; j < 4 && 4 * g + j < n_lines; ++j)
             for (uint32_t k = 0; k < 4; ++k) plane[k] |= (uint32_t)lines[4 * (4 * g + j) + k] << (8 * j);
-        uint32_t v1, v2;
-        line_merge_terms(plane[0], plane[1], plane[2], plane[3], v1, v2);
-        for (uint32_t j = 0; j < 4 && 4 * g + j < n_lines; ++j) scores[4 * g + j] = line_score(v1, v2, 8 * j);
+        uint32_t v1, v2, f1, f2, s4[4];
+        line_merge_terms_flags(plane[0], plane[1], plane[2], plane[3], v1, v2, f1, f2);
+        line_scores4(v1, v2, f1, f2, s4[0], s4[1], s4[2], s4[3]);  // the SDWA form ...
+        for (uint32_t j = 0; j < 4 && 4 * g + j < n_lines; ++j) {
+            scores[4 * g + j] = line_score(v1, v2, 8 * j);         // ... and the shift form of the same score must agree
+            if (s4[j] != scores[4 * g + j]) scores[4 * g + j] = 0xFFFFFFFFu;
+        }
         group_sums[g] = line_score_sum(v1, v2);
         uint32_t a = plane[0], b = plane[1], c = plane[2], d = plane[3], changed;
         group_slide_scores[g] = slide_merge_planes(a, b, c, d, changed);
