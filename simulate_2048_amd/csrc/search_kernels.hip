@@ -395,7 +395,9 @@ __global__ __launch_bounds__(D2_BLOCK) void expectimax_depth2_kernel(uint64_t n,
             line_scores4(v1, v2, f1, f2, s_row2, s_col2, s_row4, s_col4);
             const uint32_t best2 = max(h_base + s_row2, v_base + s_col2);
             const uint32_t best4 = max(h_base + s_row4, v_base + s_col4);
-            atomicAdd(&sums[e][0], (int32_t)best2);  // integer sums: the order of the adds does not matter
+            // integer sums: the order of the adds does not matter.  (Lanes of one entry hit the same two words; measured with the
+            // atomics replaced by plain stores -- wrong sums -- the launch is 1.3 % shorter: not worth a segmented reduction.)
+            atomicAdd(&sums[e][0], (int32_t)best2);
             atomicAdd(&sums[e][1], (int32_t)best4);
         }
     }

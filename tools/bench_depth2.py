@@ -15,7 +15,9 @@ from simulate_2048_amd import capi  # noqa: E402
 
 
 def main():
-    lib = capi.library()
+    import os
+
+    lib = capi.Library(os.environ['ENV2048_LIB']) if os.environ.get('ENV2048_LIB') else capi.library()  # (an experiment build)
     s = torch.cuda.current_stream().cuda_stream
     out = {}
     for lg in (12, 14, 16, 18, 20):
