@@ -88,7 +88,7 @@ def main():
     for r in range(reps):
         serial += 1
         t0 = time.perf_counter()
-        launch(a, b, 0, kp, ap) if False else lib.step_state_i32_keyed_mirrored(dev, stream, n, kp, a.ptr['board'], b.ptr['board'], ap, a.ptr['step_count'], b.ptr['step_count'], a.ptr['done'], b.ptr['done'], a.ptr['total'], b.ptr['total'], b.ptr['reward'], b.ptr['max_tile'], b.ptr['obs'], b.ptr['legal'], b.mirror_delta)
+        lib.step_state_i32_keyed_mirrored(dev, stream, n, kp, a.ptr['board'], b.ptr['board'], ap, a.ptr['step_count'], b.ptr['step_count'], a.ptr['done'], b.ptr['done'], a.ptr['total'], b.ptr['total'], b.ptr['reward'], b.ptr['max_tile'], b.ptr['obs'], b.ptr['legal'], b.mirror_delta)
         t1 = time.perf_counter()
         lib.stream_signal(dev, stream, word.data_ptr(), serial)
         t2 = time.perf_counter()
