@@ -421,6 +421,40 @@ class BatchedEnv2048:
                         _p(out['max_exp']), _p(out['n_empty']))
         return out
 
+    # -- checkpoint / resume -----------------------------------------------------------------------------------------------------
+    def state_dict(self) -> dict:
+        """Everything that determines the future of this batch -- the environment state is exactly the packed boards plus
+        (seed, step index, first global index), and the game every environment is in when ``rollout_episodes`` statistics are
+        being accumulated -- as host tensors / integers (``torch.save`` -able).  The reference never checkpoints its
+        environment; a resumed run here continues the SAME random stream: stepping a restored batch gives
+        byte for byte what the original would have produced."""
+        carry = None
+        if getattr(self, '_ep_length', None) is not None:
+            carry = {'length': self._ep_length.cpu(), 'return': self._ep_return.cpu()}
+        return {'format': 1, 'num_envs': self.num_envs, 'seed': self.seed, 'env_base': self.env_base, 'step_index': int(self.step_index),
+                'auto_reset': self.auto_reset, 'boards': self.boards.cpu(), 'reward': self.reward.cpu(), 'done': self.done.cpu(),
+                'episode_carry': carry}
+
+    def load_state_dict(self, state: dict) -> None:
+        """Restore ``state_dict()`` output into this batch (same number of environments; seed, index range and step index are
+        taken from the checkpoint, so is the auto-reset policy)."""
+        if state.get('format') != 1 or int(state['num_envs']) != self.num_envs:
+            raise ValueError(f'checkpoint of {state.get("num_envs")} environments (format {state.get("format")}) does not fit this batch of {self.num_envs}')
+        self.seed = int(state['seed']) & 0xFFFFFFFFFFFFFFFF
+        self.env_base = int(state['env_base'])
+        self.auto_reset = bool(state['auto_reset'])
+        self.boards.copy_(torch.as_tensor(state['boards'], dtype=torch.uint8).reshape(self.num_envs, 16))
+        self.reward.copy_(torch.as_tensor(state['reward'], dtype=torch.int32).reshape(self.num_envs))
+        self.done.copy_(torch.as_tensor(state['done'], dtype=torch.uint8).reshape(self.num_envs))
+        self.step_index = int(state['step_index'])
+        self.reset_episode_carry()
+        carry = state.get('episode_carry')
+        if carry is not None:
+            self._ep_length = torch.as_tensor(carry['length'], dtype=torch.int32).to(self.device).clone()
+            self._ep_return = torch.as_tensor(carry['return'], dtype=torch.int64).to(self.device).clone()
+        if self.legal is not None or self.obs is not None:
+            self.describe(self.legal, self.obs)  # the persistent legal / obs describe the restored boards
+
     def set_boards(self, boards) -> None:
         """Overwrite the state with packed boards (anything convertible to an (N,16) uint8 tensor)."""
         b = torch.as_tensor(boards, dtype=torch.uint8).reshape(self.num_envs, 16)

@@ -247,6 +247,20 @@ class ShardedEnv2048:
         self.synchronize()
         return torch.cat([getattr(e, name).cpu() for e in self.shards], dim=0)
 
+    def state_dict(self) -> dict:
+        """Checkpoint of the whole job: one ``BatchedEnv2048.state_dict()`` per shard (host tensors), taken on the shards' own
+        threads after their streams have drained.  The cut into shards is part of the checkpoint: restore into an object built
+        with the same total and the same number of devices."""
+        self.synchronize()
+        return {'format': 1, 'total_envs': self.total_envs, 'ranges': list(self.ranges), 'shards': self._fan(lambda g: self.shards[g].state_dict())}
+
+    def load_state_dict(self, state: dict) -> None:
+        if state.get('format') != 1 or int(state['total_envs']) != self.total_envs or [tuple(r) for r in state['ranges']] != [tuple(r) for r in self.ranges]:
+            raise ValueError('checkpoint does not fit this ShardedEnv2048 (total environments / number of shards differ)')
+        self._fan(lambda g: self.shards[g].load_state_dict(state['shards'][g]))
+        self.seed = self.shards[0].seed
+        self.env_base = self.shards[0].env_base
+
     def timed(self, fn) -> list[float]:
         """Run ``fn(g)`` on every shard bracketed by events on the shard's stream; returns per-shard milliseconds (what
         ``bench.py --single-process`` reports per device)."""

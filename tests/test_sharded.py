@@ -134,3 +134,45 @@ def test_eight_shards_each_on_its_own_device_and_stream(monkeypatch):
         assert count == c and device == g and stream == 0xA000 + g, (name, device, stream, env_base, count)  # ... and is that shard's own
         seen.add((name, g))
     assert {g for _, g in seen} == set(range(G)) and {name for name, _ in seen} >= {'reset', 'step', 'rollout'}
+
+
+def test_checkpoint_and_resume_continue_the_same_random_stream(backend, tmp_path):
+    """state_dict() / load_state_dict() (checkpoint / resume: the env state is boards + (seed, step index,
+    first global index) + the running episode of the statistics): a batch restored from a ``torch.save``d checkpoint, into a
+    fresh object, produces byte for byte what the original produces -- single batch and sharded, statistics carry included."""
+    n, seed, base = 5003, 99, 17
+    a = BatchedEnv2048(n, seed, device=backend['one'], env_base=base, auto_reset=True, with_legal=True, lib=backend['lib'])
+    a.reset()
+    for _ in range(7):
+        a.step(None)
+    stats_a = a.rollout_episodes(40)
+    path = tmp_path / 'env.pt'
+    torch.save(a.state_dict(), path)
+    b = BatchedEnv2048(n, 1, device=backend['one'], lib=backend['lib'], with_legal=True)  # other seed / base / policy: all restored
+    b.load_state_dict(torch.load(path, weights_only=True))
+    assert (b.seed, b.env_base, b.step_index, b.auto_reset) == (a.seed, a.env_base, a.step_index, True)
+    assert torch.equal(b.boards, a.boards) and torch.equal(b.legal, a.status()['legal'])  # (legal / obs are re-derived from the restored boards)
+    stats_b = stats_a.clone()
+    a.rollout_episodes(60, stats_a)
+    b.rollout_episodes(60, stats_b)  # the games in progress at the checkpoint are counted whole on both sides
+    assert torch.equal(stats_a, stats_b) and torch.equal(a.boards, b.boards)
+    for _ in range(5):
+        a.step(None)
+        b.step(None)
+    assert torch.equal(a.boards, b.boards) and torch.equal(a.reward, b.reward) and torch.equal(a.done, b.done)
+    with pytest.raises(ValueError):
+        BatchedEnv2048(n + 1, 1, device=backend['one'], lib=backend['lib']).load_state_dict(a.state_dict())
+    sh = ShardedEnv2048(n, seed, devices=backend['devices'], env_base=base, auto_reset=True, lib=backend['lib'])
+    sh2 = ShardedEnv2048(n, 5, devices=backend['devices'], lib=backend['lib'])
+    try:
+        sh.reset()
+        sh.step_sequence(9)
+        sh2.load_state_dict(sh.state_dict())
+        sh.step_sequence(6)
+        sh2.step_sequence(6)
+        assert torch.equal(sh.gather('boards'), sh2.gather('boards')) and sh2.step_index == sh.step_index
+        with pytest.raises(ValueError):
+            ShardedEnv2048(n + 4, 5, devices=backend['devices'], lib=backend['lib']).load_state_dict(sh.state_dict())
+    finally:
+        sh.close()
+        sh2.close()
