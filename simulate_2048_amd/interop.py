@@ -19,9 +19,9 @@ import numpy as np
 import torch
 
 
-# id(tensor) -> (ResultSet, field name, the tensor itself) for the tensors of pooled result sets; resultpool (which imports this
-# module for DeviceArray) fills it.  The third entry pins the identity: an id can be reused by another object once the
-# original is gone, the stored reference cannot be anything else.
+# id(tensor) -> (ResultSet, field name, the tensor itself, un-batched alias?) for the tensors of pooled result sets; resultpool
+# (which imports this module for DeviceArray) fills it.  The third entry pins the identity: an id can be reused by another
+# object once the original is gone, the stored reference cannot be anything else.
 _registry: dict = {}
 _registry_get = _registry.get
 
@@ -45,7 +45,9 @@ class DeviceArray(torch.Tensor):
         if hit is not None and hit[2] is self:
             host = hit[0].host_array(hit[1])
             if host is not None:
-                return host.astype(dtype) if dtype is not None and dtype != host.dtype else host.copy()
+                if hit[3]:  # the un-batched alias of a one-environment set: row 0
+                    host = host[0]
+                return host.astype(dtype) if dtype is not None and dtype != host.dtype else np.array(host)
         plain = self.as_subclass(torch.Tensor).detach()
         if plain.dtype == torch.bfloat16:  # NumPy has no bfloat16: widen (exact)
             plain = plain.to(torch.float32)
@@ -56,6 +58,27 @@ class DeviceArray(torch.Tensor):
 
     def numpy(self, *args, **kwargs):  # JAX-style / torch-style explicit conversion, also from the GPU
         return self.__array__()
+
+    # Scalar read-backs (`bool(done)`, `float(reward)`, `int(info['max_tile'])` of the reference's single-game loops,
+    # reinforce/training/self_play.py:102-135, evaluate.py:100-128): through __array__, i.e. from the host mirror of a pooled
+    # result set when there is one (no device-to-host copy, no stream synchronisation), else torch's own .item().
+    def item(self):
+        hit = _registry_get(id(self))
+        if hit is not None and hit[2] is self:
+            return self.__array__().item()
+        return self.as_subclass(torch.Tensor).item()
+
+    def __bool__(self):
+        return bool(self.item())
+
+    def __float__(self):
+        return float(self.item())
+
+    def __int__(self):
+        return int(self.item())
+
+    def __index__(self):
+        return int(self.item())
 
 
 def wrap(t):

@@ -128,7 +128,7 @@ def _state_ptrs(states: GameState, rt):
     """Pointers of a state's four fields + n + keep-alive list.  Tensors that ARE the tensors of a pooled result set (the
     state came out of batched_step / batched_reset) are recognised by identity: nothing to check, nothing to convert."""
     hit = pool.lookup(states.board)
-    if hit is not None and hit[1] == 'board':
+    if hit is not None and hit[1] == 'board' and not hit[3]:
         rs = hit[0]
         if states.step_count is rs.step_count and states.done is rs.done and states.total_reward is rs.total:
             p = rs.ptr
@@ -224,7 +224,7 @@ def batched_step(states: GameState, actions, keys):
 def _stashed(states: GameState, field: str):
     """obs / legal written by the launch that produced `states`, if the state is a pooled one and still as written."""
     hit = pool.lookup(states.board)
-    if hit is not None and hit[1] == 'board' and hit[0].stash_valid():
+    if hit is not None and hit[1] == 'board' and not hit[3] and hit[0].stash_valid():
         return getattr(hit[0], field)
     return None
 
@@ -272,30 +272,66 @@ def _unsqueeze(state: GameState) -> GameState:
     )
 
 
-def _one_key(key) -> torch.Tensor:
-    """A single PRNG key ((2,) uint32 array-like or a plain integer seed) as a (1, 2) int32 host tensor."""
+def _one_key(key) -> np.ndarray:
+    """A single PRNG key ((2,) uint32 array-like or a plain integer seed) as a (1, 2) uint32 HOST array (so that it travels in
+    the kernel arguments like the keys of a small batch: no staging, no copy to the device)."""
     k0, k1 = key_words(key)
-    return torch.tensor([[k0 - (1 << 32) if k0 >= 1 << 31 else k0, k1 - (1 << 32) if k1 >= 1 << 31 else k1]], dtype=torch.int32)
+    return np.array([[k0, k1]], dtype=np.uint32)
+
+
+def _single_set(state: GameState):
+    """The one-environment result set whose un-batched aliases make up `state` (it came out of reset / step), else None."""
+    hit = pool.lookup(state.board)
+    if hit is not None and hit[3]:
+        single = hit[0].single
+        if state.step_count is single['step_count'] and state.done is single['done'] and state.total_reward is single['total']:
+            return hit[0]
+    return None
+
+
+def _single_state(batched: GameState) -> GameState:
+    """Un-batched view of a one-environment state: the set's own alias objects when it is a pooled set (nothing is created),
+    else plain indexing."""
+    hit = pool.lookup(batched.board)
+    if hit is not None and hit[0].single is not None:
+        single = hit[0].single
+        return GameState(single['board'], single['step_count'], single['done'], single['total'])
+    return _squeeze(batched)
 
 
 def reset(key) -> GameState:
     """[ref env.py:55-76] new game: board with two tiles, step_count 0, done False, total_reward 0."""
-    return _squeeze(batched_reset(_one_key(key)))
+    return _single_state(batched_reset(_one_key(key)))
 
 
 def step(state: GameState, action, key):
-    """[ref env.py:79-133] -> (GameState, reward f32, done bool, info dict)."""
-    new_state, reward, done, info = batched_step(_unsqueeze(state), [int(action)], _one_key(key))
+    """[ref env.py:79-133] -> (GameState, reward f32, done bool, info dict).  A state that came out of reset / step is
+    recognised by identity: the move is the batched launch on its one-environment result set (host key and action in the
+    kernel arguments, results mirrored to the host), no view or conversion in between."""
+    rs = _single_set(state)
+    batched = GameState(rs.board, rs.step_count, rs.done, rs.total) if rs is not None else _unsqueeze(state)
+    new_state, reward, done, info = batched_step(batched, np.array([int(action)], dtype=np.int32), _one_key(key))
+    hit = pool.lookup(new_state.board)
+    if hit is not None and hit[0].single is not None:
+        single = hit[0].single
+        return (GameState(single['board'], single['step_count'], single['done'], single['total']), single['reward'], single['done'],
+                {'max_tile': single['max_tile'], 'step_count': single['step_count'], 'total_reward': single['total']})
     return _squeeze(new_state), reward[0], done[0], {k: v[0] for k, v in info.items()}
 
 
 def get_observation(state: GameState) -> torch.Tensor:
     """[ref env.py:136-151] (16,) float32."""
+    rs = _single_set(state)
+    if rs is not None and rs.stash_valid():
+        return rs.single['obs']  # written by the launch that produced the state
     return batched_get_observation(_unsqueeze(state))[0]
 
 
 def get_legal_actions(state: GameState) -> torch.Tensor:
     """[ref env.py:154-169] (4,) bool."""
+    rs = _single_set(state)
+    if rs is not None and rs.stash_valid():
+        return rs.single['legal']
     return batched_get_legal_actions(_unsqueeze(state))[0]
 
 

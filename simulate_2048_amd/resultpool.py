@@ -50,7 +50,7 @@ class ResultSet:
     __slots__ = ('n', 'arena', 'storage', 'cdata', 'board', 'obs', 'step_count', 'max_tile', 'total', 'reward', 'legal', 'done',
                  'tensors', 'ptr', 'idle_refs', 'idle_use', 'version', 'pooled', 'leased', 'layout', 'serial',
                  'mirror', 'mirror_fields', 'mirror_key', 'mirror_copies', 'mirror_delta', 'direct_serial', 'stream',
-                 'seq_ptr', 'signal_serial', 'signal_hits', 'stream_syncs', 'wait_sequence')
+                 'seq_ptr', 'signal_serial', 'signal_hits', 'stream_syncs', 'wait_sequence', 'single')
 
     def __init__(self, n: int, device: torch.device):
         self.n = n
@@ -79,6 +79,16 @@ class ResultSet:
         self.reward = carve('reward', 4 * n, torch.float32, (n,))
         self.legal = carve('legal', 4 * n, torch.bool, (n, 4))
         self.tensors = (self.board, self.obs, self.step_count, self.total, self.done, self.max_tile, self.reward, self.legal)
+        # A set of ONE environment also carries the un-batched aliases the single-environment API hands out (board (4, 4),
+        # obs (16,), legal (4,), scalars of shape ()): reset / step / get_observation of reinforce/game/env.py:55-169 then
+        # return objects of the set itself -- no view is created per call, the next step recognises its state by identity,
+        # and np.array / bool / float of them read the host mirror like the batched arrays do.
+        self.single = None
+        if n == 1:
+            self.single = {'board': self.board.view(4, 4), 'obs': self.obs.view(16), 'step_count': self.step_count.view(()),
+                           'total': self.total.view(()), 'done': self.done.view(()), 'max_tile': self.max_tile.view(()),
+                           'reward': self.reward.view(()), 'legal': self.legal.view(4)}
+            self.tensors = self.tensors + tuple(self.single.values())
         self.ptr = {name: base + offsets[name] for name, _ in sizes}
         self.version = arena._version  # ONE counter: the carved tensors are views of the arena and share its version counter
         self.recount_idle()
@@ -109,6 +119,8 @@ class ResultSet:
         ts = self.tensors  # (measured exactly the way idle() measures: indexing adds no reference, a loop variable would)
         self.idle_refs = (sys.getrefcount(ts[0]), sys.getrefcount(ts[1]), sys.getrefcount(ts[2]), sys.getrefcount(ts[3]),
                           sys.getrefcount(ts[4]), sys.getrefcount(ts[5]), sys.getrefcount(ts[6]), sys.getrefcount(ts[7]))
+        if self.single is not None:  # the eight aliases of a one-environment set
+            self.idle_refs = self.idle_refs + tuple(sys.getrefcount(ts[k]) for k in range(8, 16))
         self.idle_use = _use_count(self.cdata) if _use_count else -1
 
     def attach_mirror(self) -> None:
@@ -136,9 +148,15 @@ class ResultSet:
             return False
         refs = self.idle_refs
         ts = self.tensors
-        return (sys.getrefcount(ts[0]) == refs[0] and sys.getrefcount(ts[1]) == refs[1] and sys.getrefcount(ts[2]) == refs[2]
+        if not (sys.getrefcount(ts[0]) == refs[0] and sys.getrefcount(ts[1]) == refs[1] and sys.getrefcount(ts[2]) == refs[2]
                 and sys.getrefcount(ts[3]) == refs[3] and sys.getrefcount(ts[4]) == refs[4] and sys.getrefcount(ts[5]) == refs[5]
-                and sys.getrefcount(ts[6]) == refs[6] and sys.getrefcount(ts[7]) == refs[7])
+                and sys.getrefcount(ts[6]) == refs[6] and sys.getrefcount(ts[7]) == refs[7]):
+            return False
+        if self.single is not None:
+            for k in range(8, 16):
+                if sys.getrefcount(ts[k]) != refs[k]:
+                    return False
+        return True
 
     def next_serial(self) -> int:
         """The serial the NEXT launch into this set will have (what a *_signalled launch stores into the completion word)."""
@@ -245,7 +263,10 @@ class ResultPool:
                 rs.attach_mirror()  # (only sets the pool keeps: see attach_mirror)
                 reg = self.registry
                 for name, t in zip(('board', 'obs', 'step_count', 'total', 'done', 'max_tile', 'reward', 'legal'), rs.tensors):
-                    reg[id(t)] = (rs, name, t)
+                    reg[id(t)] = (rs, name, t, False)
+                if rs.single is not None:
+                    for name, t in rs.single.items():
+                        reg[id(t)] = (rs, name, t, True)  # True: the un-batched alias (row 0 of the field)
                 del t  # (the loop variable is a reference too)
                 rs.recount_idle()  # the registry's references belong to the idle state
             return rs

@@ -536,6 +536,67 @@ def test_the_fast_move_path_is_present_on_this_box():
 
 
 @pytest.mark.gpu
+def test_single_game_loop_runs_on_the_one_environment_result_set():
+    """The reference's SINGLE-game loops (reinforce/training/self_play.py:84-135, reinforce/evaluate.py:89-128): per move
+    get_observation, get_legal_actions, step with a fresh key, bool(done), float(reward).  States that come out of reset /
+    step are the un-batched aliases of a pooled one-environment result set, so a move is ONE launch (host key and action in the
+    kernel arguments), the getters return the stash, and every read-back -- np.array, bool, float, int -- comes from the host
+    mirror: no device-to-host copy, no new result set, results equal to the oracle's keyed step."""
+    from simulate_2048_amd import runtime
+    from simulate_2048_amd.reinforce.game.env import get_legal_actions, get_observation
+
+    resultpool.pool.clear()
+    rt = runtime.current()
+    calls = []
+
+    class Spy:
+        def __init__(self, lib):
+            self._lib = lib
+
+        def __getattr__(self, name):
+            fn = getattr(self._lib, name)
+            if not callable(fn) or name == 'wait_sequence':
+                return fn
+
+            def counted(*args, **kwargs):
+                calls.append(name)
+                return fn(*args, **kwargs)
+
+            return counted
+
+    with runtime.use(Spy(rt.lib), rt.device):
+        state = reset(np.array([5, 77], dtype=np.uint32))
+        assert tuple(state.board.shape) == (4, 4) and state.board.dtype == torch.int32 and tuple(state.done.shape) == ()
+        board = np.array(state.board)
+        assert (board != 0).sum() == 2 and int(state.step_count) == 0 and bool(state.done) is False and float(state.total_reward) == 0.0
+        ref_board = board.reshape(1, 16).astype(np.int32)
+        ref_steps, ref_done, ref_total = np.zeros(1, np.int32), np.zeros(1, np.uint8), np.zeros(1, np.float32)
+        for move in range(40):
+            if move == 10:
+                created, copies_before = resultpool.pool.created, sum(rs.mirror_copies for sets in resultpool.pool._sets.values() for rs in sets)
+                calls.clear()
+            obs = np.array(get_observation(state))
+            legal = np.array(get_legal_actions(state))
+            assert obs.shape == (16,) and obs.dtype == np.float32 and legal.shape == (4,) and legal.dtype == np.bool_
+            action = int(np.flatnonzero(legal)[0]) if legal.any() else 0
+            key = np.array([move, 4242], dtype=np.uint32)
+            state, reward, done, info = step(state, action, key)
+            want = oracle.step_state_i32_keyed(ref_board, np.array([action], np.int32), ref_steps, ref_done, ref_total, key.reshape(1, 2))
+            ref_board, ref_steps, ref_done, ref_total = want['boards'], want['step_count'], want['done'], want['total_reward']
+            assert np.array_equal(np.array(state.board).reshape(1, 16), ref_board) and float(reward) == float(want['reward'][0])
+            assert bool(done) == bool(want['done'][0]) and int(info['max_tile']) == int(want['max_tile'][0]) and int(state.step_count) == int(ref_steps[0])
+            status = oracle.status_batch(oracle.pack_values(ref_board).reshape(1, 16))
+            assert np.array_equal(np.array(get_observation(state)), status['obs'][0])
+        assert resultpool.pool.created == created, 'a steady-state single-game move allocated a result set'
+        assert calls == ['step_state_i32_keyed_inline'] * 30, calls[:5]
+        assert sum(rs.mirror_copies for sets in resultpool.pool._sets.values() for rs in sets) == copies_before
+        # an in-place edit of the board drops the stash: the getters then take a kernel of their own (and see the edit)
+        state.board[0, 0] = 1024
+        assert np.array(get_observation(state))[0] == np.float32(10 / 16)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
 def test_more_live_states_than_the_pool_keeps_take_no_mirror():
     """a set the pool does not keep is referenced by nobody once the call returns, so its pinned mirror
     would go back to torch's host allocator while the launch is still writing it.  Such sets get NO mirror (delta 0, plain
