@@ -7,10 +7,14 @@ differs from the NumPy one (``is_done`` of the all-zero board is True: core.py:3
 
 from __future__ import annotations
 
+import threading
+
+import numpy as np
 import torch
 
 from ... import ops, runtime
-from ...interop import to_tensor, wrap
+from ...interop import key_words, to_tensor, wrap
+from ...resultpool import NEXT_STATE_FIELDS, pool
 
 BOARD_SIZE = 4
 NUM_ACTIONS = 4
@@ -32,6 +36,47 @@ def _packed(board) -> torch.Tensor:
 
 def _values(packed: torch.Tensor) -> torch.Tensor:
     return wrap(ops.unpack(packed, dtype=torch.int32).reshape(4, 4))
+
+
+# ---- one launch per move for the reference's single-game loops --------------------------------------------------------------
+# play_game / evaluate_games (reinforce/training/self_play.py:95-135, reinforce/evaluate.py:96-128) call, per move,
+# encode_observation(board), legal_actions_mask(board), next_state(board, action, key), is_done(new_board) and max_tile(board).
+# next_state runs the fused move kernel (env2048_step_state_i32_keyed_inline: key and action travel in the kernel arguments)
+# into a pooled one-environment result set, which also receives the observation, legal mask, terminal flag and max tile of the
+# NEW board; the board it returns is that set's (4, 4) alias, so the four queries about it are answered from the set --
+# recognised by identity, valid while torch's version counter says nobody edited it in place -- without a launch, and their
+# np.array / bool / float read-backs come from the set's host mirror.  Any other board takes one status launch per query.
+class _MoveScratch(threading.local):
+    def __init__(self):
+        self.key = np.zeros((1, 2), dtype=np.uint32)
+        self.action = np.zeros((1,), dtype=np.int32)
+        self.key_addr, self.action_addr = self.key.ctypes.data, self.action.ctypes.data
+        self.not_done = {}  # device -> a zero byte there (the "not finished" flag next_state's kernel reads)
+
+
+_move = _MoveScratch()
+
+
+def _alias_set(board, field: str):
+    """The one-environment result set `board` is the (4, 4) alias of, if `field` of that set is current; else None."""
+    if isinstance(board, torch.Tensor):
+        hit = pool.lookup(board)
+        if hit is not None and hit[3] and hit[1] == 'board' and hit[0].has(field):
+            return hit[0]
+    return None
+
+
+def _status_i32(board, *, obs=False, legal=False, done=False):
+    """One env2048_status_i32 launch on a (4, 4) value board that is not a pooled alias -> the requested tensors."""
+    rt = runtime.current()
+    b = _board_tensor(board)
+    dev, stream = rt.handles()
+    o = torch.empty((16,), dtype=torch.float32, device=rt.device) if obs else None
+    l4 = torch.empty((4,), dtype=torch.uint8, device=rt.device) if legal else None
+    d = torch.empty((1,), dtype=torch.uint8, device=rt.device) if done else None
+    rt.lib.status_i32(dev, stream, 1, b.data_ptr(), None if o is None else o.data_ptr(), None if l4 is None else l4.data_ptr(),
+                      None if d is None else d.data_ptr())
+    return o, l4, d
 
 
 def merge_row(row):
@@ -64,21 +109,51 @@ def fill_cells(state, key):
 
 
 def next_state(state, action, key):
-    """[ref core.py:234-272] move + spawn iff the board changed -> (board, reward float32; 0.0 if unchanged)."""
-    packed = _packed(state)
-    out = ops.step(packed, [int(action) & 3], runtime.seed_to_u64(key), 0)
-    return _values(packed), wrap(out['reward'][0].to(torch.float32))
+    """[ref core.py:234-272] move + spawn iff the board changed -> (board, reward float32; 0.0 if unchanged).
+    ONE launch, which also leaves the observation, legal mask, terminal flag and max tile of the new board with it (above)."""
+    rt = runtime.current()
+    src = _alias_set(state, 'board')
+    keep = None
+    if src is not None:
+        board_ptr = src.ptr['board']
+    else:
+        keep = _board_tensor(state)
+        board_ptr = keep.data_ptr()
+    dev, stream = rt.handles()
+    not_done = _move.not_done.get(rt.device)
+    if not_done is None:
+        not_done = _move.not_done[rt.device] = torch.zeros((16,), dtype=torch.uint8, device=rt.device)
+    rs = pool.acquire(1, rt.device, stream or 0)  # (never the set `state` lives in: the caller still holds that one)
+    try:
+        k0, k1 = key_words(key)
+        _move.key[0, 0], _move.key[0, 1] = k0, k1
+        _move.action[0] = int(action) & 3
+        p = rs.ptr
+        rt.lib.step_state_i32_keyed_inline(dev, stream, 1, _move.key_addr, board_ptr, p['board'], _move.action_addr, None, None,
+                                           not_done.data_ptr(), p['done'], None, None, p['reward'], p['max_tile'], p['obs'], p['legal'],
+                                           rs.mirror_delta, rs.seq_ptr if rs.mirror_delta else None, rs.next_serial())
+        rs.mark_written(bool(rs.mirror_delta), bool(rs.mirror_delta) and rs.seq_ptr is not None, NEXT_STATE_FIELDS)
+        if rs.single is not None:
+            return rs.single['board'], rs.single['reward']
+        return wrap(rs.board[0]), wrap(rs.reward[0])
+    finally:
+        rs.leased = False
 
 
 def legal_actions_mask(state):
     """[ref core.py:275-302] bool (4,): action a changes the board. Order [left, up, right, down]."""
-    bits = ops.status(_packed(state), done=False, legal=True)['legal'][0].to(torch.int32)
-    return wrap(((bits >> torch.arange(4, device=bits.device, dtype=torch.int32)) & 1).to(torch.bool))
+    rs = _alias_set(state, 'legal')
+    if rs is not None:
+        return rs.single['legal']
+    return wrap(_status_i32(state, legal=True)[1].view(torch.bool))
 
 
 def is_done(state):
     """[ref core.py:305-321] no legal action (so the all-zero board counts as done, unlike the NumPy engine)."""
-    return ~legal_actions_mask(state).any()
+    rs = _alias_set(state, 'done')
+    if rs is not None:
+        return rs.single['done']
+    return wrap(_status_i32(state, done=True)[2].view(torch.bool)[0])
 
 
 def create_initial_board(key):
@@ -88,11 +163,17 @@ def create_initial_board(key):
 
 def encode_observation(board):
     """[ref core.py:346-377] log2(tile)/16 per cell (0 for empty), flattened to (16,) float32."""
-    return wrap(ops.status(_packed(board), done=False, legal=False, obs=True)['obs'][0])
+    rs = _alias_set(board, 'obs')
+    if rs is not None:
+        return rs.single['obs']
+    return wrap(_status_i32(board, obs=True)[0])
 
 
 def max_tile(board):
     """[ref core.py:427-442] largest tile VALUE on the board."""
+    rs = _alias_set(board, 'max_tile')
+    if rs is not None:
+        return rs.single['max_tile']
     e = ops.status(_packed(board), done=False, legal=False, max_exp=True)['max_exp'][0].to(torch.int32)
     return wrap(torch.where(e > 0, torch.ones_like(e) << e, torch.zeros_like(e)))
 

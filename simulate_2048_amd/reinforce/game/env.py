@@ -24,7 +24,7 @@ import torch
 
 from ... import capi, runtime
 from ...interop import key_words, keys_on_device, to_tensor, wrap
-from ...resultpool import STAGE_MAX_BYTES, pool, stager
+from ...resultpool import RESET_FIELDS, STAGE_MAX_BYTES, pool, stager
 from .core import _board_tensor
 
 
@@ -158,10 +158,10 @@ def batched_reset(keys) -> GameState:
         if rs.mirror_delta:  # pooled set with a pinned host mirror: the launch writes it and (small batches) signals completion
             rt.lib.reset_state_i32_keyed_signalled(dev, stream, n, kptr, p['board'], p['step_count'], p['done'], p['total'], p['obs'],
                                                    p['legal'], rs.mirror_delta, rs.seq_ptr, rs.next_serial())
-            rs.mark_written(True, rs.seq_ptr is not None)
+            rs.mark_written(True, rs.seq_ptr is not None, RESET_FIELDS)
         else:
             rt.lib.reset_state_i32_keyed(dev, stream, n, kptr, p['board'], p['step_count'], p['done'], p['total'], p['obs'], p['legal'], 0)
-            rs.mark_written()
+            rs.mark_written(fields=RESET_FIELDS)
         return GameState(board=rs.board, step_count=rs.step_count, done=rs.done, total_reward=rs.total)
     finally:
         rs.leased = False  # (the state being returned holds the tensors by now; after an error nobody does and the set is free)

@@ -42,6 +42,11 @@ MIRROR_MAX_BYTES = 64 << 10  # result sets up to this size (N <= ~430) are read 
 SIGNAL_TIMEOUT_US = 50  # how long a read polls a launch's completion word before it falls back to synchronising the stream
 
 
+ALL_FIELDS = frozenset(('board', 'obs', 'step_count', 'total', 'done', 'max_tile', 'reward', 'legal'))
+RESET_FIELDS = frozenset(('board', 'obs', 'step_count', 'total', 'done', 'legal'))  # a reset writes no reward / max_tile
+NEXT_STATE_FIELDS = frozenset(('board', 'obs', 'done', 'max_tile', 'reward', 'legal'))  # core.next_state: no bookkeeping fields
+
+
 def _align(x: int, a: int = 16) -> int:
     return (x + a - 1) // a * a
 
@@ -50,7 +55,7 @@ class ResultSet:
     __slots__ = ('n', 'arena', 'storage', 'cdata', 'board', 'obs', 'step_count', 'max_tile', 'total', 'reward', 'legal', 'done',
                  'tensors', 'ptr', 'idle_refs', 'idle_use', 'version', 'pooled', 'leased', 'layout', 'serial',
                  'mirror', 'mirror_fields', 'mirror_key', 'mirror_copies', 'mirror_delta', 'direct_serial', 'stream',
-                 'seq_ptr', 'signal_serial', 'signal_hits', 'stream_syncs', 'wait_sequence', 'single')
+                 'seq_ptr', 'signal_serial', 'signal_hits', 'stream_syncs', 'wait_sequence', 'single', 'fields')
 
     def __init__(self, n: int, device: torch.device):
         self.n = n
@@ -100,6 +105,7 @@ class ResultSet:
                        'done': (offsets['done'], n, np.bool_, (n,)), 'max_tile': (offsets['max_tile'], 4 * n, np.int32, (n,)),
                        'reward': (offsets['reward'], 4 * n, np.float32, (n,)), 'legal': (offsets['legal'], 4 * n, np.bool_, (n, 4))}
         self.serial = 0  # launches that have written this set (kernel writes do not move torch's version counter)
+        self.fields = ALL_FIELDS  # which fields the last launch into this set wrote (a reset writes no reward / max_tile ...)
         self.mirror = None
         self.mirror_fields = None
         self.mirror_key = None
@@ -162,12 +168,13 @@ class ResultSet:
         """The serial the NEXT launch into this set will have (what a *_signalled launch stores into the completion word)."""
         return self.serial + 1
 
-    def mark_written(self, mirrored: bool = False, signalled: bool = False) -> None:
+    def mark_written(self, mirrored: bool = False, signalled: bool = False, fields=None) -> None:
         """A launch has just been given this set to fill: the stash is valid from the current version on.  ``mirrored``: the
         launch writes the host mirror too (it was given ``mirror_delta``); ``signalled``: it also stores ``next_serial()`` into
-        the mirror's completion word when it is done."""
+        the mirror's completion word when it is done; ``fields``: the fields that launch writes (default: all)."""
         self.version = self.arena._version
         self.serial += 1
+        self.fields = ALL_FIELDS if fields is None else fields
         if mirrored:
             self.direct_serial = self.serial
             if signalled:
@@ -203,6 +210,10 @@ class ResultSet:
                 self.mirror_copies += 1
             self.mirror_key = key
         return self.mirror_fields[name]
+
+    def has(self, field: str) -> bool:
+        """`field` holds what the last launch into this set wrote, untouched since."""
+        return field in self.fields and self.arena._version == self.version
 
     def stash_valid(self) -> bool:
         """The set is as the kernel wrote it: no in-place torch operation touched any of its tensors since (they share the

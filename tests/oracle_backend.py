@@ -172,6 +172,15 @@ class OracleLibrary:
         self.step_state_i32_keyed_status(device, stream, n, keys, boards_in, boards_out, actions, step_count_in, step_count_out,
                                          done_in, done_out, total_in, total_out, reward, max_tile, obs, legal4)
 
+    def step_state_i32_keyed_inline(self, device, stream, n, host_keys, boards_in, boards_out, host_actions, step_count_in, step_count_out,
+                                    done_in, done_out, total_in, total_out, reward, max_tile, obs, legal4, host_mirror_delta=0,
+                                    host_sequence=None, sequence_value=0):
+        """Keys / actions come from host memory during the call (here everything is host memory): the _status form on them."""
+        assert host_mirror_delta == 0 and host_sequence is None and n <= 64
+        self.step_state_i32_keyed_status(device, stream, n, host_keys, boards_in, boards_out, host_actions, step_count_in, step_count_out,
+                                         done_in, done_out, total_in, total_out, reward, max_tile, obs, legal4)
+        self.calls[-1] = ('step_state_i32_keyed_inline', n)
+
     def reset_state_i32_keyed(self, device, stream, n, keys, boards, step_count, done, total, obs, legal4, host_mirror_delta=0):
         assert host_mirror_delta == 0, 'the stand-in works on host memory: nothing to mirror'
         self.reset_keyed_i32_status(device, stream, n, keys, boards, obs, legal4)

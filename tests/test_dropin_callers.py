@@ -535,6 +535,54 @@ def test_the_fast_move_path_is_present_on_this_box():
     torch.cuda.synchronize()
 
 
+def test_evaluate_games_loop_on_the_core_functions(api_runtime):
+    """The env-side statements of evaluate_games (reinforce/evaluate.py:88-128) and play_game (reinforce/training/self_play.py:
+    95-135), restated: per move encode_observation(state.board), legal_actions_mask(state.board), next_state(state.board,
+    action, step_key), is_done(new_board), float(reward), state._replace(board=new_board, done=done); max_tile(state.board) at
+    the end.  On the mirrors next_state is ONE launch that also leaves observation / legal mask / terminal flag / max tile of
+    the new board with it, so the other calls launch nothing; every value equals the oracle's keyed step."""
+    resultpool.pool.clear()
+    calls = getattr(api_runtime.lib, 'calls', None)
+    for game in range(3):
+        state = reset(np.array([game, 99], dtype=np.uint32))
+        ref = np.array(state.board).reshape(1, 16).astype(np.int32)
+        cumulative, steps = 0.0, 0
+        mark = len(calls) if calls is not None else 0
+        while not bool(state.done) and steps < 60:
+            obs = encode_observation(state.board)
+            legal_mask = legal_actions_mask(state.board)
+            status = oracle.status_batch(oracle.pack_values(ref).reshape(1, 16))
+            assert np.array_equal(np.array(obs), status['obs'][0]) and np.array(obs).dtype == np.float32
+            legal = np.array(legal_mask)
+            assert legal.dtype == np.bool_ and [int(x) for x in legal] == [(int(status['legal'][0]) >> a) & 1 for a in range(4)]
+            action = int(np.flatnonzero(legal)[-1]) if legal.any() else 0
+            step_key = np.array([steps, 7 + game], dtype=np.uint32)
+            new_board, reward = next_state(state.board, action, step_key)
+            done = is_done(new_board)
+            want = oracle.step_state_i32_keyed(ref, np.array([action], np.int32), np.zeros(1, np.int32), np.zeros(1, np.uint8), np.zeros(1, np.float32),
+                                               step_key.reshape(1, 2))
+            ref = want['boards']
+            assert np.array_equal(np.array(new_board).reshape(1, 16), ref) and float(reward) == float(want['reward'][0])
+            assert bool(done) == bool(want['done'][0]) and int(max_tile(new_board)) == int(want['max_tile'][0])
+            cumulative += float(reward)
+            steps += 1
+            state = state._replace(board=new_board, done=done)
+        assert steps > 10 and int(max_tile(state.board)) == int(ref.max())
+        if calls is not None:  # host logic: from the first move on, ONE library call per move
+            names = [c[0] for c in calls[mark:]]
+            assert names == ['step_state_i32_keyed_inline'] * steps, names[:6]
+    # boards that are nobody's alias take the general path: the same answers
+    plain = torch.as_tensor(ref.reshape(4, 4))
+    status = oracle.status_batch(oracle.pack_values(ref).reshape(1, 16))
+    assert np.array_equal(np.array(encode_observation(plain)), status['obs'][0])
+    assert [int(x) for x in np.array(legal_actions_mask(plain))] == [(int(status['legal'][0]) >> a) & 1 for a in range(4)]
+    assert bool(is_done(plain)) == (int(status['legal'][0]) == 0) and int(max_tile(plain)) == int(ref.max())
+    b2, r2 = next_state(plain, 1, 12345)
+    want = oracle.step_state_i32_keyed(ref, np.array([1], np.int32), np.zeros(1, np.int32), np.zeros(1, np.uint8), np.zeros(1, np.float32),
+                                       np.array([[0, 12345]], dtype=np.uint32))
+    assert np.array_equal(np.array(b2).reshape(1, 16), want['boards']) and float(r2) == float(want['reward'][0])
+
+
 @pytest.mark.gpu
 def test_single_game_loop_runs_on_the_one_environment_result_set():
     """The reference's SINGLE-game loops (reinforce/training/self_play.py:84-135, reinforce/evaluate.py:89-128): per move

@@ -58,3 +58,23 @@ for warm in range(2):
         float(reward)
     dt = (time.perf_counter() - t) / moves * 1e6
 print('reinforce.game single-game move (get_observation + get_legal_actions + step + read-backs): %.1f us' % dt)
+# one move of evaluate_games / play_game on the CORE functions (reinforce/evaluate.py:96-128): encode_observation, legal_actions_mask,
+# next_state, is_done, float(reward), _replace
+from simulate_2048_amd.reinforce.game.core import encode_observation, is_done, legal_actions_mask, max_tile, next_state  # noqa: E402
+
+state = genv.reset(11)
+for warm in range(2):
+    t = time.perf_counter()
+    for m in range(moves):
+        obs = np.array(encode_observation(state.board))
+        legal = np.array(legal_actions_mask(state.board))
+        action = int(np.flatnonzero(legal)[0]) if legal.any() else 0
+        new_board, reward = next_state(state.board, action, [m, 321])
+        done = is_done(new_board)
+        float(reward)
+        state = state._replace(board=new_board, done=done)
+        if bool(state.done):
+            int(max_tile(state.board))
+            state = genv.reset(2000 + m)
+    dt = (time.perf_counter() - t) / moves * 1e6
+print('reinforce.game evaluate_games move on the core functions (encode_observation + legal_actions_mask + next_state + is_done + read-backs): %.1f us' % dt)
