@@ -207,6 +207,28 @@ class ScalarOps:
         return self.values_nxn(nb['outcomes'][1][:2 * cells * cells].reshape(2 * cells, cells)[:count], size, dtype), count
 
 
+    # -- one-hot observation of up to 64 cells (encode / encode_flatten of twentyfortyeight/utils/binary.py) ------------------------
+    ONEHOT_MAX_CELLS = 64
+    ONEHOT_MAX_WIDTH = 64
+
+    def onehot(self, values, width: int) -> np.ndarray:
+        """(cells,) tile values -> (cells, width) 0/1 bytes: eye(width)[log2(value)] with 0 staying index 0, computed by
+        env2048_encode_onehot on pinned host operands (one launch + one polled completion word, like the other single-board
+        calls).  `cells` is padded to whole 16-cell records for the kernel and trimmed again."""
+        flat = np.asarray(values).reshape(-1)
+        cells = flat.shape[0]
+        nb = self._nxn_buffers()
+        board = nb['board'][1]
+        board[:] = 0
+        for i, v in enumerate(flat.tolist()):
+            board[i] = (int(v).bit_length() - 1) & 0xFF if v > 0 else 0
+        records = (cells + 15) // 16
+        dev, stream = self.rt.handles()
+        self.rt.lib.encode_onehot(dev, stream, records, nb['board'][2], int(width), nb['outcomes'][2])
+        self._sync()
+        return nb['outcomes'][1][:records * 16 * width].reshape(records * 16, width)[:cells].copy()
+
+
 _per_thread = threading.local()
 
 
