@@ -174,10 +174,9 @@ def max_tile(board):
     rs = _alias_set(board, 'max_tile')
     if rs is not None:
         return rs.single['max_tile']
-    e = ops.status(_packed(board), done=False, legal=False, max_exp=True)['max_exp'][0].to(torch.int32)
-    return wrap(torch.where(e > 0, torch.ones_like(e) << e, torch.zeros_like(e)))
+    return wrap(_board_tensor(board).max())  # (a board nobody's launch has described: one reduction over its 16 values)
 
 
 def count_empty(board):
     """[ref core.py:445-460] number of empty cells."""
-    return wrap(ops.status(_packed(board), done=False, legal=False, n_empty=True)['n_empty'][0].to(torch.int32))
+    return wrap((_board_tensor(board) == 0).sum().to(torch.int32))
