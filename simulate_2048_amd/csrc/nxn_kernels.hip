@@ -3,10 +3,14 @@
 // The reference's core functions take boards of any shape and its env has a `size` argument
 // (twentyfortyeight/envs/twentyfortyeight.py:21; its own timing script runs 4 / 6 / 8, tests/test_perf_utils.py:47).  The hot
 // path of this library is the packed 4 x 4 board (step_kernels.hip); this file is the general form behind the same API
-// mirrors: one byte per cell, row-major, ONE BOARD PER LANE with the board held in LDS as cells[c][lane] (a lane's accesses
-// to cell c hit consecutive bytes across the wave: four lanes per bank word, conflict-free), every line walked by plain
-// loops.  A compatibility path sized for the reference's use (single boards, small batches), not a throughput path: for
-// S = 4 it returns exactly what the packed kernels return (tests/test_nxn.py), about 20 x slower per board.
+// mirrors: one byte per cell, row-major, ONE BOARD PER LANE, the board size a template parameter (seven instantiations of
+// every kernel, chosen on the host), the board in registers and all game logic branch-free SWAR with four lines per dword
+// (nxn_ops.hpp).  Memory traffic goes through a wave-private LDS strip: the 64 boards of a wave are 64 S S CONTIGUOUS bytes,
+// fetched and written back as whole 16-byte vectors by the wave together (coalesced whatever S is) and picked up from /
+// dropped into the strip by each lane in between (lane stride padded to an odd number of dwords for the even sizes; funnel
+// shifts for the odd ones, whose boards do not start on dword boundaries).  A wave at the ragged end of the batch, or a batch
+// that does not start on a 16-byte boundary, takes a per-lane byte path instead.
+// For S = 4 every entry point returns exactly what the packed kernels return (tests/test_nxn.py).
 // Same RNG contract: the step word of (seed, env, step) picks the spawn, a fresh board takes two sequential spawns from the
 // reset block (cell ranks over S*S and S*S - 1 empties).
 #include <hip/hip_runtime.h>
@@ -14,6 +18,7 @@
 
 #include "env2048.h"
 #include "board_ops.hpp"
+#include "nxn_ops.hpp"
 #include "tiling.hpp"
 #include "device_scope.hpp"
 
@@ -22,239 +27,239 @@ using namespace env2048::host;
 
 namespace {
 
-constexpr int NXN_BLOCK = 64;  // one wave per block: a lane's board is private, nothing is shared
+constexpr int NXN_BLOCK = 256;
+constexpr int NXN_WAVES = NXN_BLOCK / 64;
 constexpr int NXN_MAX = ENV2048_NXN_MAX_SIZE;
 constexpr int NXN_MAX_CELLS = NXN_MAX * NXN_MAX;
 
-struct Cells {  // the calling lane's board in LDS
-    uint8_t *base;  // &cells[0][lane]
-    uint32_t S;
-    __device__ __forceinline__ uint32_t get(uint32_t c) const { return base[c * NXN_BLOCK]; }
-    __device__ __forceinline__ void set(uint32_t c, uint32_t v) const { base[c * NXN_BLOCK] = (uint8_t)v; }
-    __device__ __forceinline__ uint32_t count() const { return S * S; }
+// ---- the wave's boards: global memory <-> LDS strip <-> registers -------------------------------------------------------------
+template <int S>
+struct Strip {
+    using Sh = nxn::Shape<S>;
+    static constexpr bool WHOLE = Sh::CELLS % 4 == 0;  // boards start on dword boundaries (even S)
+    static constexpr int D = Sh::DENSE;
+    // lane stride in the strip, in dwords: odd (or 1), so that the lanes' reads of dword i fall into different banks
+    static constexpr int STRIDE = (WHOLE && D > 1 && D % 2 == 0) ? D + 1 : D;
+    static constexpr bool PADDED = WHOLE && STRIDE != D;
+    static constexpr int VECTORS = 4 * Sh::CELLS;  // 16-byte vectors in the 64 boards of a wave
+    static constexpr int ROUNDS = (VECTORS + 63) / 64;
+    static constexpr int DWORDS = (WHOLE ? 64 * STRIDE : 16 * Sh::CELLS) + 4;  // (+ slack: the funnel reads one dword ahead)
 };
 
-__device__ __forceinline__ void load_cells(const Cells &b, const uint8_t *boards, uint64_t i)
+__device__ __forceinline__ void strip_fence()
 {
-    const uint8_t *src = boards + i * b.count();
-    for (uint32_t c = 0; c < b.count(); ++c) b.set(c, src[c]);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the strip is wave-private: LDS operations of a wave are ordered
+    __builtin_amdgcn_wave_barrier();
 }
 
-__device__ __forceinline__ void store_cells(const Cells &b, uint8_t *boards, uint64_t i)
+// boards [first, first + 64) of the batch -> `b` of every lane (lanes past the end of the batch: an empty board)
+template <int S>
+__device__ __forceinline__ void load_board(uint32_t *strip, const uint8_t *boards, uint64_t first, uint64_t n, uint32_t lane, nxn::Rows<S> &b)
 {
-    uint8_t *dst = boards + i * b.count();
-    for (uint32_t c = 0; c < b.count(); ++c) dst[c] = (uint8_t)b.get(c);
-}
-
-// Cell k (counted from the wall the tiles move to) of line j of a move: 0 left, 1 up, 2 right, 3 down -- the directions
-// rot90(k = action) + "slide left" + rot90 back give [ref: gameboard.py:127-129; pinned by tests/test_jax_game.py:101-135].
-__device__ __forceinline__ uint32_t line_cell(uint32_t action, uint32_t j, uint32_t k, uint32_t S)
-{
-    const uint32_t kk = (action & 2u) ? S - 1u - k : k;
-    return (action & 1u) ? kk * S + j : j * S + kk;
-}
-
-// Slide + merge every line of the board towards the wall of `action`, in place [ref: gameboard.py:23-69 merge_column,
-// :72-102 slide_and_merge, :105-129 latent_state]: drop zeros, merge equal neighbours from the wall outward, each tile
-// merging at most once; score = sum of the merged VALUES.  `changed` == can_move(rot90(board, action)) [gamemove.py:132-164].
-__device__ __forceinline__ uint32_t nxn_move(const Cells &b, uint32_t action, bool &changed)
-{
-    const uint32_t S = b.S;
-    uint32_t score = 0u;
-    changed = false;
-    for (uint32_t j = 0; j < S; ++j) {
-        uint32_t v[NXN_MAX];
+    using St = Strip<S>;
+    const uint8_t *src = boards + first * St::Sh::CELLS;
+    uint32_t dense[St::D];
+    if (n - first >= 64u && ((uintptr_t)src & 15u) == 0u) {  // (wave-uniform)
+        const uint4 *vec = reinterpret_cast<const uint4 *>(src);
 #pragma unroll
-        for (uint32_t k = 0; k < (uint32_t)NXN_MAX; ++k) v[k] = k < S ? b.get(line_cell(action, j, k, S)) : 0u;  // the whole line first:
-        uint32_t w = 0u, last = 0u;  // w = cells written so far; last = the tile at w - 1 if it may still merge   (written in place below)
-#pragma unroll
-        for (uint32_t k = 0; k < (uint32_t)NXN_MAX; ++k) {
-            const uint32_t x = v[k];
-            if (x != 0u) {
-                if (x == last) {  // merges into the tile before it; that tile is spent
-                    b.set(line_cell(action, j, w - 1u, S), x + 1u);
-                    score += 1u << ((x + 1u) & 31u);
-                    last = 0u;
-                    changed = true;
+        for (int round = 0; round < St::ROUNDS; ++round) {
+            const uint32_t q = lane + 64u * round;
+            if (q < (uint32_t)St::VECTORS) {
+                const uint4 v = vec[q];
+                if (St::PADDED) {
+                    const uint32_t at = (4u * q / St::D) * St::STRIDE + 4u * q % St::D;  // D is 4 or 16 here: a vector never straddles boards
+                    strip[at] = v.x;
+                    strip[at + 1] = v.y;
+                    strip[at + 2] = v.z;
+                    strip[at + 3] = v.w;
                 } else {
-                    changed = changed || k != w;  // it moves iff a gap (or a merge) lies between it and the wall
-                    b.set(line_cell(action, j, w, S), x);
-                    last = x;
-                    ++w;
+                    reinterpret_cast<uint4 *>(strip)[q] = v;
                 }
             }
         }
-        for (uint32_t k = w; k < S; ++k) b.set(line_cell(action, j, k, S), 0u);
-    }
-    return score;
-}
-
-__device__ __forceinline__ uint32_t nxn_count_empty(const Cells &b)
-{
-    uint32_t n = 0u;
-    for (uint32_t c = 0; c < b.count(); ++c) n += b.get(c) == 0u ? 1u : 0u;
-    return n;
-}
-
-// exponent e into the k-th empty cell in row-major order [ref: gameboard.py:275,287 argwhere order]; k out of range: nothing
-__device__ __forceinline__ void nxn_place(const Cells &b, uint32_t k, uint32_t e)
-{
-    uint32_t seen = 0u;
-    for (uint32_t c = 0; c < b.count(); ++c) {
-        if (b.get(c) == 0u) {
-            if (seen == k) {
-                b.set(c, e);
-                return;
-            }
-            ++seen;
+        strip_fence();
+        if (St::WHOLE) {
+#pragma unroll
+            for (int i = 0; i < St::D; ++i) dense[i] = strip[lane * St::STRIDE + i];
+        } else {
+            const uint32_t byte = lane * St::Sh::CELLS, base = byte >> 2, shift = byte & 3u;
+            uint32_t raw[St::D + 1];
+#pragma unroll
+            for (int i = 0; i <= St::D; ++i) raw[i] = strip[base + i];
+#pragma unroll
+            for (int i = 0; i < St::D; ++i) dense[i] = __builtin_amdgcn_alignbyte(raw[i + 1], raw[i], shift);
+            dense[St::D - 1] &= nxn::low_bytes(St::Sh::CELLS - 4 * (St::D - 1));
+        }
+        strip_fence();
+    } else {
+#pragma unroll
+        for (int i = 0; i < St::D; ++i) dense[i] = 0u;
+        if (first + lane < n) {
+            const uint8_t *mine = src + (size_t)lane * St::Sh::CELLS;
+#pragma unroll
+            for (int c = 0; c < St::Sh::CELLS; ++c) dense[c >> 2] |= (uint32_t)mine[c] << (8 * (c & 3));
         }
     }
+    nxn::rows_from_dense<S>(dense, b);
 }
 
-// one spawn from a step word (RNG contract of include/env2048.h) [ref: gameboard.py:247-288 fill_cells, number_tile = 1]
-__device__ __forceinline__ void nxn_spawn_word(const Cells &b, uint32_t word)
+template <int S>
+__device__ __forceinline__ void store_board(uint32_t *strip, uint8_t *boards, uint64_t first, uint64_t n, uint32_t lane, const nxn::Rows<S> &b)
 {
-    const uint32_t n_empty = nxn_count_empty(b);
-    if (n_empty == 0u) return;
-    const uint64_t prod = (uint64_t)(word & ~3u) * (uint64_t)n_empty;
-    nxn_place(b, (uint32_t)(prod >> 32), (uint32_t)prod < SPAWN4_THRESHOLD ? 2u : 1u);
-}
-
-// zeros + two sequential spawns from one reset block [ref: twentyfortyeight.py:100-101]
-__device__ __forceinline__ void nxn_fresh(const Cells &b, const RngKey &key, uint64_t env)
-{
-    uint32_t w0, w1, w2, w3;
-    env_block(key, env, STREAM_RESET, w0, w1, w2, w3);
-    for (uint32_t c = 0; c < b.count(); ++c) b.set(c, 0u);
-    nxn_place(b, mulhi32(w0, b.count()), w1 < SPAWN4_THRESHOLD ? 2u : 1u);
-    nxn_place(b, mulhi32(w2, b.count() - 1u), w3 < SPAWN4_THRESHOLD ? 2u : 1u);
-}
-
-// [ref: gameboard.py:328-348 is_done] + [gamemove.py:45-83 legal_actions_mask] in one walk over the adjacent pairs
-__device__ __forceinline__ void nxn_status(const Cells &b, bool &done, uint32_t &legal, uint32_t &n_empty, uint32_t &max_exp)
-{
-    const uint32_t S = b.S;
-    bool h_merge = false, v_merge = false, left = false, right = false, up = false, down = false;
-    n_empty = 0u;
-    max_exp = 0u;
-    for (uint32_t r = 0; r < S; ++r)
-        for (uint32_t c = 0; c < S; ++c) {
-            const uint32_t x = b.get(r * S + c);
-            n_empty += x == 0u ? 1u : 0u;
-            max_exp = max(max_exp, x);
-            if (c + 1u < S) {
-                const uint32_t y = b.get(r * S + c + 1u);
-                h_merge = h_merge || (x != 0u && x == y);
-                left = left || (x == 0u && y != 0u);
-                right = right || (y == 0u && x != 0u);
-            }
-            if (r + 1u < S) {
-                const uint32_t y = b.get((r + 1u) * S + c);
-                v_merge = v_merge || (x != 0u && x == y);
-                up = up || (x == 0u && y != 0u);
-                down = down || (y == 0u && x != 0u);
+    using St = Strip<S>;
+    uint8_t *dst = boards + first * St::Sh::CELLS;
+    uint32_t dense[St::D];
+    nxn::dense_from_rows<S>(b, dense);
+    if (n - first >= 64u && ((uintptr_t)dst & 15u) == 0u) {
+        if (St::WHOLE) {
+#pragma unroll
+            for (int i = 0; i < St::D; ++i) strip[lane * St::STRIDE + i] = dense[i];
+        } else {  // neighbouring lanes share dwords: byte stores
+            uint8_t *bytes = reinterpret_cast<uint8_t *>(strip) + lane * St::Sh::CELLS;
+#pragma unroll
+            for (int c = 0; c < St::Sh::CELLS; ++c) bytes[c] = (uint8_t)(dense[c >> 2] >> (8 * (c & 3)));
+        }
+        strip_fence();
+        uint4 *vec = reinterpret_cast<uint4 *>(dst);
+#pragma unroll
+        for (int round = 0; round < St::ROUNDS; ++round) {
+            const uint32_t q = lane + 64u * round;
+            if (q < (uint32_t)St::VECTORS) {
+                uint4 v;
+                if (St::PADDED) {
+                    const uint32_t at = (4u * q / St::D) * St::STRIDE + 4u * q % St::D;
+                    v = make_uint4(strip[at], strip[at + 1], strip[at + 2], strip[at + 3]);
+                } else {
+                    v = reinterpret_cast<const uint4 *>(strip)[q];
+                }
+                vec[q] = v;
             }
         }
-    legal = ((left || h_merge) ? 1u : 0u) | ((up || v_merge) ? 2u : 0u) | ((right || h_merge) ? 4u : 0u) | ((down || v_merge) ? 8u : 0u);
-    done = n_empty == 0u && !h_merge && !v_merge;
+        strip_fence();
+    } else if (first + lane < n) {
+        uint8_t *mine = dst + (size_t)lane * St::Sh::CELLS;
+#pragma unroll
+        for (int c = 0; c < St::Sh::CELLS; ++c) mine[c] = (uint8_t)(dense[c >> 2] >> (8 * (c & 3)));
+    }
 }
 
-__device__ __forceinline__ uint32_t nxn_step_word(const RngKey &key, uint64_t env)
-{
-    uint32_t w[4];
-    env_block(key, env >> 2, STREAM_STEP, w[0], w[1], w[2], w[3]);
-    const uint32_t sel = (uint32_t)env & 3u;
-    return sel == 0u ? w[0] : sel == 1u ? w[1] : sel == 2u ? w[2] : w[3];
-}
+#define NXN_PROLOGUE(S)                                                                      \
+    __shared__ __attribute__((aligned(16))) uint32_t strips[NXN_WAVES][Strip<S>::DWORDS];    \
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;                        \
+    const uint64_t first = ((uint64_t)blockIdx.x * NXN_WAVES + wave) * 64u;                  \
+    if (first >= n) return; /* (a whole wave: there is no block-wide barrier below) */       \
+    uint32_t *const strip = strips[wave];                                                    \
+    const uint64_t i = first + lane;                                                         \
+    const bool active = i < n;
 
-#define NXN_PROLOGUE                                                        \
-    __shared__ uint8_t cells_lds[NXN_MAX_CELLS][NXN_BLOCK];                 \
-    const uint64_t i = (uint64_t)blockIdx.x * NXN_BLOCK + threadIdx.x;      \
-    if (i >= n) return;                                                     \
-    const Cells b{&cells_lds[0][threadIdx.x], size};
-
-__global__ __launch_bounds__(NXN_BLOCK) void nxn_afterstate_kernel(uint64_t n, uint32_t size, const uint8_t *boards_in, const uint8_t *actions,
-                                                                  uint8_t *boards_out, int32_t *reward, uint8_t *changed_out)
+template <int S>
+__global__ __launch_bounds__(NXN_BLOCK) void nxn_afterstate_kernel(uint64_t n, const uint8_t *boards_in, const uint8_t *actions, uint8_t *boards_out,
+                                                                  int32_t *reward, uint8_t *changed_out)
 {
-    NXN_PROLOGUE
-    load_cells(b, boards_in, i);
+    NXN_PROLOGUE(S)
+    nxn::Rows<S> b;
+    load_board<S>(strip, boards_in, first, n, lane, b);
+    uint32_t score;
     bool changed;
-    const uint32_t score = nxn_move(b, actions[i] & 3u, changed);
-    store_cells(b, boards_out, i);
+    nxn::afterstate<S>(b, active ? actions[i] & 3u : 0u, score, changed);
+    store_board<S>(strip, boards_out, first, n, lane, b);
+    if (!active) return;
     if (reward) reward[i] = (int32_t)score;
     if (changed_out) changed_out[i] = changed ? 1 : 0;
 }
 
 // [ref: gameboard.py:291-325 next_state + twentyfortyeight.py:106-133 step] one transition per board, in place
-__global__ __launch_bounds__(NXN_BLOCK) void nxn_step_kernel(uint64_t n, uint32_t size, uint64_t env_base, uint8_t *boards, const uint8_t *actions,
-                                                            int32_t *reward, uint8_t *done_out, uint8_t *legal_out, RngKey key, uint32_t flags)
+template <int S>
+__global__ __launch_bounds__(NXN_BLOCK) void nxn_step_kernel(uint64_t n, uint64_t env_base, uint8_t *boards, const uint8_t *actions, int32_t *reward,
+                                                            uint8_t *done_out, uint8_t *legal_out, RngKey key, uint32_t flags)
 {
-    NXN_PROLOGUE
-    load_cells(b, boards, i);
-    const uint64_t env = env_base + i;
-    const uint32_t word = nxn_step_word(key, env);
-    const uint32_t action = (flags & ENV2048_FLAG_RANDOM_ACTIONS) ? word & 3u : actions[i] & 3u;
-    bool changed, done;
-    const uint32_t score = nxn_move(b, action, changed);  // an invalid move leaves the board as it was and scores 0
-    if (changed) nxn_spawn_word(b, word);
-    uint32_t legal, n_empty, max_exp;
-    nxn_status(b, done, legal, n_empty, max_exp);
-    if (done && (flags & ENV2048_FLAG_AUTO_RESET)) {
-        nxn_fresh(b, key, env);
-        if (legal_out) {
-            bool d2;
-            nxn_status(b, d2, legal, n_empty, max_exp);
-        }
-    }
-    store_cells(b, boards, i);
+    NXN_PROLOGUE(S)
+    nxn::Rows<S> b;
+    load_board<S>(strip, boards, first, n, lane, b);
+    const bool random_action = (flags & ENV2048_FLAG_RANDOM_ACTIONS) != 0u;
+    uint32_t score, legal;
+    bool done;
+    nxn::step_board<S>(b, key, env_base + i, (active && !random_action) ? actions[i] : 0u, random_action, (flags & ENV2048_FLAG_AUTO_RESET) != 0u,
+                       score, done, legal);
+    store_board<S>(strip, boards, first, n, lane, b);
+    if (!active) return;
     if (reward) reward[i] = (int32_t)score;
     done_out[i] = done ? 1 : 0;
     if (legal_out) legal_out[i] = (uint8_t)legal;
 }
 
-__global__ __launch_bounds__(NXN_BLOCK) void nxn_status_kernel(uint64_t n, uint32_t size, const uint8_t *boards, uint8_t *done_out, uint8_t *legal_out,
-                                                              uint8_t *n_empty_out, uint8_t *max_exp_out)
+template <int S>
+__global__ __launch_bounds__(NXN_BLOCK) void nxn_status_kernel(uint64_t n, const uint8_t *boards, uint8_t *done_out, uint8_t *legal_out, uint8_t *n_empty_out,
+                                                              uint8_t *max_exp_out)
 {
-    NXN_PROLOGUE
-    load_cells(b, boards, i);
+    NXN_PROLOGUE(S)
+    nxn::Rows<S> b;
+    load_board<S>(strip, boards, first, n, lane, b);
     bool done;
-    uint32_t legal, n_empty, max_exp;
-    nxn_status(b, done, legal, n_empty, max_exp);
+    uint32_t legal, n_empty;
+    nxn::status<S>(b, done, legal, n_empty);
+    if (!active) return;
     if (done_out) done_out[i] = done ? 1 : 0;
     if (legal_out) legal_out[i] = (uint8_t)legal;
     if (n_empty_out) n_empty_out[i] = (uint8_t)n_empty;
-    if (max_exp_out) max_exp_out[i] = (uint8_t)max_exp;
+    if (max_exp_out) max_exp_out[i] = (uint8_t)nxn::max_exponent<S>(b);
 }
 
-__global__ __launch_bounds__(NXN_BLOCK) void nxn_reset_kernel(uint64_t n, uint32_t size, uint64_t env_base, uint8_t *boards, uint8_t *done_out, RngKey key)
+template <int S>
+__global__ __launch_bounds__(NXN_BLOCK) void nxn_reset_kernel(uint64_t n, uint64_t env_base, uint8_t *boards, uint8_t *done_out, RngKey key)
 {
-    NXN_PROLOGUE
-    nxn_fresh(b, key, env_base + i);
-    store_cells(b, boards, i);
-    if (done_out) done_out[i] = 0;
+    NXN_PROLOGUE(S)
+    nxn::Rows<S> b;
+    uint32_t w0, w1, w2, w3;
+    env_block(key, env_base + i, STREAM_RESET, w0, w1, w2, w3);
+    nxn::fresh<S>(b, w0, w1, w2, w3);
+    store_board<S>(strip, boards, first, n, lane, b);
+    if (active && done_out) done_out[i] = 0;
 }
 
-__global__ __launch_bounds__(NXN_BLOCK) void nxn_spawn_random_kernel(uint64_t n, uint32_t size, uint64_t env_base, uint8_t *boards, uint32_t seed_lo,
-                                                                    uint32_t seed_hi, uint64_t step_index, uint32_t count)
+template <int S>
+__global__ __launch_bounds__(NXN_BLOCK) void nxn_spawn_random_kernel(uint64_t n, uint64_t env_base, uint8_t *boards, uint32_t seed_lo, uint32_t seed_hi,
+                                                                    uint64_t step_index, uint32_t count)
 {
-    NXN_PROLOGUE
-    load_cells(b, boards, i);
+    NXN_PROLOGUE(S)
+    nxn::Rows<S> b;
+    load_board<S>(strip, boards, first, n, lane, b);
     for (uint32_t t = 0; t < count; ++t) {
         const uint64_t step = step_index + t;
-        nxn_spawn_word(b, nxn_step_word(RngKey{seed_lo, seed_hi, (uint32_t)step, (uint32_t)(step >> 32)}, env_base + i));
+        nxn::spawn_word<S>(b, nxn::step_word(RngKey{seed_lo, seed_hi, (uint32_t)step, (uint32_t)(step >> 32)}, env_base + i), true);
     }
-    store_cells(b, boards, i);
+    store_board<S>(strip, boards, first, n, lane, b);
+    (void)active;
 }
 
+// ---- chance outcomes: 2 S S slots of S S bytes per board, written cell by cell (one board per lane, the board in LDS as
+// cells[c][lane]: a lane's accesses to cell c hit consecutive bytes across the wave) ---------------------------------------------
+constexpr int OUTCOMES_BLOCK = 64;
+
+struct Cells {  // the calling lane's board in LDS
+    uint8_t *base;  // &cells[0][lane]
+    uint32_t S;
+    __device__ __forceinline__ uint32_t get(uint32_t c) const { return base[c * OUTCOMES_BLOCK]; }
+    __device__ __forceinline__ void set(uint32_t c, uint32_t v) const { base[c * OUTCOMES_BLOCK] = (uint8_t)v; }
+    __device__ __forceinline__ uint32_t count() const { return S * S; }
+};
+
 // [ref: gameboard.py:132-171 after_state] every (empty cell, value) outcome: 2 S S slots of S S bytes per board
-__global__ __launch_bounds__(NXN_BLOCK) void nxn_chance_outcomes_kernel(uint64_t n, uint32_t size, const uint8_t *boards, uint8_t *out, uint8_t *count_out)
+__global__ __launch_bounds__(OUTCOMES_BLOCK) void nxn_chance_outcomes_kernel(uint64_t n, uint32_t size, const uint8_t *boards, uint8_t *out, uint8_t *count_out)
 {
-    NXN_PROLOGUE
-    load_cells(b, boards, i);
+    __shared__ uint8_t cells_lds[NXN_MAX_CELLS][OUTCOMES_BLOCK];
+    const uint64_t i = (uint64_t)blockIdx.x * OUTCOMES_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const Cells b{&cells_lds[0][threadIdx.x], size};
     const uint32_t cells = b.count();
+    uint32_t n_empty = 0u;
+    for (uint32_t c = 0; c < cells; ++c) {
+        const uint32_t x = boards[i * cells + c];
+        b.set(c, x);
+        n_empty += x == 0u ? 1u : 0u;
+    }
     uint8_t *slots = out + i * 2u * cells * cells;
     for (uint32_t t = 0; t < 2u * cells * cells; ++t) slots[t] = 0;
-    const uint32_t n_empty = nxn_count_empty(b);
     if (n_empty == 0u) {  // :156-157 a full board: itself
         for (uint32_t c = 0; c < cells; ++c) slots[c] = (uint8_t)b.get(c);
         count_out[i] = 1;
@@ -280,6 +285,18 @@ int check_nxn(const char *who, uint64_t n, uint32_t size)
 
 inline dim3 nxn_grid(uint64_t n) { return dim3((unsigned)((n + NXN_BLOCK - 1) / NXN_BLOCK)); }
 
+// the instantiation of KERNEL for board size `size` (validated by check_nxn), launched on `grid` x NXN_BLOCK
+#define NXN_LAUNCH(KERNEL, size, grid, stream, ...)                                                                \
+    switch (size) {                                                                                                \
+    case 2: hipLaunchKernelGGL(KERNEL<2>, grid, dim3(NXN_BLOCK), 0, (hipStream_t)(stream), __VA_ARGS__); break;   \
+    case 3: hipLaunchKernelGGL(KERNEL<3>, grid, dim3(NXN_BLOCK), 0, (hipStream_t)(stream), __VA_ARGS__); break;   \
+    case 4: hipLaunchKernelGGL(KERNEL<4>, grid, dim3(NXN_BLOCK), 0, (hipStream_t)(stream), __VA_ARGS__); break;   \
+    case 5: hipLaunchKernelGGL(KERNEL<5>, grid, dim3(NXN_BLOCK), 0, (hipStream_t)(stream), __VA_ARGS__); break;   \
+    case 6: hipLaunchKernelGGL(KERNEL<6>, grid, dim3(NXN_BLOCK), 0, (hipStream_t)(stream), __VA_ARGS__); break;   \
+    case 7: hipLaunchKernelGGL(KERNEL<7>, grid, dim3(NXN_BLOCK), 0, (hipStream_t)(stream), __VA_ARGS__); break;   \
+    default: hipLaunchKernelGGL(KERNEL<8>, grid, dim3(NXN_BLOCK), 0, (hipStream_t)(stream), __VA_ARGS__); break;  \
+    }
+
 }  // namespace
 
 extern "C" {
@@ -293,7 +310,7 @@ int env2048_nxn_afterstate(int device, void *stream, uint64_t n, uint32_t size, 
     if (misaligned(reward, 4)) return fail(ENV2048_ERR_ALIGNMENT, "env2048_nxn_afterstate: reward must be 4-byte aligned");
     DeviceScope scope(device);
     if (scope.rc) return scope.rc;
-    hipLaunchKernelGGL(nxn_afterstate_kernel, nxn_grid(n), dim3(NXN_BLOCK), 0, (hipStream_t)stream, n, size, boards_in, actions, boards_out, reward, changed);
+    NXN_LAUNCH(nxn_afterstate_kernel, size, nxn_grid(n), stream, n, boards_in, actions, boards_out, reward, changed)
     return launched("env2048_nxn_afterstate launch");
 }
 
@@ -310,7 +327,7 @@ int env2048_nxn_step(int device, void *stream, uint64_t n, uint32_t size, uint64
     DeviceScope scope(device);
     if (scope.rc) return scope.rc;
     const RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)step_index, (uint32_t)(step_index >> 32)};
-    hipLaunchKernelGGL(nxn_step_kernel, nxn_grid(n), dim3(NXN_BLOCK), 0, (hipStream_t)stream, n, size, env_base, boards, actions, reward, done, legal, key, flags);
+    NXN_LAUNCH(nxn_step_kernel, size, nxn_grid(n), stream, n, env_base, boards, actions, reward, done, legal, key, flags)
     return launched("env2048_nxn_step launch");
 }
 
@@ -322,7 +339,7 @@ int env2048_nxn_status(int device, void *stream, uint64_t n, uint32_t size, cons
     if (!boards) return fail(ENV2048_ERR_INVALID_ARG, "env2048_nxn_status: boards is NULL");
     DeviceScope scope(device);
     if (scope.rc) return scope.rc;
-    hipLaunchKernelGGL(nxn_status_kernel, nxn_grid(n), dim3(NXN_BLOCK), 0, (hipStream_t)stream, n, size, boards, done, legal, n_empty, max_exp);
+    NXN_LAUNCH(nxn_status_kernel, size, nxn_grid(n), stream, n, boards, done, legal, n_empty, max_exp)
     return launched("env2048_nxn_status launch");
 }
 
@@ -336,7 +353,7 @@ int env2048_nxn_reset(int device, void *stream, uint64_t n, uint32_t size, uint6
     DeviceScope scope(device);
     if (scope.rc) return scope.rc;
     const RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)step_index, (uint32_t)(step_index >> 32)};
-    hipLaunchKernelGGL(nxn_reset_kernel, nxn_grid(n), dim3(NXN_BLOCK), 0, (hipStream_t)stream, n, size, env_base, boards, done, key);
+    NXN_LAUNCH(nxn_reset_kernel, size, nxn_grid(n), stream, n, env_base, boards, done, key)
     return launched("env2048_nxn_reset launch");
 }
 
@@ -350,8 +367,7 @@ int env2048_nxn_spawn_random(int device, void *stream, uint64_t n, uint32_t size
     if (step_index + count < step_index) return fail(ENV2048_ERR_RANGE, "env2048_nxn_spawn_random: step_index + count overflows");
     DeviceScope scope(device);
     if (scope.rc) return scope.rc;
-    hipLaunchKernelGGL(nxn_spawn_random_kernel, nxn_grid(n), dim3(NXN_BLOCK), 0, (hipStream_t)stream, n, size, env_base, boards, (uint32_t)seed,
-                       (uint32_t)(seed >> 32), step_index, count);
+    NXN_LAUNCH(nxn_spawn_random_kernel, size, nxn_grid(n), stream, n, env_base, boards, (uint32_t)seed, (uint32_t)(seed >> 32), step_index, count)
     return launched("env2048_nxn_spawn_random launch");
 }
 
@@ -362,7 +378,8 @@ int env2048_nxn_chance_outcomes(int device, void *stream, uint64_t n, uint32_t s
     if (!boards || !out_boards || !out_count) return fail(ENV2048_ERR_INVALID_ARG, "env2048_nxn_chance_outcomes: NULL argument");
     DeviceScope scope(device);
     if (scope.rc) return scope.rc;
-    hipLaunchKernelGGL(nxn_chance_outcomes_kernel, nxn_grid(n), dim3(NXN_BLOCK), 0, (hipStream_t)stream, n, size, boards, out_boards, out_count);
+    hipLaunchKernelGGL(nxn_chance_outcomes_kernel, dim3((unsigned)((n + OUTCOMES_BLOCK - 1) / OUTCOMES_BLOCK)), dim3(OUTCOMES_BLOCK), 0, (hipStream_t)stream, n, size, boards, out_boards,
+                       out_count);
     return launched("env2048_nxn_chance_outcomes launch");
 }
 
