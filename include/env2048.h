@@ -642,9 +642,10 @@ ENV2048_EXPORT int env2048_expectimax_backup(int device, void *stream, uint64_t 
  * the step word of (seed, env_base + i, step_index) picks the spawn (cell rank over the board's empty cells in row-major
  * order), a fresh board takes two sequential spawns from the reset block with cell ranks floor(r0 * S*S / 2^32) and
  * floor(r2 * (S*S - 1) / 2^32) -- so for S = 4 they return exactly what env2048_afterstate / _step / _status / _reset /
- * _spawn_random / _chance_outcomes return.  A general, loop-based kernel (one board per lane, the board in LDS): a
- * compatibility path for single boards and small batches, not the throughput path.  Scores are int32: exponents above 30
- * are outside the domain, as for the packed path.
+ * _spawn_random / _chance_outcomes return.  One board per lane, the board in registers, the size a template parameter of
+ * the kernels (csrc/nxn_ops.hpp); batches whose base address is 16-byte aligned move whole waves of boards as 16-byte vectors,
+ * any other address works through a slower per-lane byte path (as does the ragged last wave of a batch).  Scores are int32:
+ * exponents above 30 are outside the domain, as for the packed path.
  *     env2048_nxn_afterstate     latent_state: slide + merge, no spawn; reward, changed (== can_move(rot90(board, action)))
  *     env2048_nxn_step           next_state + is_done (+ legal mask of the board written back), in place
  *     env2048_nxn_status         is_done, legal-action bitmask, number of empty cells, log2(max tile)

@@ -234,6 +234,45 @@ def test_nxn_kernels_equal_the_oracle(S):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('S', [2, 3, 4, 5, 6, 7, 8])
+def test_nxn_any_alignment_any_length(S):
+    """Both memory paths of the general kernels: whole waves of a 16-byte aligned batch go through the LDS strip as 16-byte
+    vectors, a ragged last wave and a batch at any other byte offset take the per-lane byte path -- same results, and not one
+    byte outside the batch is written."""
+    lib = capi.library()
+    s = torch.cuda.current_stream().cuda_stream
+    cells = S * S
+    rng = np.random.default_rng(40 + S)
+    for n, offset in ((64, 0), (64, 1), (65, 0), (127, 5), (128, 16), (300, 8), (1, 3), (63, 0), (517, 15)):
+        src = np.where(rng.random((n, cells)) < 0.3, 0, rng.integers(1, 5, size=(n, cells))).astype(np.uint8)
+        arena = torch.full((offset + n * cells + 64,), 0xAB, dtype=torch.uint8, device='cuda')
+        view = arena[offset:offset + n * cells]
+        view.copy_(cu(src).reshape(-1))
+        acts = rng.integers(0, 4, size=n).astype(np.uint8)
+        reward = torch.zeros((n,), dtype=torch.int32, device='cuda')
+        done = torch.zeros((n,), dtype=torch.uint8, device='cuda')
+        legal = torch.zeros((n,), dtype=torch.uint8, device='cuda')
+        lib.nxn_step(0, s, n, S, 11, view.data_ptr(), p(cu(acts)), p(reward), p(done), p(legal), 5, 9, capi.FLAG_AUTO_RESET)
+        want = oracle_nxn.step_batch(src, S, acts, 5, 9, env_base=11, flags=capi.FLAG_AUTO_RESET, want_legal=True)
+        host = arena.cpu().numpy()
+        got = host[offset:offset + n * cells].reshape(n, cells)
+        bad = np.flatnonzero((got != want['boards']).any(axis=1))
+        assert bad.size == 0, (S, n, offset, bad[:5], [(src[j], acts[j], got[j], want['boards'][j]) for j in bad[:3]])
+        assert (host[:offset] == 0xAB).all() and (host[offset + n * cells:] == 0xAB).all(), (S, n, offset)
+        assert np.array_equal(reward.cpu().numpy(), want['reward']) and np.array_equal(done.cpu().numpy(), want['done'])
+        assert np.array_equal(legal.cpu().numpy(), want['legal'])
+        out = torch.full((offset + n * cells + 64,), 0xCD, dtype=torch.uint8, device='cuda')
+        changed = torch.zeros((n,), dtype=torch.uint8, device='cuda')
+        boards_in, actions_in = cu(src), cu(acts)  # (kept alive: a temporary's block would be handed to the next allocation)
+        lib.nxn_afterstate(0, s, n, S, p(boards_in), p(actions_in), out[offset:].data_ptr(), p(reward), p(changed))
+        want = oracle_nxn.afterstate_batch(src, S, acts)
+        host = out.cpu().numpy()
+        assert np.array_equal(host[offset:offset + n * cells].reshape(n, cells), want['boards']), (S, n, offset)
+        assert (host[:offset] == 0xCD).all() and (host[offset + n * cells:] == 0xCD).all()
+        assert np.array_equal(changed.cpu().numpy(), want['changed'])
+
+
+@pytest.mark.gpu
 def test_nxn_at_size_4_equals_the_packed_kernels():
     """The general kernels with S = 4 against the packed 4 x 4 kernels: same boards, rewards, done and legal bytes, step after step."""
     lib = capi.library()

@@ -50,7 +50,10 @@ while time.time() - t0 < budget:
         lib.nxn_reset(0, S(), n, size, base, P(dev), None, seed, step)
         assert np.array_equal(dev.cpu().numpy(), host)
         counts['reset'] += 1
-    dev = cu(host)
+    shift = int(rng.choice([0, 0, 1, 4, 8, int(rng.integers(0, 16))]))  # the batch at any byte offset (unaligned: the per-lane byte path)
+    arena = torch.full((shift + n * cells + 16,), 0xEE, dtype=torch.uint8, device='cuda')
+    dev = arena[shift:shift + n * cells].view(n, cells)
+    dev.copy_(cu(host))
     reward = torch.full((n,), -3, dtype=torch.int32, device='cuda')
     done = torch.full((n,), 7, dtype=torch.uint8, device='cuda')
     legal = torch.full((n,), 99, dtype=torch.uint8, device='cuda')
@@ -66,6 +69,7 @@ while time.time() - t0 < budget:
         assert np.array_equal(legal.cpu().numpy(), want['legal'])
         counts['step'] += 1
         counts['board_steps'] += n
+    assert bool((arena[:shift] == 0xEE).all()) and bool((arena[shift + n * cells:] == 0xEE).all()), 'bytes outside the batch were written'
     acts = rng.integers(0, 4, size=n).astype(np.uint8)
     out = torch.zeros_like(dev)
     changed = torch.zeros((n,), dtype=torch.uint8, device='cuda')
