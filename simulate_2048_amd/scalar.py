@@ -25,6 +25,22 @@ import torch
 from . import capi, runtime
 
 
+_tables: dict = {}
+
+
+def _value_table(dtype) -> np.ndarray:
+    """exponent byte -> tile value of `dtype` for all 256 bytes (2^e, 0 for e = 0: the mapping of env2048_unpack_i64); one gather
+    converts a board back instead of four array operations."""
+    key = np.dtype(dtype)
+    table = _tables.get(key)
+    if table is None:
+        e = np.arange(256, dtype=np.int64)
+        with np.errstate(all='ignore'):
+            table = np.where(e > 0, np.left_shift(np.int64(1), e), 0).astype(key)
+        _tables[key] = table
+    return table
+
+
 class ScalarOps:
     """Scratch buffers + the single-board operations, bound to one ``runtime.Runtime``."""
 
@@ -65,8 +81,7 @@ class ScalarOps:
     @staticmethod
     def values(packed: np.ndarray, dtype) -> np.ndarray:
         """packed exponents (..., 16) -> tile values (..., 4, 4) of `dtype`."""
-        e = packed.astype(np.int64)
-        return np.where(e > 0, np.left_shift(np.int64(1), e), 0).astype(dtype, copy=False).reshape(packed.shape[:-1] + (4, 4))
+        return _value_table(dtype)[packed].reshape(packed.shape[:-1] + (4, 4))
 
     def _sync(self) -> None:
         """Wait for the call's one launch.  A stream synchronisation is an interrupt-driven wake-up (11-12 us around a 4 us
@@ -154,14 +169,21 @@ class ScalarOps:
     def _load_nxn(self, values) -> int:
         size = self._size_of(values)
         board = self._nxn_buffers()['board'][1]
-        for i, v in enumerate(np.asarray(values).reshape(-1).tolist()):
-            board[i] = (int(v).bit_length() - 1) & 0xFF if v > 0 else 0
+        flat = np.asarray(values).reshape(-1)
+        if flat.shape[0] > 16 and flat.dtype.kind in 'iu' and flat.dtype.itemsize <= 8:
+            # floor(log2 v) of every cell at once: the binary exponent frexp reports (exact for integers below 2^53), minus one
+            e = np.frexp(np.maximum(flat, 0))[1]
+            np.subtract(e, 1, out=e)
+            np.maximum(e, 0, out=e)
+            board[:flat.shape[0]] = e
+        else:
+            for i, v in enumerate(flat.tolist()):
+                board[i] = (int(v).bit_length() - 1) & 0xFF if v > 0 else 0
         return size
 
     @staticmethod
     def values_nxn(packed: np.ndarray, size: int, dtype) -> np.ndarray:
-        e = packed[..., :size * size].astype(np.int64)
-        return np.where(e > 0, np.left_shift(np.int64(1), e), 0).astype(dtype, copy=False).reshape(e.shape[:-1] + (size, size))
+        return _value_table(dtype)[packed[..., :size * size]].reshape(packed.shape[:-1] + (size, size))
 
     def afterstate_nxn(self, values, action: int, dtype):
         size = self._load_nxn(values)
