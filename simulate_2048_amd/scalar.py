@@ -41,6 +41,23 @@ def _value_table(dtype) -> np.ndarray:
     return table
 
 
+def _exponents_into(board: np.ndarray, values) -> int:
+    """Tile values -> log2 exponents (e = floor(log2(v)) for v > 0, else 0: the mapping of env2048_pack_i64) into the first
+    cells of `board`; returns the number of cells.  Up to 16 cells a Python loop is the faster way; above that one frexp over the
+    array (the binary exponent, exact for integers below 2^53, minus one)."""
+    flat = np.asarray(values).reshape(-1)
+    cells = flat.shape[0]
+    if cells > 16 and flat.dtype.kind in 'iu':
+        e = np.frexp(np.maximum(flat, 0))[1]
+        np.subtract(e, 1, out=e)
+        np.maximum(e, 0, out=e)
+        board[:cells] = e
+    else:
+        for i, v in enumerate(flat.tolist()):
+            board[i] = (int(v).bit_length() - 1) & 0xFF if v > 0 else 0
+    return cells
+
+
 class ScalarOps:
     """Scratch buffers + the single-board operations, bound to one ``runtime.Runtime``."""
 
@@ -73,10 +90,7 @@ class ScalarOps:
     # -- host-side value <-> exponent conversion (same mapping as env2048_pack_i64 / unpack_i64) -----
     def load(self, values) -> None:
         """(4,4) tile values -> the packed input buffer: e = floor(log2(v)) for v > 0, else 0."""
-        flat = np.asarray(values).reshape(16)
-        board = self.board
-        for i, v in enumerate(flat.tolist()):
-            board[i] = (int(v).bit_length() - 1) & 0xFF if v > 0 else 0
+        _exponents_into(self.board, np.asarray(values).reshape(16))
 
     @staticmethod
     def values(packed: np.ndarray, dtype) -> np.ndarray:
@@ -168,17 +182,7 @@ class ScalarOps:
 
     def _load_nxn(self, values) -> int:
         size = self._size_of(values)
-        board = self._nxn_buffers()['board'][1]
-        flat = np.asarray(values).reshape(-1)
-        if flat.shape[0] > 16 and flat.dtype.kind in 'iu' and flat.dtype.itemsize <= 8:
-            # floor(log2 v) of every cell at once: the binary exponent frexp reports (exact for integers below 2^53), minus one
-            e = np.frexp(np.maximum(flat, 0))[1]
-            np.subtract(e, 1, out=e)
-            np.maximum(e, 0, out=e)
-            board[:flat.shape[0]] = e
-        else:
-            for i, v in enumerate(flat.tolist()):
-                board[i] = (int(v).bit_length() - 1) & 0xFF if v > 0 else 0
+        _exponents_into(self._nxn_buffers()['board'][1], values)
         return size
 
     @staticmethod
@@ -237,13 +241,10 @@ class ScalarOps:
         """(cells,) tile values -> (cells, width) 0/1 bytes: eye(width)[log2(value)] with 0 staying index 0, computed by
         env2048_encode_onehot on pinned host operands (one launch + one polled completion word, like the other single-board
         calls).  `cells` is padded to whole 16-cell records for the kernel and trimmed again."""
-        flat = np.asarray(values).reshape(-1)
-        cells = flat.shape[0]
         nb = self._nxn_buffers()
         board = nb['board'][1]
         board[:] = 0
-        for i, v in enumerate(flat.tolist()):
-            board[i] = (int(v).bit_length() - 1) & 0xFF if v > 0 else 0
+        cells = _exponents_into(board, values)
         records = (cells + 15) // 16
         dev, stream = self.rt.handles()
         self.rt.lib.encode_onehot(dev, stream, records, nb['board'][2], int(width), nb['outcomes'][2])
