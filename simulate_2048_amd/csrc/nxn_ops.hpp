@@ -291,12 +291,13 @@ ENV2048_DEV void fresh(Rows<S> &b, uint32_t w0, uint32_t w1, uint32_t w2, uint32
 // [ref: gameboard.py:328-348 is_done] + [gamemove.py:45-83 legal_actions_mask] from adjacency alone: a move is legal iff, along
 // its axis, an empty cell sits directly before an occupied one (in the direction of the move) or two equal tiles are adjacent.
 // Only bit 7 of every byte is meaningful in the intermediate words.
-template <int S>
+// COUNT false: `n_empty` comes in (the caller knows it, e.g. from the spawn that has just filled a cell) and is not recounted.
+template <int S, bool COUNT = true>
 ENV2048_DEV void status(const Rows<S> &b, bool &done, uint32_t &legal, uint32_t &n_empty)
 {
     using Sh = Shape<S>;
     uint32_t h_merge = 0u, left = 0u, right = 0u, v_merge = 0u, up = 0u, down = 0u;
-    n_empty = 0u;
+    if (COUNT) n_empty = 0u;
 #pragma unroll
     for (int g = 0; g < Sh::G; ++g) {
         uint32_t hm = 0u, lf = 0u, rt = 0u, vm = 0u, u = 0u, d = 0u;
@@ -304,7 +305,7 @@ ENV2048_DEV void status(const Rows<S> &b, bool &done, uint32_t &legal, uint32_t 
         for (int r = 0; r < S; ++r) {
             const uint32_t x = b.w[r][g];
             const uint32_t nx = x + K7F;  // bit 7: occupied
-            n_empty += ENV2048_POPC(ENV2048_BITOP3(nx, K80 & Sh::valid(g), 0u, 0x0C));
+            if (COUNT) n_empty += ENV2048_POPC(ENV2048_BITOP3(nx, K80 & Sh::valid(g), 0u, 0x0C));
             if (Sh::pair_valid(g) != 0u) {  // the cell to the right of every cell of this dword
                 const uint32_t next = g + 1 < Sh::G ? b.w[r][g + 1 < Sh::G ? g + 1 : g] : 0u;
                 const uint32_t y = ENV2048_ALIGNBYTE(next, x, 1u);
@@ -374,9 +375,8 @@ ENV2048_DEV void step_board(Rows<S> &b, const RngKey &key, uint64_t env, uint32_
     const uint32_t word = step_word(key, env);
     bool changed;
     afterstate<S>(b, random_action ? word & 3u : action & 3u, reward, changed);  // an invalid move leaves the board as it was and scores 0
-    spawn_word<S>(b, word, changed);
-    uint32_t n_empty;
-    status<S>(b, done, legal, n_empty);
+    uint32_t n_empty = spawn_word<S>(b, word, changed);  // (the empty cells left after the spawn)
+    status<S, false>(b, done, legal, n_empty);
     if (done && auto_reset) {
         uint32_t w0, w1, w2, w3;
         env_block(key, env, STREAM_RESET, w0, w1, w2, w3);
