@@ -701,6 +701,7 @@ def cold_leg(args, torch, lib, capi, device, device_index, h, stream, n, env_bas
 
     separate_pass()
     separate_s = time_passes(separate_pass)
+    copy_gbs = measured_copy_ceiling(torch, device)
     prof = load_step_profile(n, 'cold')
     gbs = lambda t: ALGO_BYTES_PER_STEP * n / t / 1e9
     return {
@@ -709,6 +710,11 @@ def cold_leg(args, torch, lib, capi, device, device_index, h, stream, n, env_bas
         'peak': HBM_PEAK_GBS,
         'unit': 'GB/s',
         'frac': gbs(cold_s) / HBM_PEAK_GBS,
+        'measured_copy_ceiling': None if copy_gbs is None else {
+            'GB/s': copy_gbs['GB/s'], 'frac_of_it': gbs(cold_s) / copy_gbs['GB/s'], 'shape': copy_gbs['shape'], 'sweep_GB/s': copy_gbs['sweep_GB/s'],
+            'what': 'SURVEY 8(d): the device-copy ceiling measured on THIS box in this run beside the 8 TB/s spec peak -- a 1 GiB streaming copy '
+                    '(tools/copy_probe.hip; read + written bytes / HIP-event time, median of 5 x 10 copies, 2 GiB touched per copy > 8 x Infinity '
+                    'Cache; best of a small sweep of launch shapes)'},
         'avg_launch_us': cold_s * 1e6,
         'avg_launch_us_means': f'time per {n}-board record; the {sets} records of a call share {plan["launches"]} kernel launch(es)',
         'kernel': f'step_many_kernel<false, false, {plan["boards_per_lane"][0]}>' if plan['launches'] < sets else f'step_kernel<false, false, {plan["boards_per_lane"][0]}>',
@@ -728,6 +734,50 @@ def cold_leg(args, torch, lib, capi, device, device_index, h, stream, n, env_bas
         'how': f'{sets} disjoint sets of (boards, actions, reward, done) = {sets * set_bytes / 2**20:.0f} MiB > 2 x Infinity Cache, '
                f'stepped round-robin by env2048_step_many, so every record reads and writes lines last touched {sets} records ago',
     }
+
+
+def measured_copy_ceiling(torch, device):
+    """GB/s (read + written) of a plain 1 GiB device-to-device streaming copy (tools/copy_probe.hip: 16-byte vectors, four
+    loads in flight per lane): what this box's HBM sustains for a pure stream, the practical ceiling an HBM-bound kernel is
+    priced against beside the spec peak.  None when the probe library cannot be built or loaded."""
+    import ctypes
+
+    try:
+        import __graft_entry__
+
+        probe = ctypes.CDLL(str(__graft_entry__.build_copy_probe()))
+    except Exception as exc:  # noqa: BLE001 (a missing measuring stick must not cost the bench line)
+        print(f'bench: copy probe unavailable ({exc})', file=sys.stderr)
+        return None
+    probe.copy_probe.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int]
+    size = 1 << 30
+    src = torch.zeros((size,), dtype=torch.uint8, device=device)
+    dst = torch.empty_like(src)
+    stream = torch.cuda.current_stream(device)
+    best = None
+    shapes = [(w, nt) for nt in (0, 1) for w in (0, 4096, 16384)]  # (0 workgroups: one 16 KiB tile per workgroup)
+    if os.environ.get('ENV2048_COPY_PROBE_SWEEP'):
+        shapes = [(w, nt) for nt in (0, 1) for w in (0, 1024, 2048, 4096, 8192, 16384, 65536)]
+    sweep = {}
+    for workgroups, nt in shapes:
+        assert probe.copy_probe(stream.cuda_stream, src.data_ptr(), dst.data_ptr(), size, workgroups, nt) == 0
+        torch.cuda.synchronize()
+        times = []
+        for _ in range(5):
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record(stream)
+            for _ in range(10):
+                probe.copy_probe(stream.cuda_stream, src.data_ptr(), dst.data_ptr(), size, workgroups, nt)
+            ev1.record(stream)
+            torch.cuda.synchronize()
+            times.append(ev0.elapsed_time(ev1) * 1e-3 / 10)
+        gbs = 2 * size / statistics.median(times) / 1e9
+        sweep[f'{"tiles" if workgroups == 0 else workgroups}{" nt" if nt else ""}'] = round(gbs, 1)
+        if best is None or gbs > best[0]:
+            best = (gbs, workgroups, nt)
+    del src, dst
+    return {'GB/s': best[0], 'shape': f'{"one 16 KiB tile per workgroup" if best[1] == 0 else str(best[1]) + " workgroups, grid-stride"}, '
+                                      f'{"non-temporal" if best[2] else "temporal"} accesses', 'sweep_GB/s': sweep}
 
 
 def other_configs(torch, lib, device, device_index, h) -> dict:
