@@ -126,15 +126,23 @@ class ScalarOps:
         self._sync()
         return self.values(self.out, dtype), int(self.reward[0]), bool(self.flags[2])
 
-    def step(self, values, action: int, seed: int, step_index: int, dtype):
-        """Full transition -> (new values, reward int, done bool). The input array is not touched."""
+    def step(self, values, action: int, seed: int, step_index: int, dtype, onehot_width: int = 0):
+        """Full transition -> (new values, reward int, done bool). The input array is not touched.  With `onehot_width` a
+        second launch behind the first encodes the NEW board (the exponents the step has just written) as
+        eye(width)[log2] rows and both are waited for once: -> (..., one-hot (16, width) bytes)."""
         self.load(values)
         self.action[0] = action & 3
         dev, stream = self.rt.handles()
         self.rt.lib.step(dev, stream, 1, 0, self._board, self._action, self._reward, self._ptr_done, None, None, seed,
                          step_index, 0)
+        if onehot_width:
+            out = self._nxn_buffers()['outcomes']
+            self.rt.lib.encode_onehot(dev, stream, 1, self._board, int(onehot_width), out[2])
         self._sync()
-        return self.values(self.board, dtype), int(self.reward[0]), bool(self.flags[0])
+        result = self.values(self.board, dtype), int(self.reward[0]), bool(self.flags[0])
+        if onehot_width:
+            return result + (out[1][:16 * onehot_width].reshape(16, onehot_width).copy(),)
+        return result
 
     def status(self, values):
         """-> (done bool, legal bitmask int)."""
@@ -198,14 +206,22 @@ class ScalarOps:
         self._sync()
         return self.values_nxn(nb['out'][1], size, dtype), int(self.reward[0]), bool(self.flags[2])
 
-    def step_nxn(self, values, action: int, seed: int, step_index: int, dtype):
+    def step_nxn(self, values, action: int, seed: int, step_index: int, dtype, onehot_width: int = 0):
         size = self._load_nxn(values)
         nb = self._nxn_buffers()
         self.action[0] = action & 3
         dev, stream = self.rt.handles()
         self.rt.lib.nxn_step(dev, stream, 1, size, 0, nb['board'][2], self._action, self._reward, self._ptr_done, None, seed, step_index, 0)
+        cells = size * size
+        if onehot_width:  # (as in step(): the one-hot rows of the new board from a second launch, one wait for both)
+            records = (cells + 15) // 16
+            nb['board'][1][cells:records * 16] = 0  # (whole 16-cell records for the encoder)
+            self.rt.lib.encode_onehot(dev, stream, records, nb['board'][2], int(onehot_width), nb['outcomes'][2])
         self._sync()
-        return self.values_nxn(nb['board'][1], size, dtype), int(self.reward[0]), bool(self.flags[0])
+        result = self.values_nxn(nb['board'][1], size, dtype), int(self.reward[0]), bool(self.flags[0])
+        if onehot_width:
+            return result + (nb['outcomes'][1][:records * 16 * onehot_width].reshape(records * 16, onehot_width)[:cells].copy(),)
+        return result
 
     def status_nxn(self, values):
         size = self._load_nxn(values)

@@ -107,13 +107,14 @@ def next_state(state: ndarray, action: int, seed: int | None = None) -> tuple[nd
     return after, 0.0 + float(reward)
 
 
-def _transition(state: ndarray, action: int, seed: int | None):
-    """One launch of the step kernel on one board: (new values, reward int, done bool)."""
+def _transition(state: ndarray, action: int, seed: int | None, onehot_width: int = 0):
+    """One launch of the step kernel on one board: (new values, reward int, done bool); with `onehot_width` also the new board's
+    one-hot rows (cells, width) from a second launch behind it, both waited for once."""
     arr = np.asarray(state)
     ops = scalar.current()
     step_fn = ops.step if is_4x4(arr, 'board') else ops.step_nxn
     stream_seed, step = rng_for(seed)
-    return step_fn(arr, int(action), stream_seed, step, arr.dtype)
+    return step_fn(arr, int(action), stream_seed, step, arr.dtype, onehot_width)
 
 
 def is_done(state: ndarray) -> bool:

@@ -63,13 +63,17 @@ class TwentyFortyEight:
         """Play ``action`` (0 left, 1 up, 2 right, 3 down): ``(observation, reward, finished)``."""
         # next_state + is_done of the reference in ONE launch: the step kernel reports the terminal test
         # of the board it wrote.  An invalid move keeps the same state object and earns the int 0.
-        board, gained, finished = gameboard._transition(self._current_state, action, None)
+        # With ``encoded=True`` the one-hot observation of the new board comes from a second launch right behind the step
+        # (it reads the exponents the step has just written) and both are waited for once.
+        width = _ONE_HOT_WIDTH if self._encoded else 0
+        board, gained, finished, *onehot = gameboard._transition(self._current_state, action, None, width)
         if np.array_equal(board, self._current_state):
             board, gained = self._current_state, 0
         else:
             gained = 0.0 + float(gained)
         self._current_state, self._current_reward = board, gained
-        return self.observation, self.reward, finished
+        observation = onehot[0].astype(np.int64).ravel() if onehot else self.observation
+        return observation, self.reward, finished
 
     def render(self) -> None:
         """Print the four rows, cells separated by ' \\t'."""

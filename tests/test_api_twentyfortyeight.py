@@ -197,6 +197,10 @@ def test_env_step_signature_and_modes():
     encoded = TwentyFortyEight(size=4, encoded=True)  # :87-97
     obs = encoded.reset()
     assert obs.ndim == 1 and len(obs) == 4 * 4 * 31 and obs.sum() == 16
+    for action in (0, 1, 2, 3):  # (step + one-hot observation as a launch pair: same as encoding the new board afterwards)
+        obs, _, _ = encoded.step(action)
+        np.testing.assert_array_equal(obs, encoded.observation)
+        assert obs.dtype == np.int64 and obs.sum() == 16
     board = np.array([[2, 2, 0, 0], [0, 0, 0, 0], [0, 0, 0, 0], [0, 0, 0, 0]])
     env_norm, env_raw = TwentyFortyEight(normalize=True), TwentyFortyEight(normalize=False)
     env_norm._current_state, env_raw._current_state = board.copy(), board.copy()  # :99-115

@@ -162,6 +162,11 @@ def test_env_of_other_sizes_plays_whole_games(api_runtime, S):
     assert encoded.observation.shape == (S * S * 31,)
     np.testing.assert_array_equal(encoded.observation, encode_flatten(encoded._current_state, encodage_size=31))
     assert encoded.observation.sum() == S * S  # one-hot per cell
+    for action in (0, 1, 2, 3, 0, 3):  # the fused step + one-hot launch pair returns what encode_flatten makes of the new board
+        obs, _, _ = encoded.step(action)
+        assert obs.dtype == np.int64 and obs.shape == (S * S * 31,)
+        np.testing.assert_array_equal(obs, encode_flatten(encoded._current_state, encodage_size=31))
+        np.testing.assert_array_equal(obs, encoded.observation)
     for bad in (1, 9, 0):
         with pytest.raises(ValueError):
             TwentyFortyEight(size=bad)
