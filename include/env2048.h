@@ -409,6 +409,15 @@ ENV2048_EXPORT int env2048_step_state_i32_keyed_inline(int device, void *stream,
  */
 ENV2048_EXPORT int env2048_status_i32(int device, void *stream, uint64_t n, const int32_t *boards, float *obs, uint8_t *legal4,
                                       uint8_t *done);
+/*
+ * Afterstates on int32 tile VALUE boards (n x 16), one launch: slide + merge towards `actions[i]` -- or towards `action` for
+ * every board when `actions` is NULL -- with no spawn; boards_out may be boards_in.  reward[i] (optional) = the merge score,
+ * changed[i] (optional) = 1 iff the move changes board i.
+ * [replaces: reinforce/game/core.py:129-170 latent_state, :104-126 slide_and_merge (action 0), :43-101 merge_row (a row in an
+ *            otherwise empty board)]
+ */
+ENV2048_EXPORT int env2048_afterstate_i32(int device, void *stream, uint64_t n, const int32_t *boards_in, const int32_t *actions,
+                                          uint32_t action, int32_t *boards_out, int32_t *reward, uint8_t *changed);
 
 /*
  * T consecutive transitions per board, boards held in registers, actions drawn on device

@@ -107,6 +107,7 @@ PROTOTYPES = {
     'env2048_step_state_i32_keyed_inline': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
                                                       _ptr, _ptr, _ptr, _ptr, ctypes.c_int64, _ptr, _u64]),
     'env2048_status_i32': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr]),
+    'env2048_afterstate_i32': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _u32, _ptr, _ptr, _ptr]),
     'env2048_rollout': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _u64, _u64, _u32, _ptr, _ptr, _ptr, _u32]),
     'env2048_replay': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _ptr, _ptr, _ptr, _u64, _u64, _u64, _u32, _u32, _ptr, _ptr, _ptr]),
     'env2048_rollout_episodes': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _u64, _u64, _u32, _u32, _ptr, _ptr, _ptr]),
@@ -332,6 +333,9 @@ class Library:
 
     def status_i32(self, device, stream, n, boards, obs, legal4, done) -> None:
         self._check(self._dll.env2048_status_i32(device, stream, n, boards, obs, legal4, done))
+
+    def afterstate_i32(self, device, stream, n, boards_in, actions, action, boards_out, reward, changed) -> None:
+        self._check(self._dll.env2048_afterstate_i32(device, stream, n, boards_in, actions, action, boards_out, reward, changed))
 
     def rollout(self, device, stream, n, env_base, boards, seed, step0, T, return_sum, episodes, valid_moves,
                 flags) -> None:

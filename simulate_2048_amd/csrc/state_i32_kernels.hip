@@ -226,6 +226,27 @@ __global__ __launch_bounds__(BLOCK) void status_i32_kernel(uint64_t n, const int
     }
 }
 
+// latent_state / slide_and_merge / merge_row of the JAX-shaped API on int32 value boards [ref: reinforce/game/core.py:129-170,
+// :104-126, :43-101]: slide + merge towards `action` (one move for the whole batch, or one per board), no spawn.
+__global__ __launch_bounds__(BLOCK) void afterstate_i32_kernel(uint64_t n, const int32_t *boards_in, const int32_t *actions, uint32_t action,
+                                                               int32_t *boards_out, int32_t *reward, uint8_t *changed_out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int4 *rows = reinterpret_cast<const int4 *>(boards_in) + 4 * i;
+    Board bd{pack4(rows[0]), pack4(rows[1]), pack4(rows[2]), pack4(rows[3])};
+    uint32_t score;
+    bool changed;
+    afterstate(bd, (actions ? (uint32_t)actions[i] : action) & 3u, score, changed);
+    int4 *out = reinterpret_cast<int4 *>(boards_out) + 4 * i;
+    out[0] = unpack4(bd.r0);
+    out[1] = unpack4(bd.r1);
+    out[2] = unpack4(bd.r2);
+    out[3] = unpack4(bd.r3);
+    if (reward) reward[i] = (int32_t)score;
+    if (changed_out) changed_out[i] = changed ? 1 : 0;
+}
+
 // A launch that fits one workgroup gets a workgroup of only as many waves as it has boards for (at the reference's batch
 // sizes, N = 2 ... 8, one wave instead of eight: less to dispatch, and the completion signal's barrier spans one wave).
 inline dim3 block_for(uint64_t n) { return dim3(n >= (uint64_t)BLOCK ? (unsigned)BLOCK : (unsigned)((n + 63) / 64 * 64)); }
@@ -428,6 +449,21 @@ int env2048_step_state_i32(int device, void *stream, uint64_t n, uint64_t env_ba
 {
     return env2048_step_state_i32_to(device, stream, n, env_base, boards, boards, actions, step_count, step_count, done_io, done_io,
                                      total_reward, total_reward, reward, max_tile, seed, step_index);
+}
+
+int env2048_afterstate_i32(int device, void *stream, uint64_t n, const int32_t *boards_in, const int32_t *actions, uint32_t action,
+                           int32_t *boards_out, int32_t *reward, uint8_t *changed)
+{
+    if (n == 0) return ENV2048_OK;
+    if (!boards_in || !boards_out) return fail(ENV2048_ERR_INVALID_ARG, "env2048_afterstate_i32: boards_in and boards_out are required");
+    if (misaligned(boards_in, 16) || misaligned(boards_out, 16)) return fail(ENV2048_ERR_ALIGNMENT, "env2048_afterstate_i32: boards must be 16-byte aligned");
+    if (misaligned(actions, 4) || misaligned(reward, 4)) return fail(ENV2048_ERR_ALIGNMENT, "env2048_afterstate_i32: actions / reward must be 4-byte aligned");
+    if (int rc = check_count(n)) return rc;
+    DeviceScope scope(device);
+    if (scope.rc) return scope.rc;
+    hipLaunchKernelGGL(afterstate_i32_kernel, grid_for(n), block_for(n), 0, (hipStream_t)stream, n, boards_in, actions, action, boards_out, reward,
+                       changed);
+    return launched("env2048_afterstate_i32 launch");
 }
 
 int env2048_status_i32(int device, void *stream, uint64_t n, const int32_t *boards, float *obs, uint8_t *legal4, uint8_t *done)

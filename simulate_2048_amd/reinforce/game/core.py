@@ -79,26 +79,35 @@ def _status_i32(board, *, obs=False, legal=False, done=False):
     return o, l4, d
 
 
+def _afterstate_i32(board: torch.Tensor, action: int):
+    """One launch of env2048_afterstate_i32 on one int32 value board (the move rides in the kernel arguments) -> (board, score)."""
+    rt = runtime.current()
+    dev, stream = rt.handles()
+    if board.data_ptr() & 15:  # (a view at an odd offset of somebody's tensor)
+        board = board.clone()
+    out = torch.empty((20,), dtype=torch.int32, device=board.device)  # 16 cells + the score (16-byte aligned behind them)
+    rt.lib.afterstate_i32(dev, stream, 1, board.data_ptr(), None, action & 3, out.data_ptr(), out.data_ptr() + 64, None)
+    return out[:16].view(4, 4), out[16]
+
+
 def merge_row(row):
     """[ref core.py:43-101] merge one row to the left -> (row (4,), score int32)."""
     rt = runtime.current()
     r = to_tensor(row).to(device=rt.device, dtype=torch.int32).reshape(4)
-    board = torch.zeros((4, 4), dtype=torch.int32, device=rt.device)
-    board[0] = r
-    after, reward, _ = ops.afterstate(_packed(board), [0])
-    return _values(after)[0], wrap(reward[0])
+    after, reward = _afterstate_i32(torch.nn.functional.pad(r, (0, 12)), 0)  # the row in an otherwise empty board
+    return wrap(after[0]), wrap(reward)
 
 
 def slide_and_merge(board):
     """[ref core.py:104-126] slide the whole board left -> (board, score int32)."""
-    after, reward, _ = ops.afterstate(_packed(board), [0])
-    return _values(after), wrap(reward[0])
+    after, reward = _afterstate_i32(_board_tensor(board), 0)
+    return wrap(after), wrap(reward)
 
 
 def latent_state(state, action):
     """[ref core.py:129-170] afterstate of `action` (0 left, 1 up, 2 right, 3 down) -> (board, reward int32)."""
-    after, reward, _ = ops.afterstate(_packed(state), [int(action) & 3])
-    return _values(after), wrap(reward[0])
+    after, reward = _afterstate_i32(_board_tensor(state), int(action))
+    return wrap(after), wrap(reward)
 
 
 def fill_cells(state, key):
@@ -179,4 +188,4 @@ def max_tile(board):
 
 def count_empty(board):
     """[ref core.py:445-460] number of empty cells."""
-    return wrap((_board_tensor(board) == 0).sum().to(torch.int32))
+    return wrap(torch.sum(_board_tensor(board) == 0, dtype=torch.int32))

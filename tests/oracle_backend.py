@@ -477,6 +477,17 @@ class OracleLibrary:
         if done is not None:
             _view(done, n, np.uint8)[:] = (res['legal'] == 0).astype(np.uint8)  # JAX is_done: no legal action
 
+    def afterstate_i32(self, device, stream, n, boards_in, actions, action, boards_out, reward, changed):
+        self.calls.append(('afterstate_i32', n))
+        packed = oracle.pack_values(_view(boards_in, n * 16, np.int32)).reshape(n, 16)
+        acts = np.full(n, action & 3, dtype=np.uint8) if actions is None else (_view(actions, n, np.int32) & 3).astype(np.uint8)
+        res = oracle.afterstate_batch(packed, acts)
+        _view(boards_out, n * 16, np.int32)[:] = oracle.unpack_values(res['boards']).reshape(-1).astype(np.int32)
+        if reward is not None:
+            _view(reward, n, np.int32)[:] = res['reward']
+        if changed is not None:
+            _view(changed, n, np.uint8)[:] = res['changed']
+
     def chance_outcomes(self, device, stream, n, boards, out_boards, out_prob, out_count):
         self.calls.append(('chance_outcomes', n))
         res = oracle.chance_outcomes(_view(boards, n * 16, np.uint8).reshape(n, 16).copy())

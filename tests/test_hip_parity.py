@@ -975,6 +975,36 @@ def test_status_i32_matches_oracle(lib):
     np.testing.assert_array_equal(legal.cpu().numpy(), want_legal)
 
 
+def test_afterstate_i32_golden(lib, golden):
+    """latent_state / slide_and_merge of the JAX-shaped API on int32 value boards (env2048_afterstate_i32) against the
+    reference's own afterstates: one move for the whole batch, one move per board, in place, outputs optional."""
+    g = golden['afterstates']
+    exps = g['boards']
+    n = exps.shape[0]
+    values = cu(oracle.unpack_values(exps).astype(np.int32))
+    want = [oracle.unpack_values(g['after'][:, a]).astype(np.int32) for a in range(4)]
+    out = torch.full((n, 16), -7, dtype=torch.int32, device='cuda')
+    reward = torch.full((n,), -7, dtype=torch.int32, device='cuda')
+    changed = torch.full((n,), 9, dtype=torch.uint8, device='cuda')
+    for a in range(4):
+        lib.afterstate_i32(DEV, stream(), n, p(values), None, a + 4 * (a & 1), p(out), p(reward), p(changed))  # (only the low two bits count)
+        np.testing.assert_array_equal(out.cpu().numpy(), want[a])
+        np.testing.assert_array_equal(reward.cpu().numpy(), g['reward'][:, a])
+        np.testing.assert_array_equal(changed.cpu().numpy(), g['valid'][:, a])
+    rng = np.random.default_rng(3)
+    acts = rng.integers(0, 4, size=n).astype(np.int32)
+    inplace = values.clone()
+    per_board = cu(acts)
+    lib.afterstate_i32(DEV, stream(), n, p(inplace), p(per_board), 0, p(inplace), None, None)
+    mixed = np.stack(want, axis=1)[np.arange(n), acts]
+    np.testing.assert_array_equal(inplace.cpu().numpy(), mixed)
+    lib.afterstate_i32(DEV, stream(), 0, None, None, 0, None, None, None)  # n == 0: nothing
+    with pytest.raises(capi.Env2048Error):
+        lib.afterstate_i32(DEV, stream(), n, p(values), None, 0, None, None, None)
+    with pytest.raises(capi.Env2048Error, match='aligned'):
+        lib.afterstate_i32(DEV, stream(), n - 1, p(values) + 4, None, 0, p(out), None, None)
+
+
 def test_config4_slicing_at_8x2pow20(lib):
     """BASELINE config 4 on one GPU: 8 388 608 boards stepped as 8 contiguous slices (what 8 ranks would
     do, each with env_base = its slice start) equal the unsliced batch -- boards, rewards and done flags."""
