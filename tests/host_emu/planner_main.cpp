@@ -222,7 +222,9 @@ static int test_helper()
     }
     CHECK(sleeper.spin_us() == 0 && spinner.spin_us() == 20000, "spin windows");
     CHECK(sleeper.cpu_ns() < 5000000ull, "a helper with spin 0 used %llu ns of CPU for two empty jobs", (unsigned long long)sleeper.cpu_ns());
-    CHECK(spinner.cpu_ns() > 10000000ull, "a helper with a 20 ms window only used %llu ns", (unsigned long long)spinner.cpu_ns());
+    // (the window is wall-clock: on a loaded machine the spinning thread is preempted and burns less than the 20 ms it spans)
+    CHECK(spinner.cpu_ns() > 2000000ull && spinner.cpu_ns() > 2 * sleeper.cpu_ns(), "a helper with a 20 ms window only used %llu ns (spin 0: %llu ns)",
+          (unsigned long long)spinner.cpu_ns(), (unsigned long long)sleeper.cpu_ns());
     // 4. fork: the child's registry slot is rebuilt (the parent's thread does not exist there) and works
     static PerDeviceRegistry<HelperThread> registry;
     int made = 0;
