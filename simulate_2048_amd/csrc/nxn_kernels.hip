@@ -30,7 +30,6 @@ namespace {
 constexpr int NXN_BLOCK = 256;
 constexpr int NXN_WAVES = NXN_BLOCK / 64;
 constexpr int NXN_MAX = ENV2048_NXN_MAX_SIZE;
-constexpr int NXN_MAX_CELLS = NXN_MAX * NXN_MAX;
 
 // ---- the wave's boards: global memory <-> LDS strip <-> registers -------------------------------------------------------------
 template <int S>
@@ -232,49 +231,74 @@ __global__ __launch_bounds__(NXN_BLOCK) void nxn_spawn_random_kernel(uint64_t n,
     (void)active;
 }
 
-// ---- chance outcomes: 2 S S slots of S S bytes per board, written cell by cell (one board per lane, the board in LDS as
-// cells[c][lane]: a lane's accesses to cell c hit consecutive bytes across the wave) ---------------------------------------------
-constexpr int OUTCOMES_BLOCK = 64;
-
-struct Cells {  // the calling lane's board in LDS
-    uint8_t *base;  // &cells[0][lane]
-    uint32_t S;
-    __device__ __forceinline__ uint32_t get(uint32_t c) const { return base[c * OUTCOMES_BLOCK]; }
-    __device__ __forceinline__ void set(uint32_t c, uint32_t v) const { base[c * OUTCOMES_BLOCK] = (uint8_t)v; }
-    __device__ __forceinline__ uint32_t count() const { return S * S; }
-};
-
-// [ref: gameboard.py:132-171 after_state] every (empty cell, value) outcome: 2 S S slots of S S bytes per board
-__global__ __launch_bounds__(OUTCOMES_BLOCK) void nxn_chance_outcomes_kernel(uint64_t n, uint32_t size, const uint8_t *boards, uint8_t *out, uint8_t *count_out)
+// ---- chance outcomes [ref: gameboard.py:132-171 after_state]: every (empty cell, value) outcome, 2 S S slots of S S bytes per
+// board (cell in row-major rank, tile 2 then 4), unused slots zero; a full board: itself, count 1.  One board per lane, the
+// board in registers as its memory image: the slot of (cell c, tile e) is that image with byte c set, stored dword by dword
+// (16-byte vectors when S S is a multiple of 16 and the output is aligned for them; any other alignment: the compiler's
+// byte-safe copy).  Every lane writes its own 2 S S S S bytes exactly once.
+template <int S, int ALIGN>
+__device__ __forceinline__ void store_slot(uint8_t *slot, const uint32_t (&image)[nxn::Shape<S>::DENSE])
 {
-    __shared__ uint8_t cells_lds[NXN_MAX_CELLS][OUTCOMES_BLOCK];
-    const uint64_t i = (uint64_t)blockIdx.x * OUTCOMES_BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const Cells b{&cells_lds[0][threadIdx.x], size};
-    const uint32_t cells = b.count();
-    uint32_t n_empty = 0u;
-    for (uint32_t c = 0; c < cells; ++c) {
-        const uint32_t x = boards[i * cells + c];
-        b.set(c, x);
-        n_empty += x == 0u ? 1u : 0u;
+    constexpr int CELLS = nxn::Shape<S>::CELLS, D = nxn::Shape<S>::DENSE;
+    uint8_t *dst = static_cast<uint8_t *>(__builtin_assume_aligned(slot, ALIGN));
+    if (CELLS % 4 == 0) {
+        __builtin_memcpy(dst, image, CELLS);
+    } else {
+        __builtin_memcpy(dst, image, 4 * (D - 1));
+        const uint32_t tail = image[D - 1];
+#pragma unroll
+        for (int b = 0; b < CELLS - 4 * (D - 1); ++b) dst[4 * (D - 1) + b] = (uint8_t)(tail >> (8 * b));
     }
-    uint8_t *slots = out + i * 2u * cells * cells;
-    for (uint32_t t = 0; t < 2u * cells * cells; ++t) slots[t] = 0;
+}
+
+template <int S, int ALIGN>
+__device__ __forceinline__ void write_outcomes(uint8_t *slots, const uint32_t (&dense)[nxn::Shape<S>::DENSE], uint32_t n_empty)
+{
+    constexpr int CELLS = nxn::Shape<S>::CELLS, D = nxn::Shape<S>::DENSE;
+    uint32_t zero[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) zero[d] = 0u;
+    uint32_t used = 0u;
     if (n_empty == 0u) {  // :156-157 a full board: itself
-        for (uint32_t c = 0; c < cells; ++c) slots[c] = (uint8_t)b.get(c);
-        count_out[i] = 1;
-        return;
-    }
-    uint32_t k = 0u;
-    for (uint32_t cell = 0; cell < cells; ++cell) {
-        if (b.get(cell) != 0u) continue;
-        for (uint32_t e = 1u; e <= 2u; ++e) {
-            uint8_t *slot = slots + (size_t)(2u * k + (e - 1u)) * cells;
-            for (uint32_t c = 0; c < cells; ++c) slot[c] = (uint8_t)(c == cell ? e : b.get(c));
+        store_slot<S, ALIGN>(slots, dense);
+        used = 1u;
+    } else {
+#pragma unroll
+        for (int c = 0; c < CELLS; ++c) {
+            if (((dense[c >> 2] >> (8 * (c & 3))) & 0xFFu) != 0u) continue;
+            uint32_t image[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) image[d] = dense[d];
+            image[c >> 2] = dense[c >> 2] | (1u << (8 * (c & 3)));
+            store_slot<S, ALIGN>(slots + (size_t)used * CELLS, image);
+            image[c >> 2] = dense[c >> 2] | (2u << (8 * (c & 3)));
+            store_slot<S, ALIGN>(slots + (size_t)(used + 1u) * CELLS, image);
+            used += 2u;
         }
-        ++k;
     }
-    count_out[i] = (uint8_t)(2u * n_empty);
+    for (uint32_t t = used; t < 2u * CELLS; ++t) store_slot<S, ALIGN>(slots + (size_t)t * CELLS, zero);
+}
+
+template <int S>
+__global__ __launch_bounds__(NXN_BLOCK) void nxn_chance_outcomes_kernel(uint64_t n, const uint8_t *boards, uint8_t *out, uint8_t *count_out)
+{
+    NXN_PROLOGUE(S)
+    using Sh = nxn::Shape<S>;
+    nxn::Rows<S> b;
+    load_board<S>(strip, boards, first, n, lane, b);
+    if (!active) return;  // (nothing below is shared with other lanes)
+    uint32_t dense[Sh::DENSE];
+    nxn::dense_from_rows<S>(b, dense);
+    const uint32_t n_empty = nxn::count_empty<S>(b);
+    uint8_t *slots = out + i * 2u * Sh::CELLS * Sh::CELLS;
+    // (2 S S S S bytes per board: a slot is 16-byte aligned iff the output is and S S is a multiple of 16, 4-byte aligned iff ... of 4)
+    if (Sh::CELLS % 16 == 0 && ((uintptr_t)out & 15u) == 0u)
+        write_outcomes<S, 16>(slots, dense, n_empty);
+    else if (Sh::CELLS % 4 == 0 && ((uintptr_t)out & 3u) == 0u)
+        write_outcomes<S, 4>(slots, dense, n_empty);
+    else
+        write_outcomes<S, 1>(slots, dense, n_empty);
+    count_out[i] = (uint8_t)(n_empty == 0u ? 1u : 2u * n_empty);
 }
 
 int check_nxn(const char *who, uint64_t n, uint32_t size)
@@ -378,8 +402,7 @@ int env2048_nxn_chance_outcomes(int device, void *stream, uint64_t n, uint32_t s
     if (!boards || !out_boards || !out_count) return fail(ENV2048_ERR_INVALID_ARG, "env2048_nxn_chance_outcomes: NULL argument");
     DeviceScope scope(device);
     if (scope.rc) return scope.rc;
-    hipLaunchKernelGGL(nxn_chance_outcomes_kernel, dim3((unsigned)((n + OUTCOMES_BLOCK - 1) / OUTCOMES_BLOCK)), dim3(OUTCOMES_BLOCK), 0, (hipStream_t)stream, n, size, boards, out_boards,
-                       out_count);
+    NXN_LAUNCH(nxn_chance_outcomes_kernel, size, nxn_grid(n), stream, n, boards, out_boards, out_count)
     return launched("env2048_nxn_chance_outcomes launch");
 }
 

@@ -275,6 +275,16 @@ def test_nxn_any_alignment_any_length(S):
         assert np.array_equal(host[offset:offset + n * cells].reshape(n, cells), want['boards']), (S, n, offset)
         assert (host[:offset] == 0xCD).all() and (host[offset + n * cells:] == 0xCD).all()
         assert np.array_equal(changed.cpu().numpy(), want['changed'])
+        # chance outcomes into an output at the same odd offset (16-byte vectors, dwords or the byte-safe copy, by alignment)
+        m = min(n, 70)
+        slots = torch.full((offset + m * 2 * cells * cells + 64,), 0xEF, dtype=torch.uint8, device='cuda')
+        count = torch.zeros((m,), dtype=torch.uint8, device='cuda')
+        lib.nxn_chance_outcomes(0, s, m, S, p(boards_in), slots[offset:].data_ptr(), p(count))
+        want_o, want_c = oracle_nxn.chance_outcomes(src[:m], S)
+        host = slots.cpu().numpy()
+        assert np.array_equal(host[offset:offset + m * 2 * cells * cells].reshape(m, 2 * cells, cells), want_o), (S, n, offset)
+        assert (host[:offset] == 0xEF).all() and (host[offset + m * 2 * cells * cells:] == 0xEF).all()
+        assert np.array_equal(count.cpu().numpy(), want_c)
 
 
 @pytest.mark.gpu
