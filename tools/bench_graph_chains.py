@@ -57,8 +57,16 @@ def main():
             lib.step_sequence(0, cur.cuda_stream, HALF, 0, b, table, r, d, None, None, 0, 7, 100, K, flags | capi.FLAG_SINGLE_CHAIN)
             cur.wait_stream(side)
 
+        def half_a_body():
+            s = torch.cuda.current_stream().cuda_stream
+            lib.step_sequence(0, s, HALF, 0, b, table, r, d, None, None, 0, 7, 100, K, flags | capi.FLAG_SINGLE_CHAIN)
+
+        def half_b_body():
+            s = torch.cuda.current_stream().cuda_stream
+            lib.step_sequence(0, s, HALF, HALF, b + HALF * 16, table_b, r + HALF * 4, d + HALF, None, None, 0, 7, 100, K, flags | capi.FLAG_SINGLE_CHAIN)
+
         graphs = {}
-        for name, body in (('graph_one_chain', one_chain_body), ('graph_two_chains', two_chain_body)):
+        for name, body in (('graph_one_chain', one_chain_body), ('graph_two_chains', two_chain_body), ('half_a', half_a_body), ('half_b', half_b_body)):
             g = torch.cuda.CUDAGraph()
             cap = torch.cuda.Stream(dev)
             with torch.cuda.stream(cap):
@@ -67,7 +75,16 @@ def main():
             with torch.cuda.graph(g, stream=cap):
                 body()
             graphs[name] = g
+        def two_graphs_two_streams():  # ONE thread, two graph launches: each half-batch chain is a graph of its own on its own stream
+            cur = torch.cuda.current_stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                graphs['half_b'].replay()
+            graphs['half_a'].replay()
+            cur.wait_stream(side)
+
         forms = {
+            'two_graphs_two_streams': two_graphs_two_streams,
             'launches_one_chain': lambda: eager(capi.FLAG_SINGLE_CHAIN),
             'launches_as_planned': lambda: eager(0),
             'graph_one_chain': graphs['graph_one_chain'].replay,
