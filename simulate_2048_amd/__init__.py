@@ -18,6 +18,7 @@ call raises.  The CPU oracle used by the tests lives in the top-level ``oracle/`
 
 from . import capi  # noqa: F401
 from .batch import BatchedEnv2048  # noqa: F401
+from .batch_nxn import BatchedEnvNxN  # noqa: F401
 from .trajectory import TrajectoryBuffer  # noqa: F401
 
-__all__ = ['capi', 'BatchedEnv2048', 'TrajectoryBuffer']
+__all__ = ['capi', 'BatchedEnv2048', 'BatchedEnvNxN', 'TrajectoryBuffer']

@@ -172,6 +172,64 @@ def test_env_of_other_sizes_plays_whole_games(api_runtime, S):
             TwentyFortyEight(size=bad)
 
 
+def _batched_nxn_games(lib, device, S):
+    """BatchedEnvNxN against the oracle: reset, given and in-kernel moves with auto-reset, the legal mask, afterstates, status,
+    slices of the batch playing the same games as the whole (global environment indices), checkpoint."""
+    from simulate_2048_amd import BatchedEnvNxN
+
+    n, seed, base = 700, 99 + S, 31
+    env = BatchedEnvNxN(n, S, seed, device=device, env_base=base, auto_reset=True, with_legal=True, lib=lib)
+    parts = [BatchedEnvNxN(k, S, seed, device=device, env_base=base + o, auto_reset=True, lib=lib) for o, k in ((0, 300), (300, 400))]
+    ref = oracle_nxn.reset_batch(n, S, seed, 0, env_base=base)
+    assert np.array_equal(env.reset().cpu().numpy().reshape(n, -1), ref)
+    assert np.array_equal(env.legal.cpu().numpy(), oracle_nxn.status_batch(ref, S)['legal'])
+    for part in parts:
+        part.reset()
+    rng = np.random.default_rng(S)
+    saved = None
+    for t in range(1, 40):
+        acts = None if t % 4 == 0 else rng.integers(0, 4, size=n).astype(np.uint8)
+        dev_acts = None if acts is None else torch.from_numpy(acts).to(device)
+        if t == 20:
+            saved = env.state_dict()
+        boards, reward, done = env.step(dev_acts)
+        want = oracle_nxn.step_batch(ref, S, acts, seed, t, env_base=base, flags=capi.FLAG_AUTO_RESET, want_legal=True)
+        ref = want['boards']
+        assert np.array_equal(boards.cpu().numpy().reshape(n, -1), ref), (S, t)
+        assert np.array_equal(reward.cpu().numpy(), want['reward']) and np.array_equal(done.cpu().numpy(), want['done'])
+        assert np.array_equal(env.legal.cpu().numpy(), want['legal'])
+        for part, (o, k) in zip(parts, ((0, 300), (300, 400))):
+            part.step(None if dev_acts is None else dev_acts[o:o + k].contiguous())
+            assert torch.equal(part.boards, env.boards[o:o + k]), (S, t, o)
+    acts = rng.integers(0, 4, size=n).astype(np.uint8)
+    after, reward, changed = env.afterstates(torch.from_numpy(acts).to(device))
+    want = oracle_nxn.afterstate_batch(ref, S, acts)
+    assert np.array_equal(after.cpu().numpy().reshape(n, -1), want['boards']) and np.array_equal(reward.cpu().numpy(), want['reward'])
+    assert np.array_equal(changed.cpu().numpy(), want['changed'])
+    st, want = env.status(), oracle_nxn.status_batch(ref, S)
+    for key in ('done', 'legal', 'n_empty', 'max_exp'):
+        assert np.array_equal(st[key].cpu().numpy(), want[key]), key
+    vals = env.values().cpu().numpy().reshape(n, -1)
+    assert np.array_equal(vals, np.where(ref > 0, np.int64(1) << ref.astype(np.int64), 0))
+    final = env.boards.clone()
+    env.load_state_dict(saved)  # back to step 20, replay: the same games
+    rng2 = np.random.default_rng(S)
+    replay = [None if t % 4 == 0 else rng2.integers(0, 4, size=n).astype(np.uint8) for t in range(1, 40)]
+    for t in range(20, 40):
+        a = replay[t - 1]
+        env.step(None if a is None else torch.from_numpy(a).to(device))
+    assert torch.equal(env.boards, final)
+    with pytest.raises(ValueError):
+        BatchedEnvNxN(4, 9, lib=lib, device=device)
+    with pytest.raises(ValueError):
+        env.step(torch.zeros((n + 1,), dtype=torch.uint8, device=device))
+
+
+@pytest.mark.parametrize('S', [2, 3, 4, 6, 8])
+def test_batched_env_of_other_sizes(api_runtime, S):
+    _batched_nxn_games(api_runtime.lib, api_runtime.device, S)
+
+
 # ------------------------------------------------------------------------------------------------ C-ABI on the GPU
 def p(t):
     return None if t is None else t.data_ptr()
