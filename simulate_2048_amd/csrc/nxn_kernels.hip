@@ -301,6 +301,51 @@ __global__ __launch_bounds__(NXN_BLOCK) void nxn_chance_outcomes_kernel(uint64_t
     count_out[i] = (uint8_t)(n_empty == 0u ? 1u : 2u * n_empty);
 }
 
+// The same enumeration with ONE BOARD PER WAVE (even sizes, a 4-byte aligned output): the 2 S S slots of a board are one
+// contiguous block of 2 S^4 bytes, and the per-lane form above writes 64 such blocks 2 S^4 bytes apart with every store
+// instruction -- a power-of-two stride for S = 4, 8 that lands on few memory channels (1.0 / 1.9 TB/s written).  Here the 64
+// lanes of a wave write consecutive dwords of one board's block: lane l of round r owns dword 64 r + l, i.e. bytes 4 ... of
+// slot t = (256 r + 4 l) / (S S), and builds it from the board (in LDS) and the rank-ordered list of the board's empty cells
+// (a ballot over "cell c is empty" + mbcnt gives every empty cell its rank; the list lives in LDS too).  Waves stride over
+// the boards of the batch.
+constexpr int OUTCOME_WAVES_PER_BLOCK = 4;
+
+template <int S>
+__global__ __launch_bounds__(64 * OUTCOME_WAVES_PER_BLOCK) void nxn_chance_outcomes_wave_kernel(uint64_t n, const uint8_t *boards, uint32_t *out, uint8_t *count_out)
+{
+    constexpr uint32_t CELLS = S * S, BOARD_DWORDS = CELLS / 4, OUT_DWORDS = 2u * CELLS * CELLS / 4u;
+    static_assert(CELLS % 4 == 0, "even sizes only");
+    __shared__ __attribute__((aligned(16))) uint32_t cells_lds[OUTCOME_WAVES_PER_BLOCK][16];
+    __shared__ uint8_t rank_lds[OUTCOME_WAVES_PER_BLOCK][64];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint8_t *const cell_bytes = reinterpret_cast<uint8_t *>(cells_lds[wave]);
+    const uint64_t waves = (uint64_t)gridDim.x * OUTCOME_WAVES_PER_BLOCK;
+    for (uint64_t board = (uint64_t)blockIdx.x * OUTCOME_WAVES_PER_BLOCK + wave; board < n; board += waves) {
+        const uint32_t value = lane < CELLS ? boards[board * CELLS + lane] : 0xFFu;
+        const bool empty = value == 0u;
+        const uint64_t mask = __ballot(empty);
+        const uint32_t n_empty = (uint32_t)__popcll(mask);
+        strip_fence();  // (the previous board's reads of the two strips are done)
+        if (lane < CELLS) cell_bytes[lane] = (uint8_t)value;
+        if (empty) rank_lds[wave][__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))] = (uint8_t)lane;
+        strip_fence();
+        const uint32_t slots_used = n_empty ? 2u * n_empty : 1u;  // [ref: gameboard.py:156-157] a full board: itself
+        uint32_t *const block = out + board * OUT_DWORDS;
+#pragma unroll 4
+        for (uint32_t w = lane; w < OUT_DWORDS; w += 64u) {
+            const uint32_t slot = 4u * w / CELLS, first_cell = 4u * w % CELLS;
+            uint32_t word = cells_lds[wave][first_cell >> 2];
+            if (n_empty) {
+                const uint32_t cell = rank_lds[wave][(slot >> 1) & 63u];  // (& 63: slots past the used ones read a stale byte, zeroed below)
+                if ((cell >> 2) == (first_cell >> 2)) word |= ((slot & 1u) + 1u) << (8u * (cell & 3u));  // tile 2 then tile 4 into the empty cell
+            }
+            block[w] = slot < slots_used ? word : 0u;
+        }
+        if (lane == 0u) count_out[board] = (uint8_t)slots_used;
+    }
+    (void)BOARD_DWORDS;
+}
+
 int check_nxn(const char *who, uint64_t n, uint32_t size)
 {
     if (size < 2u || size > (uint32_t)NXN_MAX) return fail(ENV2048_ERR_INVALID_ARG, "%s: size must be in [2, %d], got %u", who, NXN_MAX, size);
@@ -402,6 +447,18 @@ int env2048_nxn_chance_outcomes(int device, void *stream, uint64_t n, uint32_t s
     if (!boards || !out_boards || !out_count) return fail(ENV2048_ERR_INVALID_ARG, "env2048_nxn_chance_outcomes: NULL argument");
     DeviceScope scope(device);
     if (scope.rc) return scope.rc;
+    if (size % 2u == 0u && ((uintptr_t)out_boards & 3u) == 0u) {  // one board per wave: coalesced stores
+        const unsigned blocks = (unsigned)((n + OUTCOME_WAVES_PER_BLOCK - 1) / OUTCOME_WAVES_PER_BLOCK < 8192u ? (n + OUTCOME_WAVES_PER_BLOCK - 1) / OUTCOME_WAVES_PER_BLOCK : 8192u);
+        uint32_t *out_words = reinterpret_cast<uint32_t *>(out_boards);
+        const dim3 block(64 * OUTCOME_WAVES_PER_BLOCK);
+        switch (size) {
+        case 2: hipLaunchKernelGGL(nxn_chance_outcomes_wave_kernel<2>, dim3(blocks), block, 0, (hipStream_t)stream, n, boards, out_words, out_count); break;
+        case 4: hipLaunchKernelGGL(nxn_chance_outcomes_wave_kernel<4>, dim3(blocks), block, 0, (hipStream_t)stream, n, boards, out_words, out_count); break;
+        case 6: hipLaunchKernelGGL(nxn_chance_outcomes_wave_kernel<6>, dim3(blocks), block, 0, (hipStream_t)stream, n, boards, out_words, out_count); break;
+        default: hipLaunchKernelGGL(nxn_chance_outcomes_wave_kernel<8>, dim3(blocks), block, 0, (hipStream_t)stream, n, boards, out_words, out_count); break;
+        }
+        return launched("env2048_nxn_chance_outcomes launch");
+    }
     NXN_LAUNCH(nxn_chance_outcomes_kernel, size, nxn_grid(n), stream, n, boards, out_boards, out_count)
     return launched("env2048_nxn_chance_outcomes launch");
 }
