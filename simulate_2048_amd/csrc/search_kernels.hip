@@ -32,12 +32,20 @@ __global__ __launch_bounds__(BLOCK) void afterstate_kernel(uint64_t n, const uin
 // computed once, up/down slide the row dwords as planes, left/right the transposed ones, and the two
 // directions of an axis differ only in the order the planes are handed to slide_merge_planes.
 // out_boards[4*i + a], out_reward[4*i + a]; out_legal[i] bit a = action a changes the board.
+// The four afterstates of board i lie side by side (64 bytes), so a lane storing its own four would put 16 bytes into each of 64
+// different 64-byte segments with every store instruction; instead the wave's 256 afterstates go through a wave-private LDS
+// strip ([action][lane]: conflict-free 16-byte writes) and leave as four store instructions of 1 KiB of consecutive bytes.
 __global__ __launch_bounds__(BLOCK) void afterstates4_kernel(uint64_t n, const uint8_t *boards, uint8_t *out_boards,
                                                              int32_t *out_reward, uint8_t *out_legal)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const Board bd = load_board(boards, i);
+    __shared__ uint4 strips[BLOCK / 64][4][64];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t first = (uint64_t)blockIdx.x * BLOCK + 64u * wave;
+    if (first >= n) return;  // (a whole wave; nothing below is shared between waves)
+    const uint64_t i = first + lane;
+    const bool active = i < n;
+    const Board bd = active ? load_board(boards, i) : Board{0u, 0u, 0u, 0u};
+    uint4(&strip)[4][64] = strips[wave];
     uint32_t c0, c1, c2, c3;
     transpose4x4(bd.r0, bd.r1, bd.r2, bd.r3, c0, c1, c2, c3);
     uint32_t legal = 0u;
@@ -47,13 +55,13 @@ __global__ __launch_bounds__(BLOCK) void afterstates4_kernel(uint64_t n, const u
         rewards.x = (int32_t)slide_merge_planes(a, b, c, d, changed);
         Board out;
         transpose4x4(a, b, c, d, out.r0, out.r1, out.r2, out.r3);
-        store_board(out_boards, 4 * i + 0, out);
+        strip[0][lane] = make_uint4(out.r0, out.r1, out.r2, out.r3);
         legal |= changed != 0u ? 1u : 0u;
     }
     {  // 1 = up: planes are the rows
         uint32_t a = bd.r0, b = bd.r1, c = bd.r2, d = bd.r3, changed;
         rewards.y = (int32_t)slide_merge_planes(a, b, c, d, changed);
-        store_board(out_boards, 4 * i + 1, Board{a, b, c, d});
+        strip[1][lane] = make_uint4(a, b, c, d);
         legal |= changed != 0u ? 2u : 0u;
     }
     {  // 2 = right: columns, last column is the wall
@@ -61,15 +69,25 @@ __global__ __launch_bounds__(BLOCK) void afterstates4_kernel(uint64_t n, const u
         rewards.z = (int32_t)slide_merge_planes(a, b, c, d, changed);
         Board out;
         transpose4x4(d, c, b, a, out.r0, out.r1, out.r2, out.r3);
-        store_board(out_boards, 4 * i + 2, out);
+        strip[2][lane] = make_uint4(out.r0, out.r1, out.r2, out.r3);
         legal |= changed != 0u ? 4u : 0u;
     }
     {  // 3 = down: rows, last row is the wall
         uint32_t a = bd.r3, b = bd.r2, c = bd.r1, d = bd.r0, changed;
         rewards.w = (int32_t)slide_merge_planes(a, b, c, d, changed);
-        store_board(out_boards, 4 * i + 3, Board{d, c, b, a});
+        strip[3][lane] = make_uint4(d, c, b, a);
         legal |= changed != 0u ? 8u : 0u;
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the strip is wave-private: LDS ops of a wave are ordered
+    __builtin_amdgcn_wave_barrier();
+    uint4 *out = reinterpret_cast<uint4 *>(out_boards) + 4u * first;
+    const uint64_t vectors = 4u * (n - first < 64u ? n - first : 64u);
+#pragma unroll
+    for (uint32_t j = 0; j < 4u; ++j) {
+        const uint32_t q = 64u * j + lane;  // afterstate q of the wave: board q >> 2, action q & 3
+        if (q < vectors) out[q] = strip[q & 3u][q >> 2];
+    }
+    if (!active) return;
     if (out_reward) reinterpret_cast<int4 *>(out_reward)[i] = rewards;
     if (out_legal) out_legal[i] = (uint8_t)legal;
 }
