@@ -31,6 +31,66 @@ __device__ __forceinline__ int4 unpack4(uint32_t r)
     return make_int4(v(r & 0xFFu), v((r >> 8) & 0xFFu), v((r >> 16) & 0xFFu), v(r >> 24));
 }
 
+// ---- coalesced int32 boards --------------------------------------------------------------------------------------------------
+// A board of int32 values is 64 bytes, so a lane that loads / stores its own board touches 16 bytes in each of 64 different
+// 64-byte segments with every instruction.  The batch kernels below go through a wave-private 1 KiB LDS strip instead: the
+// 256 rows of a wave's 64 boards are moved by four instructions of 1 KiB of CONSECUTIVE bytes each (lane l of instruction j
+// owns row (64 j + l) & 3 of board (64 j + l) >> 2) and converted to / from the packed form on that lane; the strip holds one
+// packed dword per row.  (At 2^22 boards: status 4.7 -> see profiles/r04_ee, r04_ff.)
+constexpr uint32_t NO_ROW = 0xFFFFFFFFu;  // (no packed row is all ones: exponents are <= 31)
+
+__device__ __forceinline__ void strip_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the strip is wave-private: LDS operations of a wave are ordered
+    __builtin_amdgcn_wave_barrier();
+}
+
+// boards [first, first + 64) of `boards` -> the packed board of every lane (boards past n: empty)
+__device__ __forceinline__ Board load_rows_coalesced(const int32_t *boards, uint32_t *strip, uint64_t first, uint64_t n, uint32_t lane)
+{
+    const int4 *rows = reinterpret_cast<const int4 *>(boards) + 4 * first;
+    const uint64_t live = 4u * (n - first < 64u ? n - first : 64u);
+    strip_sync();
+#pragma unroll
+    for (uint32_t j = 0; j < 4u; ++j) {
+        const uint32_t q = 64u * j + lane;
+        strip[q] = q < live ? pack4(rows[q]) : 0u;
+    }
+    strip_sync();
+    const uint4 v = reinterpret_cast<const uint4 *>(strip)[lane];
+    return Board{v.x, v.y, v.z, v.w};
+}
+
+// the packed board of every lane -> boards [first, first + 64) of `boards` as int32 values (`skip` lanes: nothing is written
+// for their board); `mirror` != 0: also `mirror` bytes further on (the caller's pinned-host copy of its results)
+__device__ __forceinline__ void store_rows_coalesced(int32_t *boards, int64_t mirror, uint32_t *strip, uint64_t first, uint64_t n, uint32_t lane,
+                                                     const Board &bd, bool skip)
+{
+    strip_sync();
+    reinterpret_cast<uint4 *>(strip)[lane] = skip ? make_uint4(NO_ROW, NO_ROW, NO_ROW, NO_ROW) : make_uint4(bd.r0, bd.r1, bd.r2, bd.r3);
+    strip_sync();
+    int4 *rows = reinterpret_cast<int4 *>(boards) + 4 * first;
+    const uint64_t live = 4u * (n - first < 64u ? n - first : 64u);
+#pragma unroll
+    for (uint32_t j = 0; j < 4u; ++j) {
+        const uint32_t q = 64u * j + lane;
+        const uint32_t x = strip[q];
+        if (x != NO_ROW && q < live) {
+            const int4 v = unpack4(x);
+            rows[q] = v;
+            if (mirror) *reinterpret_cast<int4 *>(reinterpret_cast<char *>(rows + q) + mirror) = v;
+        }
+    }
+}
+
+// the f32 observation of every lane's board, coalesced (board_io.hpp), and its host-mirror copy
+__device__ __forceinline__ void store_obs_rows_coalesced(float *obs, int64_t mirror, uint32_t *strip, uint64_t first, uint64_t n, uint32_t lane,
+                                                         const Board &bd, bool skip)
+{
+    store_obs_coalesced(obs, strip, first, n, lane, bd, skip);
+    if (mirror) store_obs_coalesced(reinterpret_cast<float *>(reinterpret_cast<char *>(obs) + mirror), strip, first, n, lane, bd, skip);
+}
+
 // Completion signal of a SINGLE-WORKGROUP launch with a host mirror (the *_signalled entry points): once every thread's
 // stores -- the device copies and the host-mirror copies -- are performed at system scope, one thread stores
 // `sequence_value` into the caller's pinned host word.  The host polls that word instead of synchronising the stream
@@ -46,11 +106,15 @@ __device__ __forceinline__ void signal_sequence(uint64_t *sequence, uint64_t val
 }
 
 // One environment: `*_in` -> `*_out` (the same pointers for the in-place entry point): a finished game copies through.
+// COOP: the board comes in packed (`bd`, loaded by the wave together) and the new board / the observation are NOT stored here
+// -- the caller stores them for the whole wave (store_rows_coalesced / store_obs_rows_coalesced) when `moved` comes back true
+// (a frozen game's board is copied through here, value by value, as it came in).
+template <bool COOP>
 __device__ __forceinline__ void step_state_i32_one(uint64_t i, uint64_t env_base, const int32_t *boards_in, int32_t *boards_out,
                                                    const int32_t *actions, const int32_t *step_count_in, int32_t *step_count_out,
                                                    const uint8_t *done_in, uint8_t *done_out, const float *total_in, float *total_out,
                                                    float *reward_out, int32_t *max_tile, RngKey key, const uint2 *keys, float *obs_out,
-                                                   uint32_t *legal4_out, int64_t mirror)
+                                                   uint32_t *legal4_out, int64_t mirror, Board &bd, bool &moved)
 {
     // `mirror` != 0: every output element is ALSO written `mirror` bytes further on -- the caller's pinned-host copy of its
     // result block (a few hundred bytes at the reference's batch sizes), so that reading the results back needs no copy
@@ -60,9 +124,9 @@ __device__ __forceinline__ void step_state_i32_one(uint64_t i, uint64_t env_base
     };
     const int4 *rows_in = reinterpret_cast<const int4 *>(boards_in) + 4 * i;
     int4 *rows_out = reinterpret_cast<int4 *>(boards_out) + 4 * i;
-    const int4 v0 = rows_in[0], v1 = rows_in[1], v2 = rows_in[2], v3 = rows_in[3];
-    Board bd{pack4(v0), pack4(v1), pack4(v2), pack4(v3)};
+    if (!COOP) bd = Board{pack4(rows_in[0]), pack4(rows_in[1]), pack4(rows_in[2]), pack4(rows_in[3])};
     const bool was_done = done_in[i] != 0;
+    moved = !was_done;
     const bool in_place = boards_in == boards_out && done_in == done_out && step_count_in == step_count_out && total_in == total_out;
     // keyed form: environment i draws from ITS OWN key, as environment 0 at step 0 of the stream seeded with
     // (keys[i][0] << 32) | keys[i][1] -- row i of the batch equals the single-environment call with keys[i]
@@ -86,10 +150,12 @@ __device__ __forceinline__ void step_state_i32_one(uint64_t i, uint64_t env_base
         afterstate(bd, (uint32_t)actions[i] & 3u, score, changed);
         spawn_tile_word(bd, word, changed);
         reward = (float)score;  // exact: a step's score is < 2^24
-        put(rows_out + 0, unpack4(bd.r0));
-        put(rows_out + 1, unpack4(bd.r1));
-        put(rows_out + 2, unpack4(bd.r2));
-        put(rows_out + 3, unpack4(bd.r3));
+        if (!COOP) {
+            put(rows_out + 0, unpack4(bd.r0));
+            put(rows_out + 1, unpack4(bd.r1));
+            put(rows_out + 2, unpack4(bd.r2));
+            put(rows_out + 3, unpack4(bd.r3));
+        }
         legal_bits = legal_mask(bd);
         done = legal_bits == 0u ? 1 : 0;
         steps += 1;
@@ -99,16 +165,16 @@ __device__ __forceinline__ void step_state_i32_one(uint64_t i, uint64_t env_base
     }
     // what the caller asks about the NEW state right after a move (reinforce/training/self_play.py:316-317), in the same
     // launch: observation and (N, 4) legal bytes of the board this step leaves behind -- a finished game's unchanged board
-    if (obs_out) {
+    if (obs_out && !COOP) {
         store_obs(obs_out, i, bd);
         if (mirror) store_obs(reinterpret_cast<float *>(reinterpret_cast<char *>(obs_out) + mirror), i, bd);
     }
     if (legal4_out) put(legal4_out + i, (legal_bits & 1u) | ((legal_bits & 2u) << 7) | ((legal_bits & 4u) << 14) | ((legal_bits & 8u) << 21));
     if (was_done && !in_place) {  // the values as they came in (not re-derived from the packed form)
-        put(rows_out + 0, v0);
-        put(rows_out + 1, v1);
-        put(rows_out + 2, v2);
-        put(rows_out + 3, v3);
+        put(rows_out + 0, rows_in[0]);
+        put(rows_out + 1, rows_in[1]);
+        put(rows_out + 2, rows_in[2]);
+        put(rows_out + 3, rows_in[3]);
     }
     if (!was_done || !in_place) {
         put(done_out + i, done);
@@ -139,10 +205,20 @@ __global__ __launch_bounds__(BLOCK) void step_state_i32_kernel(uint64_t n, uint6
                                                                uint32_t *legal4_out, int64_t mirror, uint64_t *sequence,
                                                                uint64_t sequence_value)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i < n)
-        step_state_i32_one(i, env_base, boards_in, boards_out, actions, step_count_in, step_count_out, done_in, done_out, total_in, total_out,
-                           reward_out, max_tile, key, keys, obs_out, legal4_out, mirror);
+    __shared__ __attribute__((aligned(16))) uint32_t strips[BLOCK / 64][256];
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (block_for(): a small launch runs a smaller workgroup)
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t first = i - lane;
+    uint32_t *const strip = strips[threadIdx.x >> 6];
+    if (first < n) {  // (wave-uniform)
+        Board bd = load_rows_coalesced(boards_in, strip, first, n, lane);
+        bool moved = false;
+        if (i < n)
+            step_state_i32_one<true>(i, env_base, boards_in, boards_out, actions, step_count_in, step_count_out, done_in, done_out, total_in,
+                                     total_out, reward_out, max_tile, key, keys, obs_out, legal4_out, mirror, bd, moved);
+        store_rows_coalesced(boards_out, mirror, strip, first, n, lane, bd, !moved);
+        if (obs_out) store_obs_rows_coalesced(obs_out, mirror, strip, first, n, lane, bd, i >= n);
+    }
     signal_sequence(sequence, sequence_value);  // (outside the bounds check: every thread of the block takes part)
 }
 
@@ -161,17 +237,21 @@ __global__ __launch_bounds__(ENV2048_INLINE_MAX_ENVS) void step_state_i32_inline
     int64_t mirror, uint64_t *sequence, uint64_t sequence_value, const InlineInputs in)
 {
     const uint64_t i = threadIdx.x;
-    if (i < n)
-        step_state_i32_one(i, 0u, boards_in, boards_out, in.actions, step_count_in, step_count_out, done_in, done_out, total_in, total_out,
-                           reward_out, max_tile, RngKey{0u, 0u, 0u, 0u}, in.keys, obs_out, legal4_out, mirror);
+    if (i < n) {  // (the latency path, at most one wave of boards: every lane moves its own board)
+        Board bd;
+        bool moved;
+        step_state_i32_one<false>(i, 0u, boards_in, boards_out, in.actions, step_count_in, step_count_out, done_in, done_out, total_in, total_out,
+                                  reward_out, max_tile, RngKey{0u, 0u, 0u, 0u}, in.keys, obs_out, legal4_out, mirror, bd, moved);
+    }
     signal_sequence(sequence, sequence_value);
 }
 
 // batched_reset with one PRNG key per environment, straight to int32 value boards: board i = the fresh board of
 // environment 0 at step 0 of the stream seeded with keys[i] (= create_initial_board(keys[i])).
 // step_count / done / total (each may be NULL): the bookkeeping fields of a fresh GameState, written as zeros.
-__device__ __forceinline__ void reset_keyed_i32_one(uint64_t i, const uint2 *keys, int32_t *boards, float *obs_out, uint32_t *legal4_out,
-                                                    int32_t *step_count, uint8_t *done, float *total, int64_t mirror)
+// (The board and its observation are stored by the caller, for the whole wave at once.)
+__device__ __forceinline__ Board reset_keyed_i32_one(uint64_t i, const uint2 *keys, uint32_t *legal4_out, int32_t *step_count, uint8_t *done,
+                                                     float *total, int64_t mirror)
 {
     auto put = [mirror](auto *p, auto v) {  // (see step_state_i32_kernel)
         *p = v;
@@ -181,15 +261,6 @@ __device__ __forceinline__ void reset_keyed_i32_one(uint64_t i, const uint2 *key
     uint32_t w0, w1, w2, w3;
     env_block(RngKey{k.y, k.x, 0u, 0u}, 0u, STREAM_RESET, w0, w1, w2, w3);
     const Board bd = fresh_board(w0, w1, w2, w3);
-    int4 *rows = reinterpret_cast<int4 *>(boards) + 4 * i;
-    put(rows + 0, unpack4(bd.r0));
-    put(rows + 1, unpack4(bd.r1));
-    put(rows + 2, unpack4(bd.r2));
-    put(rows + 3, unpack4(bd.r3));
-    if (obs_out) {
-        store_obs(obs_out, i, bd);
-        if (mirror) store_obs(reinterpret_cast<float *>(reinterpret_cast<char *>(obs_out) + mirror), i, bd);
-    }
     if (legal4_out) {
         const uint32_t bits = legal_mask(bd);
         put(legal4_out + i, (bits & 1u) | ((bits & 2u) << 7) | ((bits & 4u) << 14) | ((bits & 8u) << 21));
@@ -197,14 +268,24 @@ __device__ __forceinline__ void reset_keyed_i32_one(uint64_t i, const uint2 *key
     if (step_count) put(step_count + i, (int32_t)0);
     if (done) put(done + i, (uint8_t)0);
     if (total) put(total + i, 0.0f);
+    return bd;
 }
 
 __global__ __launch_bounds__(BLOCK) void reset_keyed_i32_kernel(uint64_t n, const uint2 *keys, int32_t *boards, float *obs_out,
                                                                 uint32_t *legal4_out, int32_t *step_count, uint8_t *done, float *total,
                                                                 int64_t mirror, uint64_t *sequence, uint64_t sequence_value)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i < n) reset_keyed_i32_one(i, keys, boards, obs_out, legal4_out, step_count, done, total, mirror);
+    __shared__ __attribute__((aligned(16))) uint32_t strips[BLOCK / 64][256];
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t first = i - lane;
+    uint32_t *const strip = strips[threadIdx.x >> 6];
+    if (first < n) {  // (wave-uniform)
+        Board bd{0u, 0u, 0u, 0u};
+        if (i < n) bd = reset_keyed_i32_one(i, keys, legal4_out, step_count, done, total, mirror);
+        store_rows_coalesced(boards, mirror, strip, first, n, lane, bd, i >= n);
+        if (obs_out) store_obs_rows_coalesced(obs_out, mirror, strip, first, n, lane, bd, i >= n);
+    }
     signal_sequence(sequence, sequence_value);
 }
 
@@ -214,11 +295,15 @@ __global__ __launch_bounds__(BLOCK) void reset_keyed_i32_kernel(uint64_t n, cons
 __global__ __launch_bounds__(BLOCK) void status_i32_kernel(uint64_t n, const int32_t *boards, float *obs, uint32_t *legal4,
                                                            uint8_t *done)
 {
+    __shared__ __attribute__((aligned(16))) uint32_t strips[BLOCK / 64][256];
     const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t first = i - lane;
+    if (first >= n) return;  // (a whole wave; nothing below is shared between waves)
+    uint32_t *const strip = strips[threadIdx.x >> 6];
+    const Board bd = load_rows_coalesced(boards, strip, first, n, lane);
+    if (obs) store_obs_coalesced(obs, strip, first, n, lane, bd, i >= n);
     if (i >= n) return;
-    const int4 *rows = reinterpret_cast<const int4 *>(boards) + 4 * i;
-    const Board bd{pack4(rows[0]), pack4(rows[1]), pack4(rows[2]), pack4(rows[3])};
-    if (obs) store_obs(obs, i, bd);
     if (legal4 || done) {
         const uint32_t bits = legal_mask(bd);
         if (legal4) legal4[i] = (bits & 1u) | ((bits & 2u) << 7) | ((bits & 4u) << 14) | ((bits & 8u) << 21);
@@ -231,18 +316,18 @@ __global__ __launch_bounds__(BLOCK) void status_i32_kernel(uint64_t n, const int
 __global__ __launch_bounds__(BLOCK) void afterstate_i32_kernel(uint64_t n, const int32_t *boards_in, const int32_t *actions, uint32_t action,
                                                                int32_t *boards_out, int32_t *reward, uint8_t *changed_out)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const int4 *rows = reinterpret_cast<const int4 *>(boards_in) + 4 * i;
-    Board bd{pack4(rows[0]), pack4(rows[1]), pack4(rows[2]), pack4(rows[3])};
+    __shared__ __attribute__((aligned(16))) uint32_t strips[BLOCK / 64][256];
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t first = i - lane;
+    if (first >= n) return;  // (a whole wave; nothing below is shared between waves)
+    uint32_t *const strip = strips[threadIdx.x >> 6];
+    Board bd = load_rows_coalesced(boards_in, strip, first, n, lane);
     uint32_t score;
     bool changed;
-    afterstate(bd, (actions ? (uint32_t)actions[i] : action) & 3u, score, changed);
-    int4 *out = reinterpret_cast<int4 *>(boards_out) + 4 * i;
-    out[0] = unpack4(bd.r0);
-    out[1] = unpack4(bd.r1);
-    out[2] = unpack4(bd.r2);
-    out[3] = unpack4(bd.r3);
+    afterstate(bd, ((actions && i < n) ? (uint32_t)actions[i] : action) & 3u, score, changed);
+    store_rows_coalesced(boards_out, 0, strip, first, n, lane, bd, i >= n);
+    if (i >= n) return;
     if (reward) reward[i] = (int32_t)score;
     if (changed_out) changed_out[i] = changed ? 1 : 0;
 }
