@@ -1,11 +1,25 @@
 // device_scope.hpp -- HIP-side helpers of the C-ABI entry points: device selection, launch geometry, error mapping.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "errors.hpp"
 
 namespace env2048 {
 namespace host {
+
+// Store policy of the write-dominated kernels (chance outcomes, one-hot encoding, unpacking): an output larger than the 256 MiB
+// Infinity Cache is a stream nobody on the chip reads back soon -- non-temporal stores hold 6.1 - 6.6 TB/s there where plain
+// stores drop to 3.9 (profiles/r04_gg_*); a smaller one stays in the cache and plain stores are the faster ones.
+// ENV2048_EXP_STREAM_STORES=1 / 0 forces either (A/B measurements).
+inline bool stream_output(uint64_t bytes)
+{
+    static const int forced = [] {
+        const char *e = getenv("ENV2048_EXP_STREAM_STORES");
+        return e ? (e[0] == '1' ? 1 : 0) : -1;
+    }();
+    return forced >= 0 ? forced == 1 : bytes > (256ull << 20);
+}
 
 inline int hip_fail(hipError_t e, const char *what)
 {

@@ -339,7 +339,7 @@ __global__ __launch_bounds__(64 * OUTCOME_WAVES_PER_BLOCK) void nxn_chance_outco
                 const uint32_t cell = rank_lds[wave][(slot >> 1) & 63u];  // (& 63: slots past the used ones read a stale byte, zeroed below)
                 if ((cell >> 2) == (first_cell >> 2)) word |= ((slot & 1u) + 1u) << (8u * (cell & 3u));  // tile 2 then tile 4 into the empty cell
             }
-            block[w] = slot < slots_used ? word : 0u;
+            block[w] = slot < slots_used ? word : 0u;  // (dword stores: non-temporal ones gain nothing at this width, measured)
         }
         if (lane == 0u) count_out[board] = (uint8_t)slots_used;
     }

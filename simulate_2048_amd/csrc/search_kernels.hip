@@ -798,7 +798,9 @@ __global__ __launch_bounds__(BLOCK) void spawn_random_kernel(uint64_t n, uint64_
     }
     store_board(boards, i, bd);
 }
-// one thread per (board, outcome slot): 32 consecutive lanes write the 512 B of one board's outcomes
+// one thread per (board, outcome slot): 32 consecutive lanes write the 512 B of one board's outcomes.  STREAM: the output is
+// larger than the Infinity Cache and nobody on the chip reads it back soon -- non-temporal stores (chosen on the host by size).
+template <bool STREAM>
 __global__ __launch_bounds__(BLOCK) void chance_outcomes_kernel(uint64_t n, const uint8_t *boards, uint8_t *out_boards,
                                                                 float *out_prob, uint8_t *out_count)
 {
@@ -820,8 +822,14 @@ __global__ __launch_bounds__(BLOCK) void chance_outcomes_kernel(uint64_t n, cons
     } else {
         bd = Board{0u, 0u, 0u, 0u};
     }
-    store_board(out_boards, t, bd);
-    out_prob[t] = prob;
+    if (STREAM) {
+        typedef uint32_t vec4 __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store(vec4{bd.r0, bd.r1, bd.r2, bd.r3}, reinterpret_cast<vec4 *>(out_boards) + t);
+        __builtin_nontemporal_store(prob, out_prob + t);
+    } else {
+        store_board(out_boards, t, bd);
+        out_prob[t] = prob;
+    }
     if (out_count && slot == 0u) out_count[i] = (uint8_t)(n_empty ? 2u * n_empty : 1u);
 }
 
@@ -903,8 +911,14 @@ int env2048_chance_outcomes(int device, void *stream, uint64_t n, const uint8_t 
     if (int rc = check_count(32 * n)) return rc;
     DeviceScope scope(device);
     if (scope.rc) return scope.rc;
-    hipLaunchKernelGGL(chance_outcomes_kernel, grid_for(32 * n), dim3(BLOCK), 0, (hipStream_t)stream, n, boards, out_boards,
-                       out_prob, out_count);
+    const char *force = getenv("ENV2048_EXP_OUTCOME_STORES");  // (A/B aid of tools/bench_all_entries.py: "stream" / "plain")
+    const bool streaming = force ? force[0] == 's' : n * 641u > (256ull << 20);  // (the 256 MiB Infinity Cache)  // 32 x (16 + 4) + 1 bytes per board
+    if (streaming)
+        hipLaunchKernelGGL(chance_outcomes_kernel<true>, grid_for(32 * n), dim3(BLOCK), 0, (hipStream_t)stream, n, boards, out_boards, out_prob,
+                           out_count);
+    else
+        hipLaunchKernelGGL(chance_outcomes_kernel<false>, grid_for(32 * n), dim3(BLOCK), 0, (hipStream_t)stream, n, boards, out_boards, out_prob,
+                           out_count);
     return launched("env2048_chance_outcomes launch");
 }
 

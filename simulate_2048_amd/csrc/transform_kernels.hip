@@ -62,6 +62,8 @@ __global__ __launch_bounds__(BLOCK) void onehot_kernel(uint64_t n, const uint8_t
 // Same output, 16 bytes per thread (1 KiB per wave store) for 16-byte aligned `out`: instead of testing every
 // output byte, a thread walks the (at most 16/width + 2) cells that overlap its chunk and drops each cell's
 // single 1 into place.  One division per chunk, done as a multiply (exact for block-local offsets < 2^18).
+// STREAM: non-temporal stores (device_scope.hpp stream_output()).
+template <bool STREAM>
 __global__ __launch_bounds__(BLOCK) void onehot_kernel16(uint64_t n, const uint8_t *boards, uint32_t width, uint32_t inv_width,
                                                          uint4 *out)
 {
@@ -89,7 +91,12 @@ __global__ __launch_bounds__(BLOCK) void onehot_kernel16(uint64_t n, const uint8
             ++cell;
             base += width;
         }
-        dst[q] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+        if (STREAM) {
+            typedef uint32_t vec4 __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(vec4{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)}, reinterpret_cast<vec4 *>(dst) + q);
+        } else {
+            dst[q] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+        }
     }
 }
 
@@ -148,7 +155,7 @@ __global__ __launch_bounds__(BLOCK) void unpack_kernel(uint64_t n_quads, const u
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const uint32_t e = (x >> (8 * j)) & 0xFFu;
-        values[4 * q + j] = e ? (T)((uint64_t)1 << (e & 63u)) : (T)0;
+        values[4 * q + j] = e ? (T)((uint64_t)1 << (e & 63u)) : (T)0;  // (plain stores: non-temporal ones halve the rate of the int64 form, measured)
     }
 }
 
@@ -201,8 +208,11 @@ int env2048_encode_onehot(int device, void *stream, uint64_t n, const uint8_t *b
     if (int rc = check_count(n)) return rc;
     DeviceScope scope(device);
     if (scope.rc) return scope.rc;
-    if (!misaligned(out, 16))
-        hipLaunchKernelGGL(onehot_kernel16, dim3((unsigned)((n + 63) / 64)), dim3(BLOCK), 0, (hipStream_t)stream, n, boards, width,
+    if (!misaligned(out, 16) && stream_output(n * 16u * width))
+        hipLaunchKernelGGL(onehot_kernel16<true>, dim3((unsigned)((n + 63) / 64)), dim3(BLOCK), 0, (hipStream_t)stream, n, boards, width,
+                           0xFFFFFFFFu / width + 1u, reinterpret_cast<uint4 *>(out));
+    else if (!misaligned(out, 16))
+        hipLaunchKernelGGL(onehot_kernel16<false>, dim3((unsigned)((n + 63) / 64)), dim3(BLOCK), 0, (hipStream_t)stream, n, boards, width,
                            0xFFFFFFFFu / width + 1u, reinterpret_cast<uint4 *>(out));
     else
         hipLaunchKernelGGL(onehot_kernel, dim3((unsigned)((n + 63) / 64)), dim3(BLOCK), 0, (hipStream_t)stream, n, boards, width,
