@@ -261,110 +261,166 @@ struct EpisodeRows {
     const uint8_t *max_exp;  // may be NULL
 };
 
-constexpr uint32_t EPISODE_ROWS_IN_FLIGHT = 8;  // rows whose loads are issued together (the walk itself is sequential)
+constexpr uint32_t EPISODE_ROWS_IN_FLIGHT = 8;  // rows whose loads are issued together (the walk itself is sequential; 16 / 32 measured: no gain)
 
+// Both kernels exist for E = 1 and E = 4 adjacent games per lane.  With one game per lane a wave reads 64 bytes of a `done` /
+// `max_exp` row per load instruction -- a stream of tiny requests (1.9 - 2.4 TB/s of row bytes, profiles/r04_jj_*); with four,
+// a lane takes a dword of flags and 16 bytes of rewards per row and writes 16 bytes of `episode_of`, and walks four independent
+// games.  E = 4 needs n and row_stride to be multiples of 4 and the rows aligned for those accesses (the host checks).
+template <int E>
+__device__ __forceinline__ uint32_t load_flags(const uint8_t *row, uint64_t i0)
+{
+    if (E == 4) return *reinterpret_cast<const uint32_t *>(row + i0);
+    return row[i0];
+}
+
+template <int E>
 __global__ __launch_bounds__(256) void count_episodes_kernel(EpisodeRows a, uint32_t *counts)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= a.n) return;
+    const uint64_t i0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * E;
+    if (i0 >= a.n) return;
     const bool frozen = (a.flags & ENV2048_EPISODES_FROZEN) != 0u;
-    uint32_t count = 0u, open = 0u, phys = a.first_row;
-    bool stop = false;
-    for (uint32_t r0 = 0; r0 < a.rows && !stop; r0 += EPISODE_ROWS_IN_FLIGHT) {
-        uint8_t d[EPISODE_ROWS_IN_FLIGHT];
+    uint32_t count[E], open[E], phys = a.first_row;
+    bool stop[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) count[e] = open[e] = 0u, stop[e] = false;
+    bool all_stopped = false;
+    for (uint32_t r0 = 0; r0 < a.rows && !all_stopped; r0 += EPISODE_ROWS_IN_FLIGHT) {
+        uint32_t d[EPISODE_ROWS_IN_FLIGHT];
         const uint32_t batch = min(EPISODE_ROWS_IN_FLIGHT, a.rows - r0);
 #pragma unroll
         for (uint32_t u = 0; u < EPISODE_ROWS_IN_FLIGHT; ++u) {
-            d[u] = 0;
+            d[u] = 0u;
             if (u < batch) {
-                d[u] = a.done[(uint64_t)phys * a.row_stride + i];
+                d[u] = load_flags<E>(a.done + (uint64_t)phys * a.row_stride, i0);
                 phys = phys + 1u == a.ring_rows ? 0u : phys + 1u;
             }
         }
 #pragma unroll
         for (uint32_t u = 0; u < EPISODE_ROWS_IN_FLIGHT; ++u) {
-            if (u < batch && !stop) {
-                ++open;
-                if (d[u]) {
-                    ++count;
-                    open = 0u;
-                    stop = frozen;  // a finished game stops recording (self_play.py:359,368)
-                }
-            }
-        }
-    }
-    counts[i] = count + (open ? 1u : 0u);
-}
-
-__global__ __launch_bounds__(256) void segment_episodes_kernel(EpisodeRows a, const uint64_t *offsets, env2048_episode *episodes,
-                                                               int32_t *episode_of)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= a.n) return;
-    const bool frozen = (a.flags & ENV2048_EPISODES_FROZEN) != 0u;
-    const bool reward_f32 = (a.flags & ENV2048_EPISODES_REWARD_F32) != 0u;
-    uint64_t slot = offsets[i];
-    uint32_t start = 0u, length = 0u, best = 0u, phys = a.first_row, r = 0u;
-    double total = 0.0;
-    bool stop = false;
-    auto emit = [&](bool terminated) {
-        env2048_episode e;
-        e.env = (uint32_t)i;
-        e.start = start;
-        e.length = length;
-        e.terminated = terminated ? 1 : 0;
-        e.max_exp = (uint8_t)best;
-        e.reserved = 0;
-        e.total_reward = total;
-        episodes[slot++] = e;
-    };
-    while (r < a.rows && !stop) {
-        uint8_t d[EPISODE_ROWS_IN_FLIGHT], m[EPISODE_ROWS_IN_FLIGHT];
-        double w[EPISODE_ROWS_IN_FLIGHT];
-        uint64_t at[EPISODE_ROWS_IN_FLIGHT];
-        const uint32_t batch = min(EPISODE_ROWS_IN_FLIGHT, a.rows - r);
-#pragma unroll
-        for (uint32_t u = 0; u < EPISODE_ROWS_IN_FLIGHT; ++u) {
-            d[u] = m[u] = 0;
-            w[u] = 0.0;
-            at[u] = 0;
             if (u < batch) {
-                at[u] = (uint64_t)phys * a.row_stride + i;
-                phys = phys + 1u == a.ring_rows ? 0u : phys + 1u;
-                d[u] = a.done[at[u]];
-                if (a.reward) w[u] = reward_f32 ? (double)static_cast<const float *>(a.reward)[at[u]] : (double)static_cast<const int32_t *>(a.reward)[at[u]];
-                if (a.max_exp) m[u] = a.max_exp[at[u]];
-            }
-        }
 #pragma unroll
-        for (uint32_t u = 0; u < EPISODE_ROWS_IN_FLIGHT; ++u) {
-            if (u < batch) {
-                if (stop) {  // frozen: rows after the end of the game belong to no episode
-                    if (episode_of) episode_of[at[u]] = -1;
-                } else {
-                    total += w[u];
-                    best = max(best, (uint32_t)m[u]);
-                    ++length;
-                    if (episode_of) episode_of[at[u]] = (int32_t)slot;
-                    if (d[u]) {
-                        emit(true);
-                        start = r + u + 1u;
-                        length = 0u;
-                        best = 0u;
-                        total = 0.0;
-                        stop = frozen;
+                for (int e = 0; e < E; ++e) {
+                    if (!stop[e]) {
+                        ++open[e];
+                        if ((d[u] >> (8 * e)) & 0xFFu) {
+                            ++count[e];
+                            open[e] = 0u;
+                            stop[e] = frozen;  // a finished game stops recording (self_play.py:359,368)
+                        }
                     }
                 }
             }
         }
-        r += batch;
+        all_stopped = true;
+#pragma unroll
+        for (int e = 0; e < E; ++e) all_stopped = all_stopped && stop[e];
     }
-    if (length) emit(false);
-    if (episode_of)
-        for (; r < a.rows; ++r) {
-            episode_of[(uint64_t)phys * a.row_stride + i] = -1;
-            phys = phys + 1u == a.ring_rows ? 0u : phys + 1u;
+#pragma unroll
+    for (int e = 0; e < E; ++e) counts[i0 + e] = count[e] + (open[e] ? 1u : 0u);
+}
+
+template <int E>
+__global__ __launch_bounds__(256) void segment_episodes_kernel(EpisodeRows a, const uint64_t *offsets, env2048_episode *episodes,
+                                                               int32_t *episode_of)
+{
+    const uint64_t i0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * E;
+    if (i0 >= a.n) return;
+    const bool frozen = (a.flags & ENV2048_EPISODES_FROZEN) != 0u;
+    const bool reward_f32 = (a.flags & ENV2048_EPISODES_REWARD_F32) != 0u;
+    uint64_t slot[E];
+    uint32_t start[E], length[E], best[E], phys = a.first_row, r = 0u;
+    double total[E];
+    bool stop[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        slot[e] = offsets[i0 + e];
+        start[e] = length[e] = best[e] = 0u;
+        total[e] = 0.0;
+        stop[e] = false;
+    }
+    auto emit = [&](int e, bool terminated) {
+        env2048_episode rec;
+        rec.env = (uint32_t)(i0 + e);
+        rec.start = start[e];
+        rec.length = length[e];
+        rec.terminated = terminated ? 1 : 0;
+        rec.max_exp = (uint8_t)best[e];
+        rec.reserved = 0;
+        rec.total_reward = total[e];
+        episodes[slot[e]++] = rec;
+    };
+    bool all_stopped = false;
+    while (r < a.rows && !(all_stopped && !episode_of)) {  // (with episode_of the rows after the end of a frozen game get their -1)
+        uint32_t d[EPISODE_ROWS_IN_FLIGHT], m[EPISODE_ROWS_IN_FLIGHT];
+        uint32_t w[EPISODE_ROWS_IN_FLIGHT][E];  // reward bits (int32 or float32)
+        uint64_t at[EPISODE_ROWS_IN_FLIGHT];
+        const uint32_t batch = min(EPISODE_ROWS_IN_FLIGHT, a.rows - r);
+#pragma unroll
+        for (uint32_t u = 0; u < EPISODE_ROWS_IN_FLIGHT; ++u) {
+            d[u] = m[u] = 0u;
+            at[u] = 0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) w[u][e] = 0u;
+            if (u < batch) {
+                at[u] = (uint64_t)phys * a.row_stride + i0;
+                phys = phys + 1u == a.ring_rows ? 0u : phys + 1u;
+                d[u] = load_flags<E>(a.done, at[u]);
+                if (a.reward) {
+                    if (E == 4) {
+                        const uint4 v = *reinterpret_cast<const uint4 *>(static_cast<const uint32_t *>(a.reward) + at[u]);
+                        w[u][0] = v.x, w[u][E > 1 ? 1 : 0] = v.y, w[u][E > 2 ? 2 : 0] = v.z, w[u][E > 3 ? 3 : 0] = v.w;
+                    } else {
+                        w[u][0] = static_cast<const uint32_t *>(a.reward)[at[u]];
+                    }
+                }
+                if (a.max_exp) m[u] = load_flags<E>(a.max_exp, at[u]);
+            }
         }
+#pragma unroll
+        for (uint32_t u = 0; u < EPISODE_ROWS_IN_FLIGHT; ++u) {
+            if (u < batch) {
+                int32_t owner[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    owner[e] = -1;  // frozen: rows after the end of the game belong to no episode
+                    if (!stop[e]) {
+                        total[e] += reward_f32 ? (double)__uint_as_float(w[u][e]) : (double)(int32_t)w[u][e];
+                        best[e] = max(best[e], (m[u] >> (8 * e)) & 0xFFu);
+                        ++length[e];
+                        owner[e] = (int32_t)slot[e];
+                        if ((d[u] >> (8 * e)) & 0xFFu) {
+                            emit(e, true);
+                            start[e] = r + u + 1u;
+                            length[e] = 0u;
+                            best[e] = 0u;
+                            total[e] = 0.0;
+                            stop[e] = frozen;
+                        }
+                    }
+                }
+                if (episode_of) {
+                    if (E == 4)
+                        *reinterpret_cast<int4 *>(episode_of + at[u]) = make_int4(owner[0], owner[E > 1 ? 1 : 0], owner[E > 2 ? 2 : 0], owner[E > 3 ? 3 : 0]);
+                    else
+                        episode_of[at[u]] = owner[0];
+                }
+            }
+        }
+        r += batch;
+        all_stopped = true;
+#pragma unroll
+        for (int e = 0; e < E; ++e) all_stopped = all_stopped && stop[e];
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+        if (length[e]) emit(e, false);
+}
+
+// E = 4 when every access of the four-games-per-lane form is aligned
+inline bool episodes_by_four(uint64_t n, uint64_t row_stride, const void *done, const void *reward, const void *max_exp, const void *episode_of)
+{
+    return n % 4 == 0 && row_stride % 4 == 0 && !misaligned(done, 4) && !misaligned(max_exp, 4) && !misaligned(reward, 16) && !misaligned(episode_of, 16);
 }
 
 }  // namespace
@@ -392,7 +448,10 @@ int env2048_count_episodes(int device, void *stream, uint64_t n, uint64_t row_st
     DeviceScope scope(device);
     if (scope.rc) return scope.rc;
     const EpisodeRows a{n, row_stride, rows, first_row, ring_rows, flags, done, nullptr, nullptr};
-    hipLaunchKernelGGL(count_episodes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, counts);
+    if (episodes_by_four(n, row_stride, done, nullptr, nullptr, nullptr))
+        hipLaunchKernelGGL(count_episodes_kernel<4>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, counts);
+    else
+        hipLaunchKernelGGL(count_episodes_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, counts);
     return launched("env2048_count_episodes launch");
 }
 
@@ -408,8 +467,12 @@ int env2048_segment_episodes(int device, void *stream, uint64_t n, uint64_t row_
     DeviceScope scope(device);
     if (scope.rc) return scope.rc;
     const EpisodeRows a{n, row_stride, rows, first_row, ring_rows, flags, done, reward, max_exp};
-    hipLaunchKernelGGL(segment_episodes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, offsets,
-                       episodes, episode_of);
+    if (episodes_by_four(n, row_stride, done, reward, max_exp, episode_of))
+        hipLaunchKernelGGL(segment_episodes_kernel<4>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, offsets, episodes,
+                           episode_of);
+    else
+        hipLaunchKernelGGL(segment_episodes_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, offsets, episodes,
+                           episode_of);
     return launched("env2048_segment_episodes launch");
 }
 

@@ -333,6 +333,45 @@ def test_device_step_counter_and_graph_replay(make_env):
         assert env.step_index == 501 + K * (replay + 1) == ref.step_index
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,stride', [(304, 304), (301, 304), (300, 301), (4, 4), (3, 8), (1024, 1028), (4100, 4100)])
+@pytest.mark.parametrize('flags', [0, 1, 2, 3])
+def test_episode_kernels_on_random_rows(n, stride, flags):
+    """env2048_count_episodes / env2048_segment_episodes on random rows of a ring, against the oracle: batches the
+    four-games-per-lane form takes (n and row_stride multiples of 4, aligned rows) and ones it does not (odd n, odd stride,
+    rows at an odd offset), frozen games and float rewards, with and without episode_of."""
+    lib = capi.library()
+    s = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(n * 7 + stride + flags)
+    ring, rows, first = 50, 37, 20
+    done = (rng.random((ring, stride)) < 0.07).astype(np.uint8)
+    reward = rng.integers(0, 5000, size=(ring, stride)).astype(np.int32)
+    if flags & 2:
+        reward = (reward.astype(np.float32) / 7.0).astype(np.float32)
+    max_exp = rng.integers(1, 16, size=(ring, stride)).astype(np.uint8)
+    want, want_of = oracle.segment_episodes(done, reward, max_exp, n=n, rows=rows, first_row=first, ring_rows=ring, flags=flags, want_episode_of=True)
+    for shift in (0, 1):  # (shift 1: every row starts one element later -- the aligned form cannot take it)
+        pad = lambda a: torch.from_numpy(np.concatenate([np.zeros(shift, dtype=a.dtype), a.reshape(-1)])).cuda()[shift:]
+        d_done, d_reward, d_max = pad(done), pad(reward), pad(max_exp)
+        counts = torch.zeros((n,), dtype=torch.int32, device='cuda')
+        lib.count_episodes(0, s, n, stride, rows, first, ring, d_done.data_ptr(), flags & 1, counts.data_ptr())
+        ends = torch.cumsum(counts.to(torch.int64), dim=0)
+        offsets = (ends - counts).contiguous()
+        assert int(ends[-1]) == len(want)
+        raw = torch.zeros((max(len(want), 1), 24), dtype=torch.uint8, device='cuda')
+        episode_of = torch.full((ring * stride + shift,), -7, dtype=torch.int32, device='cuda')[shift:]
+        lib.segment_episodes(0, s, n, stride, rows, first, ring, d_done.data_ptr(), d_reward.data_ptr(), d_max.data_ptr(), flags, offsets.data_ptr(),
+                             raw.data_ptr(), episode_of.data_ptr())
+        got = raw.cpu().numpy()[:len(want)].view(oracle.EPISODE_DTYPE).reshape(-1)
+        for field in ('env', 'start', 'length', 'terminated', 'max_exp', 'total_reward'):
+            np.testing.assert_array_equal(got[field], want[field], err_msg=f'{field} shift={shift}')
+        np.testing.assert_array_equal(episode_of.cpu().numpy().reshape(ring, stride), want_of)
+        lib.segment_episodes(0, s, n, stride, rows, first, ring, d_done.data_ptr(), None, None, flags & 1, offsets.data_ptr(), raw.data_ptr(), None)
+        got = raw.cpu().numpy()[:len(want)].view(oracle.EPISODE_DTYPE).reshape(-1)
+        np.testing.assert_array_equal(got['length'], want['length'])
+        assert (got['total_reward'] == 0).all()
+
+
 def test_episode_entry_points_reject_bad_arguments(make_env):
     env = make_env(8, 1)
     if isinstance(env.lib, OracleLibrary):
