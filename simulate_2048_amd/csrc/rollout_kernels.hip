@@ -274,50 +274,54 @@ __device__ __forceinline__ uint32_t load_flags(const uint8_t *row, uint64_t i0)
     return row[i0];
 }
 
+// Records per game, in closed form -- no walk: a window of R > 0 rows holds one record per finished game plus the open one at
+// its end (the last row did not finish a game); a FROZEN game holds exactly one (self_play.py:359,368: it stops recording at
+// its first `done`).  So the pass is a sum of flags down the column: for E = 4 one dword add per row and lane (flags
+// normalised to 0 / 1 per byte; the byte sums are widened every 255 rows).
 template <int E>
 __global__ __launch_bounds__(256) void count_episodes_kernel(EpisodeRows a, uint32_t *counts)
 {
     const uint64_t i0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * E;
     if (i0 >= a.n) return;
     const bool frozen = (a.flags & ENV2048_EPISODES_FROZEN) != 0u;
-    uint32_t count[E], open[E], phys = a.first_row;
-    bool stop[E];
+    uint32_t count[E], phys = a.first_row, packed = 0u, last = 0u;
 #pragma unroll
-    for (int e = 0; e < E; ++e) count[e] = open[e] = 0u, stop[e] = false;
-    bool all_stopped = false;
-    for (uint32_t r0 = 0; r0 < a.rows && !all_stopped; r0 += EPISODE_ROWS_IN_FLIGHT) {
-        uint32_t d[EPISODE_ROWS_IN_FLIGHT];
-        const uint32_t batch = min(EPISODE_ROWS_IN_FLIGHT, a.rows - r0);
+    for (int e = 0; e < E; ++e) count[e] = 0u;
+    if (!frozen) {
+        uint32_t since_widened = 0u;
+        for (uint32_t r0 = 0; r0 < a.rows; r0 += EPISODE_ROWS_IN_FLIGHT) {
+            uint32_t d[EPISODE_ROWS_IN_FLIGHT];
+            const uint32_t batch = min(EPISODE_ROWS_IN_FLIGHT, a.rows - r0);
 #pragma unroll
-        for (uint32_t u = 0; u < EPISODE_ROWS_IN_FLIGHT; ++u) {
-            d[u] = 0u;
-            if (u < batch) {
-                d[u] = load_flags<E>(a.done + (uint64_t)phys * a.row_stride, i0);
-                phys = phys + 1u == a.ring_rows ? 0u : phys + 1u;
-            }
-        }
-#pragma unroll
-        for (uint32_t u = 0; u < EPISODE_ROWS_IN_FLIGHT; ++u) {
-            if (u < batch) {
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    if (!stop[e]) {
-                        ++open[e];
-                        if ((d[u] >> (8 * e)) & 0xFFu) {
-                            ++count[e];
-                            open[e] = 0u;
-                            stop[e] = frozen;  // a finished game stops recording (self_play.py:359,368)
-                        }
-                    }
+            for (uint32_t u = 0; u < EPISODE_ROWS_IN_FLIGHT; ++u) {
+                d[u] = 0u;
+                if (u < batch) {
+                    d[u] = load_flags<E>(a.done + (uint64_t)phys * a.row_stride, i0);
+                    phys = phys + 1u == a.ring_rows ? 0u : phys + 1u;
                 }
             }
-        }
-        all_stopped = true;
 #pragma unroll
-        for (int e = 0; e < E; ++e) all_stopped = all_stopped && stop[e];
+            for (uint32_t u = 0; u < EPISODE_ROWS_IN_FLIGHT; ++u) {
+                if (u < batch) {
+                    last = (((d[u] & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d[u]) >> 7 & 0x01010101u;  // 1 in every byte that is not zero
+                    packed += last;
+                }
+            }
+            since_widened += batch;
+            if (since_widened > 255u - EPISODE_ROWS_IN_FLIGHT) {  // (before any byte can pass 255)
+#pragma unroll
+                for (int e = 0; e < E; ++e) count[e] += (packed >> (8 * e)) & 0xFFu;
+                packed = 0u;
+                since_widened = 0u;
+            }
+        }
     }
 #pragma unroll
-    for (int e = 0; e < E; ++e) counts[i0 + e] = count[e] + (open[e] ? 1u : 0u);
+    for (int e = 0; e < E; ++e) {
+        const uint32_t finished = count[e] + ((packed >> (8 * e)) & 0xFFu);
+        const uint32_t open = a.rows != 0u && ((last >> (8 * e)) & 1u) == 0u ? 1u : 0u;
+        counts[i0 + e] = frozen ? (a.rows != 0u ? 1u : 0u) : finished + open;
+    }
 }
 
 template <int E>
