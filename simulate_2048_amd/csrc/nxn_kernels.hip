@@ -313,7 +313,7 @@ constexpr int OUTCOME_WAVES_PER_BLOCK = 4;
 template <int S>
 __global__ __launch_bounds__(64 * OUTCOME_WAVES_PER_BLOCK) void nxn_chance_outcomes_wave_kernel(uint64_t n, const uint8_t *boards, uint32_t *out, uint8_t *count_out)
 {
-    constexpr uint32_t CELLS = S * S, BOARD_DWORDS = CELLS / 4, OUT_DWORDS = 2u * CELLS * CELLS / 4u;
+    constexpr uint32_t CELLS = S * S, OUT_DWORDS = 2u * CELLS * CELLS / 4u;
     static_assert(CELLS % 4 == 0, "even sizes only");
     __shared__ __attribute__((aligned(16))) uint32_t cells_lds[OUTCOME_WAVES_PER_BLOCK][16];
     __shared__ uint8_t rank_lds[OUTCOME_WAVES_PER_BLOCK][64];
@@ -343,7 +343,6 @@ __global__ __launch_bounds__(64 * OUTCOME_WAVES_PER_BLOCK) void nxn_chance_outco
         }
         if (lane == 0u) count_out[board] = (uint8_t)slots_used;
     }
-    (void)BOARD_DWORDS;
 }
 
 int check_nxn(const char *who, uint64_t n, uint32_t size)
