@@ -324,7 +324,8 @@ __global__ __launch_bounds__(256) void count_episodes_kernel(EpisodeRows a, uint
     }
 }
 
-template <int E>
+// STREAM_OF (E = 4 only): `episode_of` is a write stream beyond the Infinity Cache -- non-temporal stores (device_scope.hpp).
+template <int E, bool STREAM_OF = false>
 __global__ __launch_bounds__(256) void segment_episodes_kernel(EpisodeRows a, const uint64_t *offsets, env2048_episode *episodes,
                                                                int32_t *episode_of)
 {
@@ -404,7 +405,11 @@ __global__ __launch_bounds__(256) void segment_episodes_kernel(EpisodeRows a, co
                     }
                 }
                 if (episode_of) {
-                    if (E == 4)
+                    if (E == 4 && STREAM_OF) {
+                        typedef int32_t vec4 __attribute__((ext_vector_type(4)));
+                        __builtin_nontemporal_store(vec4{owner[0], owner[E > 1 ? 1 : 0], owner[E > 2 ? 2 : 0], owner[E > 3 ? 3 : 0]},
+                                                    reinterpret_cast<vec4 *>(episode_of + at[u]));
+                    } else if (E == 4)
                         *reinterpret_cast<int4 *>(episode_of + at[u]) = make_int4(owner[0], owner[E > 1 ? 1 : 0], owner[E > 2 ? 2 : 0], owner[E > 3 ? 3 : 0]);
                     else
                         episode_of[at[u]] = owner[0];
@@ -471,9 +476,12 @@ int env2048_segment_episodes(int device, void *stream, uint64_t n, uint64_t row_
     DeviceScope scope(device);
     if (scope.rc) return scope.rc;
     const EpisodeRows a{n, row_stride, rows, first_row, ring_rows, flags, done, reward, max_exp};
-    if (episodes_by_four(n, row_stride, done, reward, max_exp, episode_of))
-        hipLaunchKernelGGL(segment_episodes_kernel<4>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, offsets, episodes,
-                           episode_of);
+    if (episodes_by_four(n, row_stride, done, reward, max_exp, episode_of) && episode_of && stream_output((uint64_t)rows * n * 4u))
+        hipLaunchKernelGGL((segment_episodes_kernel<4, true>), dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, offsets,
+                           episodes, episode_of);
+    else if (episodes_by_four(n, row_stride, done, reward, max_exp, episode_of))
+        hipLaunchKernelGGL((segment_episodes_kernel<4, false>), dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, offsets,
+                           episodes, episode_of);
     else
         hipLaunchKernelGGL(segment_episodes_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, offsets, episodes,
                            episode_of);
