@@ -95,6 +95,7 @@ class BatchedEnv2048:
         self.step_counter = torch.zeros((1,), dtype=torch.int64, device=self.device) if device_step_counter else None
         self._pending = 0  # steps enqueued since the device counter was last advanced (their offsets)
         self._in_capture = False
+        self._record_args = None  # (see _record_step)
         self.boards = torch.zeros((n, 16), dtype=torch.uint8, device=self.device)
         self.reward = torch.zeros((n,), dtype=torch.int32, device=self.device)
         self.done = torch.zeros((n,), dtype=torch.uint8, device=self.device)
@@ -258,6 +259,20 @@ class BatchedEnv2048:
             # commit_steps() closes the region
             self.commit_steps()
         return self.boards, reward, done
+
+    def _record_step(self, actions_ptr, reward_ptr, done_ptr, legal_ptr, obs_ptr, max_exp_ptr, extra_flags: int) -> None:
+        """The recorder's form of step(): the outputs are ROWS of a ``TrajectoryBuffer`` given as device addresses the buffer has
+        checked once at construction (dtype, shape, device, contiguity), so a recorded move costs no tensor indexing and no
+        validation on the host.  ``actions_ptr`` None = moves drawn in the kernel.  Not for envs with a device step counter."""
+        flags = self.flags | extra_flags | (capi.FLAG_RANDOM_ACTIONS if actions_ptr is None else 0)
+        dev, stream = _stream_handle(self.device)
+        record = self._record_args
+        if record is None:
+            record = self._record_args = (capi.StepArgs * 1)()
+        record[0] = capi.StepArgs(self.num_envs, self.env_base, self._ptr_boards, actions_ptr, reward_ptr, done_ptr, legal_ptr, obs_ptr,
+                                  self.seed, self._step_index, flags, 0, max_exp_ptr)
+        self.lib.step_many(dev, stream, record)
+        self._step_index += 1
 
     def _check_out(self, t: torch.Tensor, dtype, shape) -> torch.Tensor:
         if t.dtype != dtype or tuple(t.shape) != tuple(shape) or t.device != self.boards.device or not t.is_contiguous():

@@ -79,6 +79,11 @@ class TrajectoryBuffer:
         self.boards = torch.zeros((C + extra, n, 16), dtype=torch.uint8, device=dev) if record_boards else None
         self.t = 0  # steps recorded since begin()
         self._unrecorded_random = False
+        # Per-row views and addresses, made ONCE: a recorded move then indexes Python tuples instead of tensors (six tensor
+        # index operations cost ~10 us of host time per move -- more than the move at small batches).
+        rows_of = lambda t: None if t is None else t.unbind(0)
+        self._rows = {name: rows_of(getattr(self, name)) for name in ('actions', 'reward', 'done', 'max_exp', 'legal', 'obs', 'policy', 'value', 'boards')}
+        self._ptrs = {name: None if rows is None else tuple(r.data_ptr() for r in rows) for name, rows in self._rows.items()}
 
     # -- bookkeeping --------------------------------------------------------------------------------------------
     @property
@@ -116,15 +121,42 @@ class TrajectoryBuffer:
         if not self.ring and t >= self.horizon:
             raise IndexError(f'trajectory buffer full ({self.horizon} steps)')
         row, nxt = self._row(t), self._row(t + 1)
+        rows, ptrs, env = self._rows, self._ptrs, self.env
+        if env.step_counter is not None:
+            return self._step_with_device_counter(actions, policy, value, row, nxt)
+        action_row = rows['actions'][row]
+        if actions is not None:
+            if actions.data_ptr() != ptrs['actions'][row]:
+                action_row.copy_(actions.to(device=action_row.device, dtype=torch.uint8).reshape(action_row.shape))
+        else:
+            # on-device random play: write the moves the step WOULD draw into the action row and play them from there -- the
+            # same step (same words), and the row says what was played (ADVICE r2: these rows used to stay zero)
+            env.random_actions(action_row)
+        if policy is not None:
+            if self.policy is None:
+                raise ValueError('this buffer was built without record_policy=True')
+            if policy.data_ptr() != ptrs['policy'][row]:
+                rows['policy'][row].copy_(policy)
+        if value is not None:
+            if self.value is None:
+                raise ValueError('this buffer was built without record_value=True')
+            if value.data_ptr() != ptrs['value'][row]:
+                rows['value'][row].copy_(value)
+        env._record_step(ptrs['actions'][row], ptrs['reward'][row], ptrs['done'][row], None if self.legal is None else ptrs['legal'][nxt],
+                         None if self.obs is None else ptrs['obs'][nxt], None if self.max_exp is None else ptrs['max_exp'][row],
+                         capi.FLAG_REWARD_LOG2_F32 if self.normalize_reward else 0)
+        if self.boards is not None:
+            rows['boards'][nxt].copy_(env.boards)
+        self.t = t + 1
+        return env.boards, rows['reward'][row], rows['done'][row]
+
+    def _step_with_device_counter(self, actions, policy, value, row, nxt):
+        """step() for an env whose step index lives on the device (graph capture): the general BatchedEnv2048.step path."""
         if actions is not None:
             dst = self.actions[row]
             if actions.data_ptr() != dst.data_ptr():
                 dst.copy_(actions.to(device=dst.device, dtype=torch.uint8).reshape(dst.shape))
             actions = dst
-        elif self.env.step_counter is None:
-            # on-device random play: write the moves the step WOULD draw into the action row and play them from there -- the
-            # same step (same words), and the row says what was played (ADVICE r2: these rows used to stay zero)
-            actions = self.env.random_actions(self.actions[row])
         else:
             self._unrecorded_random = True  # (step index on the device: the moves cannot be materialised beforehand)
         if policy is not None:
@@ -144,7 +176,7 @@ class TrajectoryBuffer:
                             normalized_reward=self.normalize_reward)
         if self.boards is not None:
             self.boards[nxt].copy_(self.env.boards)
-        self.t = t + 1
+        self.t += 1
         return out
 
     def _require_action_rows(self) -> None:
