@@ -16,18 +16,28 @@ namespace {
 // The actions ENV2048_FLAG_RANDOM_ACTIONS makes a step take, materialised: action of environment env at (seed, step) = low two
 // bits of its step word.  For recorders: a step played with these actions read from memory is the same step (same words for
 // the spawn), and the action row then says what was played (recorded random steps had all-zero action rows).
+// One lane per STEP BLOCK: the four environments 4 b ... 4 b + 3 share block b of the step stream (RNG contract), so a lane draws
+// one Philox block and writes their four moves as one dword (bytes at the ragged ends of the batch, or when the destination
+// is not dword-aligned for that lane).
 __global__ __launch_bounds__(BLOCK) void random_actions_kernel(uint64_t n, uint64_t env_base, uint32_t seed_lo, uint32_t seed_hi,
                                                                uint64_t step_index, uint8_t *actions)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const uint64_t env = env_base + i;
+    const uint64_t block = (env_base >> 2) + (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const uint64_t first = 4u * block, end = env_base + n;  // environments [first, first + 4) of the global index space
+    if (first >= end) return;
     const RngKey key{seed_lo, seed_hi, (uint32_t)step_index, (uint32_t)(step_index >> 32)};
     uint32_t w[4];
-    env_block(key, env >> 2, STREAM_STEP, w[0], w[1], w[2], w[3]);
-    const uint32_t sel = (uint32_t)env & 3u;
-    const uint32_t word = sel == 0u ? w[0] : sel == 1u ? w[1] : sel == 2u ? w[2] : w[3];
-    actions[i] = (uint8_t)(word & 3u);
+    env_block(key, block, STREAM_STEP, w[0], w[1], w[2], w[3]);
+    const uint32_t moves = (w[0] & 3u) | ((w[1] & 3u) << 8) | ((w[2] & 3u) << 16) | ((w[3] & 3u) << 24);
+    if (first >= env_base && first + 4u <= end && (((uintptr_t)actions + (first - env_base)) & 3u) == 0u) {
+        *reinterpret_cast<uint32_t *>(actions + (first - env_base)) = moves;
+    } else {
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+            const uint64_t env = first + k;
+            if (env >= env_base && env < end) actions[env - env_base] = (uint8_t)(moves >> (8u * k));
+        }
+    }
 }
 
 // One block per 64 boards; a thread writes whole output DWORDs (coalesced 4-byte stores): byte g of a
@@ -194,7 +204,8 @@ int env2048_random_actions(int device, void *stream, uint64_t n, uint64_t env_ba
     if (int rc = check_count(n)) return rc;
     DeviceScope scope(device);
     if (scope.rc) return scope.rc;
-    hipLaunchKernelGGL(random_actions_kernel, grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, n, env_base, (uint32_t)seed,
+    const uint64_t step_blocks = ((env_base + n + 3u) >> 2) - (env_base >> 2);  // step blocks the batch touches
+    hipLaunchKernelGGL(random_actions_kernel, grid_for(step_blocks), dim3(BLOCK), 0, (hipStream_t)stream, n, env_base, (uint32_t)seed,
                        (uint32_t)(seed >> 32), step_index, actions);
     return launched("env2048_random_actions launch");
 }

@@ -975,6 +975,20 @@ def test_status_i32_matches_oracle(lib):
     np.testing.assert_array_equal(legal.cpu().numpy(), want_legal)
 
 
+@pytest.mark.parametrize('n,env_base,shift', [(1, 0, 0), (3, 1, 0), (4, 4, 0), (5, 7, 1), (64, 2, 3), (257, (1 << 33) + 3, 0), (1000, 5, 2), (4096, 0, 0), (4099, 13, 1)])
+def test_random_actions_are_the_low_bits_of_the_step_words(lib, n, env_base, shift):
+    """env2048_random_actions (one lane per step block, dword stores where the batch and the destination allow) against the
+    oracle's step words, for batches that start and end inside a block and destinations at any byte offset; no byte outside
+    the batch is written."""
+    seed, step = 0xABCDEF0123456789, (1 << 34) + 17
+    arena = torch.full((n + shift + 8,), 0x77, dtype=torch.uint8, device='cuda')
+    lib.random_actions(DEV, stream(), n, env_base, seed, step, arena[shift:].data_ptr())
+    host = arena.cpu().numpy()
+    want = np.array([oracle.step_word(seed, env_base + i, step) & 3 for i in range(n)], dtype=np.uint8)
+    np.testing.assert_array_equal(host[shift:shift + n], want)
+    assert (host[:shift] == 0x77).all() and (host[shift + n:] == 0x77).all()
+
+
 def test_afterstate_i32_golden(lib, golden):
     """latent_state / slide_and_merge of the JAX-shaped API on int32 value boards (env2048_afterstate_i32) against the
     reference's own afterstates: one move for the whole batch, one move per board, in place, outputs optional."""
