@@ -96,6 +96,7 @@ class BatchedEnv2048:
         self._pending = 0  # steps enqueued since the device counter was last advanced (their offsets)
         self._in_capture = False
         self._record_args = None  # (see _record_step)
+        self._actions_u8 = None  # (see step: actions of another dtype / device are converted into this buffer)
         self.boards = torch.zeros((n, 16), dtype=torch.uint8, device=self.device)
         self.reward = torch.zeros((n,), dtype=torch.int32, device=self.device)
         self.done = torch.zeros((n,), dtype=torch.uint8, device=self.device)
@@ -193,10 +194,15 @@ class BatchedEnv2048:
         if actions is None:
             flags |= capi.FLAG_RANDOM_ACTIONS
         else:
-            if actions.dtype != torch.uint8 or actions.device != self.boards.device or not actions.is_contiguous():
-                actions = actions.to(device=self.boards.device, dtype=torch.uint8).contiguous()
             if actions.numel() != self.num_envs:
                 raise ValueError(f'expected {self.num_envs} actions, got {actions.numel()}')
+            if actions.dtype != torch.uint8 or actions.device != self.boards.device or not actions.is_contiguous():
+                # (an int64 argmax, a host tensor ...: converted into a persistent uint8 buffer -- one copy kernel, no allocation)
+                staged = self._actions_u8
+                if staged is None:
+                    staged = self._actions_u8 = torch.empty((self.num_envs,), dtype=torch.uint8, device=self.boards.device)
+                staged.copy_(actions.reshape(self.num_envs))
+                actions = staged
         dev, stream = _stream_handle(self.device)
         if self.step_counter is not None:  # the launch reads and advances the device counter: nothing to track on the host
             return self._step_with_counter(dev, stream, actions, flags, out_reward, out_done, out_legal, out_obs, out_max_exp,

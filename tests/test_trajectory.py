@@ -27,6 +27,31 @@ def host(t):
     return t.cpu().numpy()
 
 
+def test_step_takes_actions_of_any_integer_dtype_and_device(make_env):
+    """A policy's int64 argmax, int32 actions, a host tensor, a strided view: converted into the env's persistent uint8 buffer
+    (values mod 4, like the uint8 form) -- the same games as with uint8 actions on the device."""
+    n, seed = 513, 11
+    a, b = make_env(n, seed, auto_reset=True), make_env(n, seed, auto_reset=True)
+    a.reset()
+    b.reset()
+    rng = np.random.default_rng(2)
+    for t in range(12):
+        raw = rng.integers(-8, 300, size=n)
+        want = torch.from_numpy((raw & 3).astype(np.uint8)).to(a.device)
+        a.step(want)
+        form = t % 4
+        if form == 0:
+            given = torch.from_numpy(raw.astype(np.int64)).to(b.device)
+        elif form == 1:
+            given = torch.from_numpy(raw.astype(np.int32)).to(b.device)
+        elif form == 2:
+            given = torch.from_numpy(raw.astype(np.int64))  # on the host
+        else:
+            given = torch.from_numpy(np.stack([raw, raw], axis=1).astype(np.int16)).to(b.device)[:, 0]  # not contiguous
+        b.step(given)
+        assert torch.equal(a.boards, b.boards) and torch.equal(a.reward, b.reward) and torch.equal(a.done, b.done), t
+
+
 def test_recorded_rows_match_oracle(make_env):
     """Every row the step kernel writes into the [T, N] arrays -- incl. max_exp (pre-reset) and, with
     normalize_reward, the float32 log-normalised reward (<= 1 ulp from the oracle's double-precision value)."""
