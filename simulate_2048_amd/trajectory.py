@@ -45,6 +45,33 @@ class Trajectory(NamedTuple):
         return len(self.observations)
 
 
+class _Rows:
+    """Rows of a (rows, ...) tensor: ``rows[r]`` is the view of row r (all made at once for buffers of up to 4096 rows -- one
+    unbind --, on first use beyond that), ``rows.address[r]`` its device address (arithmetic, no tensor involved)."""
+
+    __slots__ = ('tensor', 'views', 'address')
+
+    class _Addresses:
+        __slots__ = ('base', 'pitch')
+
+        def __init__(self, tensor: torch.Tensor):
+            self.base, self.pitch = tensor.data_ptr(), tensor.stride(0) * tensor.element_size()
+
+        def __getitem__(self, row: int) -> int:
+            return self.base + row * self.pitch
+
+    def __init__(self, tensor: torch.Tensor):
+        self.tensor = tensor
+        self.views = list(tensor.unbind(0)) if tensor.shape[0] <= 4096 else [None] * tensor.shape[0]
+        self.address = _Rows._Addresses(tensor)
+
+    def __getitem__(self, row: int) -> torch.Tensor:
+        view = self.views[row]
+        if view is None:
+            view = self.views[row] = self.tensor[row]
+        return view
+
+
 class TrajectoryBuffer:
     """Rows of ``env`` recorded on device.
 
@@ -79,11 +106,11 @@ class TrajectoryBuffer:
         self.boards = torch.zeros((C + extra, n, 16), dtype=torch.uint8, device=dev) if record_boards else None
         self.t = 0  # steps recorded since begin()
         self._unrecorded_random = False
-        # Per-row views and addresses, made ONCE: a recorded move then indexes Python tuples instead of tensors (six tensor
-        # index operations cost ~10 us of host time per move -- more than the move at small batches).
-        rows_of = lambda t: None if t is None else t.unbind(0)
-        self._rows = {name: rows_of(getattr(self, name)) for name in ('actions', 'reward', 'done', 'max_exp', 'legal', 'obs', 'policy', 'value', 'boards')}
-        self._ptrs = {name: None if rows is None else tuple(r.data_ptr() for r in rows) for name, rows in self._rows.items()}
+        # Row addresses by arithmetic and row views made once each: a recorded move then does no tensor indexing (six index
+        # operations cost ~10 us of host time per move -- more than the move at small batches).
+        names = ('actions', 'reward', 'done', 'max_exp', 'legal', 'obs', 'policy', 'value', 'boards')
+        self._rows = {name: None if getattr(self, name) is None else _Rows(getattr(self, name)) for name in names}
+        self._ptrs = {name: None if rows is None else rows.address for name, rows in self._rows.items()}
 
     # -- bookkeeping --------------------------------------------------------------------------------------------
     @property
