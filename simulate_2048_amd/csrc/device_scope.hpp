@@ -21,6 +21,18 @@ inline bool stream_output(uint64_t bytes)
     return forced >= 0 ? forced == 1 : bytes > (256ull << 20);
 }
 
+// Write-through (sc1) stores for the 16-byte outputs of the kernels that write boards / observations (everything but the
+// step kernel, which has its own size rule): nothing is left dirty in the XCD L2s for the end-of-kernel write-back.
+// ENV2048_EXP_THROUGH=0 turns them off (A/B measurements).
+inline bool wide_stores_through()
+{
+    static const bool on = [] {
+        const char *e = getenv("ENV2048_EXP_THROUGH");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
 inline int hip_fail(hipError_t e, const char *what)
 {
     return fail(ENV2048_ERR_HIP_BASE - (int)e, "%s: %s (hipError %d)", what, hipGetErrorString(e), (int)e);

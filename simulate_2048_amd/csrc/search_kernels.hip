@@ -15,7 +15,7 @@ using namespace env2048::host;
 namespace {
 __global__ __launch_bounds__(BLOCK) void afterstate_kernel(uint64_t n, const uint8_t *boards_in,
                                                            const uint8_t *actions, uint8_t *boards_out,
-                                                           int32_t *reward, uint8_t *changed_out)
+                                                           int32_t *reward, uint8_t *changed_out, bool through)
 {
     const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
@@ -23,7 +23,7 @@ __global__ __launch_bounds__(BLOCK) void afterstate_kernel(uint64_t n, const uin
     uint32_t score;
     bool changed;
     afterstate(bd, (uint32_t)actions[i] & 3u, score, changed);
-    store_board(boards_out, i, bd);
+    store_board(boards_out, i, bd, through);
     if (reward) reward[i] = (int32_t)score;
     if (changed_out) changed_out[i] = changed ? 1 : 0;
 }
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(BLOCK) void afterstate_kernel(uint64_t n, const uin
 // different 64-byte segments with every store instruction; instead the wave's 256 afterstates go through a wave-private LDS
 // strip ([action][lane]: conflict-free 16-byte writes) and leave as four store instructions of 1 KiB of consecutive bytes.
 __global__ __launch_bounds__(BLOCK) void afterstates4_kernel(uint64_t n, const uint8_t *boards, uint8_t *out_boards,
-                                                             int32_t *out_reward, uint8_t *out_legal)
+                                                             int32_t *out_reward, uint8_t *out_legal, bool through)
 {
     __shared__ uint4 strips[BLOCK / 64][4][64];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -85,7 +85,13 @@ __global__ __launch_bounds__(BLOCK) void afterstates4_kernel(uint64_t n, const u
 #pragma unroll
     for (uint32_t j = 0; j < 4u; ++j) {
         const uint32_t q = 64u * j + lane;  // afterstate q of the wave: board q >> 2, action q & 3
-        if (q < vectors) out[q] = strip[q & 3u][q >> 2];
+        if (q < vectors) {
+            const uint4 v = strip[q & 3u][q >> 2];
+            if (through)
+                store_x4_through(out + q, u32x4{v.x, v.y, v.z, v.w});
+            else
+                out[q] = v;
+        }
     }
     if (!active) return;
     if (out_reward) reinterpret_cast<int4 *>(out_reward)[i] = rewards;
@@ -850,7 +856,7 @@ int env2048_afterstate(int device, void *stream, uint64_t n, const uint8_t *boar
     DeviceScope scope(device);
     if (scope.rc) return scope.rc;
     hipLaunchKernelGGL(afterstate_kernel, grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, n, boards_in, actions,
-                       boards_out, reward, changed);
+                       boards_out, reward, changed, wide_stores_through());
     return launched("env2048_afterstate launch");
 }
 
@@ -865,7 +871,7 @@ int env2048_afterstates4(int device, void *stream, uint64_t n, const uint8_t *bo
     DeviceScope scope(device);
     if (scope.rc) return scope.rc;
     hipLaunchKernelGGL(afterstates4_kernel, grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, n, boards, out_boards, out_reward,
-                       out_legal);
+                       out_legal, wide_stores_through());
     return launched("env2048_afterstates4 launch");
 }
 

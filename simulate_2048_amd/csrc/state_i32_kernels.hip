@@ -64,7 +64,7 @@ __device__ __forceinline__ Board load_rows_coalesced(const int32_t *boards, uint
 // the packed board of every lane -> boards [first, first + 64) of `boards` as int32 values (`skip` lanes: nothing is written
 // for their board); `mirror` != 0: also `mirror` bytes further on (the caller's pinned-host copy of its results)
 __device__ __forceinline__ void store_rows_coalesced(int32_t *boards, int64_t mirror, uint32_t *strip, uint64_t first, uint64_t n, uint32_t lane,
-                                                     const Board &bd, bool skip)
+                                                     const Board &bd, bool skip, bool through)
 {
     strip_sync();
     reinterpret_cast<uint4 *>(strip)[lane] = skip ? make_uint4(NO_ROW, NO_ROW, NO_ROW, NO_ROW) : make_uint4(bd.r0, bd.r1, bd.r2, bd.r3);
@@ -77,7 +77,10 @@ __device__ __forceinline__ void store_rows_coalesced(int32_t *boards, int64_t mi
         const uint32_t x = strip[q];
         if (x != NO_ROW && q < live) {
             const int4 v = unpack4(x);
-            rows[q] = v;
+            if (through)
+                store_x4_through(rows + q, u32x4{(uint32_t)v.x, (uint32_t)v.y, (uint32_t)v.z, (uint32_t)v.w});
+            else
+                rows[q] = v;
             if (mirror) *reinterpret_cast<int4 *>(reinterpret_cast<char *>(rows + q) + mirror) = v;
         }
     }
@@ -85,9 +88,9 @@ __device__ __forceinline__ void store_rows_coalesced(int32_t *boards, int64_t mi
 
 // the f32 observation of every lane's board, coalesced (board_io.hpp), and its host-mirror copy
 __device__ __forceinline__ void store_obs_rows_coalesced(float *obs, int64_t mirror, uint32_t *strip, uint64_t first, uint64_t n, uint32_t lane,
-                                                         const Board &bd, bool skip)
+                                                         const Board &bd, bool skip, bool through)
 {
-    store_obs_coalesced(obs, strip, first, n, lane, bd, skip);
+    store_obs_coalesced(obs, strip, first, n, lane, bd, skip, through);
     if (mirror) store_obs_coalesced(reinterpret_cast<float *>(reinterpret_cast<char *>(obs) + mirror), strip, first, n, lane, bd, skip);
 }
 
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(BLOCK) void step_state_i32_kernel(uint64_t n, uint6
                                                                const float *total_in, float *total_out, float *reward_out,
                                                                int32_t *max_tile, RngKey key, const uint2 *keys, float *obs_out,
                                                                uint32_t *legal4_out, int64_t mirror, uint64_t *sequence,
-                                                               uint64_t sequence_value)
+                                                               uint64_t sequence_value, bool through)
 {
     __shared__ __attribute__((aligned(16))) uint32_t strips[BLOCK / 64][256];
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (block_for(): a small launch runs a smaller workgroup)
@@ -216,8 +219,8 @@ __global__ __launch_bounds__(BLOCK) void step_state_i32_kernel(uint64_t n, uint6
         if (i < n)
             step_state_i32_one<true>(i, env_base, boards_in, boards_out, actions, step_count_in, step_count_out, done_in, done_out, total_in,
                                      total_out, reward_out, max_tile, key, keys, obs_out, legal4_out, mirror, bd, moved);
-        store_rows_coalesced(boards_out, mirror, strip, first, n, lane, bd, !moved);
-        if (obs_out) store_obs_rows_coalesced(obs_out, mirror, strip, first, n, lane, bd, i >= n);
+        store_rows_coalesced(boards_out, mirror, strip, first, n, lane, bd, !moved, through);
+        if (obs_out) store_obs_rows_coalesced(obs_out, mirror, strip, first, n, lane, bd, i >= n, through);
     }
     signal_sequence(sequence, sequence_value);  // (outside the bounds check: every thread of the block takes part)
 }
@@ -273,7 +276,7 @@ __device__ __forceinline__ Board reset_keyed_i32_one(uint64_t i, const uint2 *ke
 
 __global__ __launch_bounds__(BLOCK) void reset_keyed_i32_kernel(uint64_t n, const uint2 *keys, int32_t *boards, float *obs_out,
                                                                 uint32_t *legal4_out, int32_t *step_count, uint8_t *done, float *total,
-                                                                int64_t mirror, uint64_t *sequence, uint64_t sequence_value)
+                                                                int64_t mirror, uint64_t *sequence, uint64_t sequence_value, bool through)
 {
     __shared__ __attribute__((aligned(16))) uint32_t strips[BLOCK / 64][256];
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -283,8 +286,8 @@ __global__ __launch_bounds__(BLOCK) void reset_keyed_i32_kernel(uint64_t n, cons
     if (first < n) {  // (wave-uniform)
         Board bd{0u, 0u, 0u, 0u};
         if (i < n) bd = reset_keyed_i32_one(i, keys, legal4_out, step_count, done, total, mirror);
-        store_rows_coalesced(boards, mirror, strip, first, n, lane, bd, i >= n);
-        if (obs_out) store_obs_rows_coalesced(obs_out, mirror, strip, first, n, lane, bd, i >= n);
+        store_rows_coalesced(boards, mirror, strip, first, n, lane, bd, i >= n, through);
+        if (obs_out) store_obs_rows_coalesced(obs_out, mirror, strip, first, n, lane, bd, i >= n, through);
     }
     signal_sequence(sequence, sequence_value);
 }
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(BLOCK) void reset_keyed_i32_kernel(uint64_t n, cons
 // observation, the legal-action mask as four 0/1 BYTES per board (a torch/NumPy bool array) and the
 // JAX-flavoured done flag ("no action changes the board").
 __global__ __launch_bounds__(BLOCK) void status_i32_kernel(uint64_t n, const int32_t *boards, float *obs, uint32_t *legal4,
-                                                           uint8_t *done)
+                                                           uint8_t *done, bool through)
 {
     __shared__ __attribute__((aligned(16))) uint32_t strips[BLOCK / 64][256];
     const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(BLOCK) void status_i32_kernel(uint64_t n, const int
     if (first >= n) return;  // (a whole wave; nothing below is shared between waves)
     uint32_t *const strip = strips[threadIdx.x >> 6];
     const Board bd = load_rows_coalesced(boards, strip, first, n, lane);
-    if (obs) store_obs_coalesced(obs, strip, first, n, lane, bd, i >= n);
+    if (obs) store_obs_coalesced(obs, strip, first, n, lane, bd, i >= n, through);
     if (i >= n) return;
     if (legal4 || done) {
         const uint32_t bits = legal_mask(bd);
@@ -314,7 +317,7 @@ __global__ __launch_bounds__(BLOCK) void status_i32_kernel(uint64_t n, const int
 // latent_state / slide_and_merge / merge_row of the JAX-shaped API on int32 value boards [ref: reinforce/game/core.py:129-170,
 // :104-126, :43-101]: slide + merge towards `action` (one move for the whole batch, or one per board), no spawn.
 __global__ __launch_bounds__(BLOCK) void afterstate_i32_kernel(uint64_t n, const int32_t *boards_in, const int32_t *actions, uint32_t action,
-                                                               int32_t *boards_out, int32_t *reward, uint8_t *changed_out)
+                                                               int32_t *boards_out, int32_t *reward, uint8_t *changed_out, bool through)
 {
     __shared__ __attribute__((aligned(16))) uint32_t strips[BLOCK / 64][256];
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -326,7 +329,7 @@ __global__ __launch_bounds__(BLOCK) void afterstate_i32_kernel(uint64_t n, const
     uint32_t score;
     bool changed;
     afterstate(bd, ((actions && i < n) ? (uint32_t)actions[i] : action) & 3u, score, changed);
-    store_rows_coalesced(boards_out, 0, strip, first, n, lane, bd, i >= n);
+    store_rows_coalesced(boards_out, 0, strip, first, n, lane, bd, i >= n, through);
     if (i >= n) return;
     if (reward) reward[i] = (int32_t)score;
     if (changed_out) changed_out[i] = changed ? 1 : 0;
@@ -381,7 +384,7 @@ static int step_state_i32_common(const char *who, int device, void *stream, uint
     hipLaunchKernelGGL(step_state_i32_kernel, grid_for(n), block_for(n), 0, (hipStream_t)stream, n, env_base, boards_in, boards_out,
                        actions, step_count_in, step_count_out, done_in, done_out, total_reward_in, total_reward_out, reward,
                        max_tile, key, reinterpret_cast<const uint2 *>(keys), obs_out, reinterpret_cast<uint32_t *>(legal4_out),
-                       host_mirror_delta, host_sequence, sequence_value);
+                       host_mirror_delta, host_sequence, sequence_value, wide_stores_through());
     return launched(who);
 }
 
@@ -422,7 +425,7 @@ int env2048_reset_state_i32_keyed_signalled(int device, void *stream, uint64_t n
     if (scope.rc) return scope.rc;
     hipLaunchKernelGGL(reset_keyed_i32_kernel, grid_for(n), block_for(n), 0, (hipStream_t)stream, n, reinterpret_cast<const uint2 *>(keys),
                        boards, obs, reinterpret_cast<uint32_t *>(legal4), step_count, done, total_reward, host_mirror_delta, host_sequence,
-                       sequence_value);
+                       sequence_value, wide_stores_through());
     return launched("env2048_reset_keyed_i32 launch");
 }
 
@@ -547,7 +550,7 @@ int env2048_afterstate_i32(int device, void *stream, uint64_t n, const int32_t *
     DeviceScope scope(device);
     if (scope.rc) return scope.rc;
     hipLaunchKernelGGL(afterstate_i32_kernel, grid_for(n), block_for(n), 0, (hipStream_t)stream, n, boards_in, actions, action, boards_out, reward,
-                       changed);
+                       changed, wide_stores_through());
     return launched("env2048_afterstate_i32 launch");
 }
 
@@ -561,7 +564,7 @@ int env2048_status_i32(int device, void *stream, uint64_t n, const int32_t *boar
     DeviceScope scope(device);
     if (scope.rc) return scope.rc;
     hipLaunchKernelGGL(status_i32_kernel, grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, n, boards, obs,
-                       reinterpret_cast<uint32_t *>(legal4), done);
+                       reinterpret_cast<uint32_t *>(legal4), done, wide_stores_through());
     return launched("env2048_status_i32 launch");
 }
 
