@@ -19,6 +19,7 @@
 #include "env2048.h"
 #include "board_ops.hpp"
 #include "nxn_ops.hpp"
+#include "board_io.hpp"
 #include "tiling.hpp"
 #include "device_scope.hpp"
 
@@ -131,7 +132,7 @@ __device__ __forceinline__ void store_board(uint32_t *strip, uint8_t *boards, ui
                 } else {
                     v = reinterpret_cast<const uint4 *>(strip)[q];
                 }
-                vec[q] = v;
+                store_x4_through(vec + q, u32x4{v.x, v.y, v.z, v.w});  // (write-through, like every wide output)
             }
         }
         strip_fence();

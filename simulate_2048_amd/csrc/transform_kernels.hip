@@ -105,7 +105,7 @@ __global__ __launch_bounds__(BLOCK) void onehot_kernel16(uint64_t n, const uint8
             typedef uint32_t vec4 __attribute__((ext_vector_type(4)));
             __builtin_nontemporal_store(vec4{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)}, reinterpret_cast<vec4 *>(dst) + q);
         } else {
-            dst[q] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+            store_x4_through(dst + q, u32x4{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)});  // (write-through, like every wide output)
         }
     }
 }

@@ -12,7 +12,9 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from simulate_2048_amd import capi  # noqa: E402
 
-lib = capi.library()
+import os  # noqa: E402
+
+lib = capi.Library(os.environ['ENV2048_LIB']) if os.environ.get('ENV2048_LIB') else capi.library()  # (an A/B build)
 S = torch.cuda.current_stream().cuda_stream
 LG = int(sys.argv[1]) if len(sys.argv) > 1 else 22
 N = 1 << LG
