@@ -247,7 +247,7 @@ ENV2048_EXPORT int env2048_step_sequence(int device, void *stream, uint64_t n, u
  *   - env2048_helper_stats reports what the helper of `device` has cost so far: created (0/1), spin_us (the window in
  *     force), jobs served, and cpu_ns = thread CPU time consumed (CLOCK_THREAD_CPUTIME_ID, sampled after every job and
  *     poll window).  It makes no device call.  bench.py prints it for the K = 200 leg.
-  *
+ *
  * Two more environment switches exist for A/B measurements only (read once per process, no effect on results):
  * ENV2048_EXP_STREAM_STORES=1 / 0 forces non-temporal / plain stores in the write-stream kernels that otherwise choose by
  * output size (env2048_chance_outcomes, env2048_encode_onehot, episode_of of env2048_segment_episodes);
