@@ -619,8 +619,9 @@ ENV2048_EXPORT int env2048_expectimax_depth2(int device, void *stream, uint64_t 
  *   env2048_expand_count   counts[i] = number of children of board i.
  *   env2048_expand_offsets the offsets env2048_expand needs, computed on the device: offsets[i] = number of children of the
  *                          boards before i (count, block scan, scan of the block totals, add -- three small launches enqueued
- *                          by this call).  `scratch` is caller-owned device memory of ceil(n / 512) + 1 uint64; when the call
- *                          has completed scratch[ceil(n / 512)] holds the TOTAL number of children.  A host that must size
+ *                          by this call).  `scratch` is caller-owned device memory of env2048_expand_scratch_words(n) =
+ *                          ceil(n / ENV2048_EXPAND_OFFSETS_BLOCK) + 1 uint64; when the call has completed its LAST word holds the
+ *                          TOTAL number of children.  A host that must size
  *                          the next frontier passes `host_total`: two uint64 of PINNED (device-accessible) host memory --
  *                          the device writes the total into word 0 and then `sequence_value` into word 1 (release, system
  *                          scope), so env2048_wait_sequence(host_total + 1, sequence_value, ...) replaces a stream
@@ -638,6 +639,8 @@ ENV2048_EXPORT int env2048_expectimax_depth2(int device, void *stream, uint64_t 
  * Depth d = expand x (d - 2), depth2_f64 on the last frontier, backup x (d - 2) (simulate_2048_amd.ops.expectimax does that).
  */
 ENV2048_EXPORT int env2048_expand_count(int device, void *stream, uint64_t n, const uint8_t *boards, uint32_t *counts);
+#define ENV2048_EXPAND_OFFSETS_BLOCK 512
+ENV2048_EXPORT uint64_t env2048_expand_scratch_words(uint64_t n);
 ENV2048_EXPORT int env2048_expand_offsets(int device, void *stream, uint64_t n, const uint8_t *boards, uint64_t *offsets, uint64_t *scratch,
                                           uint64_t *host_total, uint64_t sequence_value);
 ENV2048_EXPORT int env2048_expand(int device, void *stream, uint64_t n, const uint8_t *boards, const uint64_t *offsets, uint8_t *children,

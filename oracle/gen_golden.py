@@ -22,7 +22,7 @@ Fixture sets:
   transforms.npz        encode_flatten(...,31) one-hot observations and normalize_reward values
   chance_outcomes.npz   after_state(board): every (empty cell, value) outcome in the reference's order + float64 probabilities
   expectimax_d2.npz     depth-2 expectimax (Q2, exact integer terms, best action) composed from latent_state / after_state / can_move
-  nxn.npz               boards of sizes 2, 3, 5, 6, 8: latent_state / can_move / legal mask / is_done / merge_column / after_state and
+  nxn.npz               boards of sizes 2 ... 8: latent_state / can_move / legal mask / is_done / merge_column / after_state and
                         Philox-driven whole games replayed by the reference's functions (the `size` argument of the env)
   random_play_stats.npz per-game length / total reward / max tile of 3000 uniformly-random games played by the REFERENCE engine
                         with its own NumPy RNG: the distribution the build's Philox-driven play must reproduce
@@ -465,7 +465,7 @@ def gen_expectimax_d3(count: int = 512):
     return n, int((best == 255).sum()), float(val.max())
 
 
-NXN_SIZES = (2, 3, 5, 6, 8)
+NXN_SIZES = (2, 3, 5, 6, 8, 7, 4)  # (7 and 4 appended in round 5: the generator is shared, so the earlier sizes keep their data)
 
 
 def gen_nxn():

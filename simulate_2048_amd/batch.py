@@ -31,6 +31,11 @@ def _stream_handle(device: torch.device):
     return index, torch.cuda.current_stream(device).cuda_stream
 
 
+def _host_copy(t: torch.Tensor) -> torch.Tensor:
+    """A host tensor that shares nothing with `t` (``.cpu()`` of a host tensor -- the injected-library tests -- is the tensor itself)."""
+    return t.detach().to('cpu', copy=True)
+
+
 def _p(t):
     return None if t is None else t.data_ptr()
 
@@ -451,9 +456,9 @@ class BatchedEnv2048:
         byte for byte what the original would have produced."""
         carry = None
         if getattr(self, '_ep_length', None) is not None:
-            carry = {'length': self._ep_length.cpu(), 'return': self._ep_return.cpu()}
+            carry = {'length': _host_copy(self._ep_length), 'return': _host_copy(self._ep_return)}
         return {'format': 1, 'num_envs': self.num_envs, 'seed': self.seed, 'env_base': self.env_base, 'step_index': int(self.step_index),
-                'auto_reset': self.auto_reset, 'boards': self.boards.cpu(), 'reward': self.reward.cpu(), 'done': self.done.cpu(),
+                'auto_reset': self.auto_reset, 'boards': _host_copy(self.boards), 'reward': _host_copy(self.reward), 'done': _host_copy(self.done),
                 'episode_carry': carry}
 
     def load_state_dict(self, state: dict) -> None:

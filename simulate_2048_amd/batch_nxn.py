@@ -14,7 +14,7 @@ from __future__ import annotations
 import torch
 
 from . import capi
-from .batch import _p, _stream_handle
+from .batch import _host_copy, _p, _stream_handle
 
 
 class BatchedEnvNxN:
@@ -42,6 +42,25 @@ class BatchedEnvNxN:
         self.reward = torch.zeros((n,), dtype=torch.int32, device=self.device)
         self.done = torch.zeros((n,), dtype=torch.uint8, device=self.device)
         self.legal = torch.zeros((n,), dtype=torch.uint8, device=self.device) if with_legal else None
+        self._actions_u8 = None
+
+    def _actions(self, actions: torch.Tensor) -> torch.Tensor:
+        """The caller's moves as the kernels read them: a contiguous uint8 tensor of shape (num_envs,) on this device.  Anything else
+        with the right number of elements (an int64 argmax, a host tensor, a strided view) is converted into a persistent uint8
+        buffer -- one copy kernel, no allocation -- as ``BatchedEnv2048.step`` does; a wrong count raises."""
+        if not isinstance(actions, torch.Tensor):
+            actions = torch.as_tensor(actions)
+        if actions.numel() != self.num_envs:
+            raise ValueError(f'expected {self.num_envs} actions, got {actions.numel()}')
+        if actions.dtype == torch.uint8 and actions.device == self.device and actions.dim() == 1 and actions.is_contiguous():
+            return actions
+        if actions.dtype.is_floating_point or actions.dtype.is_complex or actions.dtype == torch.bool:
+            raise ValueError(f'actions must be integers (0 left, 1 up, 2 right, 3 down), got {actions.dtype}')
+        staged = self._actions_u8
+        if staged is None:
+            staged = self._actions_u8 = torch.empty((self.num_envs,), dtype=torch.uint8, device=self.device)
+        staged.copy_(actions.reshape(self.num_envs))  # wraps mod 256, the kernel reads mod 4
+        return staged
 
     def reset(self) -> torch.Tensor:
         """Two tiles on every (empty) board, from the reset block of the current step index.  Returns the boards (in place)."""
@@ -53,14 +72,14 @@ class BatchedEnvNxN:
         return self.boards
 
     def step(self, actions: torch.Tensor | None = None):
-        """One move per board (uint8 actions 0 left, 1 up, 2 right, 3 down on this device; None: drawn from the step word in the
-        kernel) -> (boards, reward int32, done uint8), all updated in place; ``legal`` describes the boards left behind."""
+        """One move per board (actions 0 left, 1 up, 2 right, 3 down, taken mod 4; a contiguous uint8 tensor on this device is read
+        in place, anything else goes through ``_actions``; None: drawn from the step word in the kernel) -> (boards, reward int32,
+        done uint8), all updated in place; ``legal`` describes the boards left behind."""
         flags = capi.FLAG_AUTO_RESET if self.auto_reset else 0
         if actions is None:
             flags |= capi.FLAG_RANDOM_ACTIONS
         else:
-            if actions.dtype != torch.uint8 or actions.device != self.device or actions.shape != (self.num_envs,) or not actions.is_contiguous():
-                raise ValueError(f'actions must be a contiguous uint8 tensor of shape ({self.num_envs},) on {self.device}')
+            actions = self._actions(actions)
         dev, stream = _stream_handle(self.device)
         self.lib.nxn_step(dev, stream, self.num_envs, self.size, self.env_base, _p(self.boards), _p(actions), _p(self.reward), _p(self.done),
                           _p(self.legal), self.seed, self.step_index, flags)
@@ -78,6 +97,7 @@ class BatchedEnvNxN:
     def afterstates(self, actions: torch.Tensor):
         """latent_state of every board for its action, no spawn -> (boards (N, S, S), reward int32, changed uint8); the env is untouched."""
         n = self.num_envs
+        actions = self._actions(actions)
         out = torch.empty_like(self.boards)
         reward = torch.empty((n,), dtype=torch.int32, device=self.device)
         changed = torch.empty((n,), dtype=torch.uint8, device=self.device)
@@ -90,14 +110,30 @@ class BatchedEnvNxN:
         e = self.boards.to(torch.int64)
         return torch.where(e > 0, torch.ones_like(e) << e, torch.zeros_like(e)).to(dtype)
 
+    # -- checkpoint / resume (the layout of BatchedEnv2048.state_dict plus the board size) -----------------------------------------
     def state_dict(self) -> dict:
-        return {'boards': self.boards.clone(), 'step_index': self.step_index, 'seed': self.seed, 'env_base': self.env_base, 'size': self.size}
+        """Everything that determines the future of this batch, as host tensors / integers (``torch.save`` -able): stepping a
+        restored batch gives byte for byte what the original would have produced."""
+        return {'format': 1, 'size': self.size, 'num_envs': self.num_envs, 'seed': self.seed, 'env_base': self.env_base,
+                'step_index': int(self.step_index), 'auto_reset': self.auto_reset, 'boards': _host_copy(self.boards),
+                'reward': _host_copy(self.reward), 'done': _host_copy(self.done)}
 
     def load_state_dict(self, state: dict) -> None:
-        if int(state['size']) != self.size or tuple(state['boards'].shape) != tuple(self.boards.shape):
-            raise ValueError('state_dict of another shape')
-        self.boards.copy_(state['boards'])
-        self.step_index, self.seed, self.env_base = int(state['step_index']), int(state['seed']), int(state['env_base'])
+        """Restore ``state_dict()`` output into this batch (same size and number of environments; seed, index range, step index
+        and the auto-reset policy come from the checkpoint); ``legal`` is recomputed for the restored boards."""
+        if state.get('format') != 1 or int(state['size']) != self.size or int(state['num_envs']) != self.num_envs:
+            raise ValueError(f'checkpoint of {state.get("num_envs")} boards of size {state.get("size")} (format {state.get("format")}) '
+                             f'does not fit this batch of {self.num_envs} boards of size {self.size}')
+        shape = (self.num_envs, self.size, self.size)
+        self.boards.copy_(torch.as_tensor(state['boards'], dtype=torch.uint8).reshape(shape))
+        self.reward.copy_(torch.as_tensor(state['reward'], dtype=torch.int32).reshape(self.num_envs))
+        self.done.copy_(torch.as_tensor(state['done'], dtype=torch.uint8).reshape(self.num_envs))
+        self.seed = int(state['seed']) & 0xFFFFFFFFFFFFFFFF
+        self.env_base, self.step_index = int(state['env_base']), int(state['step_index'])
+        self.auto_reset = bool(state['auto_reset'])
+        if self.legal is not None:
+            dev, stream = _stream_handle(self.device)
+            self.lib.nxn_status(dev, stream, self.num_envs, self.size, _p(self.boards), None, _p(self.legal), None, None)
 
 
 __all__ = ['BatchedEnvNxN']

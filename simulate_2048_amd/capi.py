@@ -66,6 +66,7 @@ EPISODES_FROZEN = 1
 EPISODES_REWARD_F32 = 2
 ROLLOUT_STATS_WORDS = 40
 SIGNAL_MAX_ENVS = 512
+EXPAND_OFFSETS_BLOCK = 512
 INLINE_MAX_ENVS = 64
 NXN_MAX_SIZE = 8
 
@@ -122,6 +123,7 @@ PROTOTYPES = {
     'env2048_expectimax_ply': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
     'env2048_expectimax_depth2': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr, _ptr]),
     'env2048_expand_count': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr]),
+    'env2048_expand_scratch_words': (_u64, [_u64]),
     'env2048_expand_offsets': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr, _u64]),
     'env2048_expand': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr, _ptr, _ptr, _ptr]),
     'env2048_expectimax_depth2_f64': (_c_int, [_c_int, _ptr, _u64, _ptr, _ptr]),
@@ -318,6 +320,10 @@ class Library:
 
     def expand_count(self, device, stream, n, boards, counts) -> None:
         self._check(self._dll.env2048_expand_count(device, stream, n, boards, counts))
+
+    def expand_scratch_words(self, n) -> int:
+        """uint64 words of the `scratch` argument of ``expand_offsets`` for n boards (the library's block size decides)."""
+        return int(self._dll.env2048_expand_scratch_words(n))
 
     def expand_offsets(self, device, stream, n, boards, offsets, scratch, host_total=None, sequence_value=0) -> None:
         self._check(self._dll.env2048_expand_offsets(device, stream, n, boards, offsets, scratch, host_total, sequence_value))

@@ -522,13 +522,17 @@ __global__ __launch_bounds__(BLOCK) void expand_count_kernel(uint64_t n, const u
 }
 
 // ---- offsets of a level on the device: count, scan, total -- no host round trip per level ---------------------------------
-// expand_offsets_kernel: children of every board of a block of BLOCK boards + the exclusive scan inside the block (wave scan
+// The block of these launches is the header's ENV2048_EXPAND_OFFSETS_BLOCK, not the tunable BLOCK of tiling.hpp: the caller sizes `scratch`
+// from it.
+constexpr int OFFSETS_BLOCK = ENV2048_EXPAND_OFFSETS_BLOCK;
+static_assert(OFFSETS_BLOCK % 64 == 0 && OFFSETS_BLOCK <= 1024, "expand_offsets_kernel: whole waves, one workgroup");
+// expand_offsets_kernel: children of every board of a block of OFFSETS_BLOCK boards + the exclusive scan inside the block (wave scan
 // by DPP-free shuffles, then the eight wave totals through LDS): offsets[i] = children of the block's boards before i,
 // block_total[block] = children of the block.
-__global__ __launch_bounds__(BLOCK) void expand_offsets_kernel(uint64_t n, const uint8_t *boards, uint64_t *offsets, uint64_t *block_total)
+__global__ __launch_bounds__(OFFSETS_BLOCK) void expand_offsets_kernel(uint64_t n, const uint8_t *boards, uint64_t *offsets, uint64_t *block_total)
 {
-    __shared__ uint32_t wave_total[WAVES_PER_BLOCK];
-    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    __shared__ uint32_t wave_total[OFFSETS_BLOCK / 64];
+    const uint64_t i = (uint64_t)blockIdx.x * OFFSETS_BLOCK + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t count = 0u;
     if (i < n) {
@@ -550,7 +554,7 @@ __global__ __launch_bounds__(BLOCK) void expand_offsets_kernel(uint64_t n, const
     __syncthreads();
     uint32_t before = 0u, all = 0u;
 #pragma unroll
-    for (uint32_t w = 0; w < (uint32_t)WAVES_PER_BLOCK; ++w) {
+    for (uint32_t w = 0; w < (uint32_t)(OFFSETS_BLOCK / 64); ++w) {
         const uint32_t t = wave_total[w];
         before += w < wave ? t : 0u;
         all += t;
@@ -592,9 +596,9 @@ __global__ __launch_bounds__(1024) void scan_block_totals_kernel(uint64_t blocks
     }
 }
 
-__global__ __launch_bounds__(BLOCK) void add_block_base_kernel(uint64_t n, uint64_t *offsets, const uint64_t *block_base)
+__global__ __launch_bounds__(OFFSETS_BLOCK) void add_block_base_kernel(uint64_t n, uint64_t *offsets, const uint64_t *block_base)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const uint64_t i = (uint64_t)blockIdx.x * OFFSETS_BLOCK + threadIdx.x;
     if (i < n) offsets[i] += block_base[blockIdx.x];
 }
 
@@ -987,6 +991,8 @@ int env2048_expand_count(int device, void *stream, uint64_t n, const uint8_t *bo
     return launched("env2048_expand_count launch");
 }
 
+uint64_t env2048_expand_scratch_words(uint64_t n) { return (n + ENV2048_EXPAND_OFFSETS_BLOCK - 1) / ENV2048_EXPAND_OFFSETS_BLOCK + 1; }
+
 int env2048_expand_offsets(int device, void *stream, uint64_t n, const uint8_t *boards, uint64_t *offsets, uint64_t *scratch,
                            uint64_t *host_total, uint64_t sequence_value)
 {
@@ -997,10 +1003,10 @@ int env2048_expand_offsets(int device, void *stream, uint64_t n, const uint8_t *
     if (int rc = check_count(n)) return rc;
     DeviceScope scope(device);
     if (scope.rc) return scope.rc;
-    const uint64_t blocks = (n + BLOCK - 1) / BLOCK;
-    hipLaunchKernelGGL(expand_offsets_kernel, grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, n, boards, offsets, scratch);
+    const uint64_t blocks = env2048_expand_scratch_words(n) - 1;
+    hipLaunchKernelGGL(expand_offsets_kernel, dim3((unsigned)blocks), dim3(OFFSETS_BLOCK), 0, (hipStream_t)stream, n, boards, offsets, scratch);
     hipLaunchKernelGGL(scan_block_totals_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, blocks, scratch, host_total, sequence_value);
-    hipLaunchKernelGGL(add_block_base_kernel, grid_for(n), dim3(BLOCK), 0, (hipStream_t)stream, n, offsets, scratch);
+    hipLaunchKernelGGL(add_block_base_kernel, dim3((unsigned)blocks), dim3(OFFSETS_BLOCK), 0, (hipStream_t)stream, n, offsets, scratch);
     return launched("env2048_expand_offsets launch");
 }
 

@@ -100,6 +100,7 @@ __device__ __forceinline__ void store_obs_rows_coalesced(float *obs, int64_t mir
 // (an interrupt-driven wake-up that costs more than the whole move at the reference's batch sizes).  Every thread of the
 // block calls this exactly once, on every path, as its last action; the kernel then ends by itself -- nothing on the GPU
 // ever waits for the host.  sequence == NULL (wave-uniform): no barrier, no fence, nothing.
+static_assert(BLOCK >= ENV2048_SIGNAL_MAX_ENVS, "a signalled launch (n <= ENV2048_SIGNAL_MAX_ENVS) must be ONE workgroup: signal_sequence orders with a workgroup barrier");
 __device__ __forceinline__ void signal_sequence(uint64_t *sequence, uint64_t value)
 {
     if (!sequence) return;

@@ -77,7 +77,9 @@ class DeviceArray(torch.Tensor):
     def __int__(self):
         return int(self.item())
 
-    def __index__(self):
+    def __index__(self):  # as torch: only integer (and bool) scalars index or count; a float reward must not truncate silently
+        if self.dtype.is_floating_point or self.dtype.is_complex:
+            raise TypeError(f'only integer tensors of a single element can be converted to an index (got {self.dtype})')
         return int(self.item())
 
 

@@ -197,7 +197,7 @@ def expand(boards: torch.Tensor, rt=None) -> dict:
                 'reward': torch.empty((0, 4), dtype=torch.int32, device=rt.device), 'n_empty': torch.empty((0, 4), dtype=torch.uint8, device=rt.device)}
     dev, stream = rt.handles()
     offsets = torch.empty((n,), dtype=torch.int64, device=rt.device)
-    scratch = torch.empty(((n + 511) // 512 + 1,), dtype=torch.int64, device=rt.device)
+    scratch = torch.empty((rt.lib.expand_scratch_words(n),), dtype=torch.int64, device=rt.device)
     _, slot, words, address, serial = _total_slot(rt, stream)
     rt.lib.expand_offsets(dev, stream, n, _p(boards), _p(offsets), _p(scratch), address, serial)
     out = {'offsets': offsets, 'reward': torch.empty((n, 4), dtype=torch.int32, device=rt.device),

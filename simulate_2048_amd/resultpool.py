@@ -254,9 +254,10 @@ class ResultPool:
         key = (n, device, stream)
         with self._lock:
             sets = self._sets.pop(key, None)  # (re-inserted below: dict order = recency of use)
+            if self._graveyard:  # (an empty-list test on the steady-state path; parked sets go as soon as their last launch is done)
+                self._reap()
             if sets is None:
                 sets = []
-                self._reap()
                 while len(self._sets) >= MAX_KEYS:  # a caller cycling through many batch sizes must not pin memory for all of them
                     oldest = next(iter(self._sets))
                     self._bury(self._sets.pop(oldest))

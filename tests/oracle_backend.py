@@ -14,6 +14,7 @@ import ctypes
 import numpy as np
 
 import oracle
+from simulate_2048_amd import capi
 from oracle import nxn as nxn_oracle
 
 
@@ -394,6 +395,9 @@ class OracleLibrary:
             c += (2 * after[a]['changed'].astype(np.uint32) * (after[a]['boards'] == 0).sum(axis=1).astype(np.uint32))
         _view(counts, n, np.uint32)[:] = c
 
+    def expand_scratch_words(self, n):
+        return (n + capi.EXPAND_OFFSETS_BLOCK - 1) // capi.EXPAND_OFFSETS_BLOCK + 1
+
     def expand_offsets(self, device, stream, n, boards, offsets, scratch, host_total=None, sequence_value=0):
         self.calls.append(('expand_offsets', n))
         counts = np.zeros(n, dtype=np.uint32)
@@ -401,8 +405,8 @@ class OracleLibrary:
         self.calls.pop()
         ends = np.cumsum(counts.astype(np.int64))
         _view(offsets, n, np.int64)[:] = ends - counts
-        blocks = (n + 511) // 512
-        block_sums = np.add.reduceat(counts.astype(np.int64), np.arange(0, n, 512))
+        blocks = self.expand_scratch_words(n) - 1
+        block_sums = np.add.reduceat(counts.astype(np.int64), np.arange(0, n, capi.EXPAND_OFFSETS_BLOCK))
         sc = _view(scratch, blocks + 1, np.int64)
         sc[:blocks] = np.cumsum(block_sums) - block_sums
         sc[blocks] = int(ends[-1])

@@ -85,6 +85,12 @@ def test_returns_are_numpy_convertible_device_arrays(api_runtime):
     assert hasattr(states.board, '__dlpack__')
     back = torch.from_dlpack(states.board.as_subclass(torch.Tensor))
     assert back.data_ptr() == states.board.data_ptr()  # zero-copy hand-over of the device buffer
+    # an integer scalar indexes / counts, a float one does not (as for any torch tensor: no silent truncation)
+    assert list(range(states.step_count[0] + 2)) == [0, 1] and [7, 8][states.step_count[0]] == 7
+    with pytest.raises(TypeError):
+        range(states.total_reward[0])
+    with pytest.raises(TypeError):
+        [7, 8][states.total_reward[0]]
 
 
 def test_batched_step_is_vmap_of_step(api_runtime):
