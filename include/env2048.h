@@ -16,7 +16,8 @@
  *     and two events, created by the first env2048_step_sequence call that runs as two chains (see there, and "The helper
  *     thread" below it for what that thread costs and how to switch its polling off).
  *   - `stream` is a hipStream_t (NULL = the device's default stream).  Calls are ASYNCHRONOUS on
- *     that stream; the caller synchronises.  Entry points are re-entrant and thread-safe.
+ *     that stream; the caller synchronises.  Entry points are re-entrant and thread-safe.  (One exception, stronger, not
+ *     weaker: an env2048_step_sequence call that takes the direct route returns with its results complete -- see there.)
  *   - Return value: 0 (ENV2048_OK) or a negative error code; env2048_last_error() returns a
  *     thread-local message for the last failure on the calling thread.  No exceptions, no traps
  *     on bad *data* (actions are taken mod 4; exponents > 31 are undefined input).
@@ -61,7 +62,7 @@ extern "C" {
 #define ENV2048_EXPORT
 #endif
 
-#define ENV2048_ABI_VERSION 4
+#define ENV2048_ABI_VERSION 5
 
 #define ENV2048_OK 0
 #define ENV2048_ERR_INVALID_ARG (-1) /* NULL required pointer, bad flag bits */
@@ -91,6 +92,9 @@ extern "C" {
 /* env2048_step_sequence only, a tuning hint that changes no result: never split the batch into two half-batch chains
  * (see env2048_step_sequence). */
 #define ENV2048_FLAG_SINGLE_CHAIN 512u
+/* env2048_step_sequence only, a tuning hint that changes no result: never take the direct-dispatch route (the library's own
+ * queues, see env2048_step_sequence, "The direct route"): the call stays `count` asynchronous launches on `stream`. */
+#define ENV2048_FLAG_NO_DIRECT 1024u
 /* env2048_step* only: `reward` is an n-float32 array receiving the LOG-NORMALISED reward log2(score) / 16 (0 for a
  * score of 0) -- normalize_reward of the reference (twentyfortyeight/utils/normalize.py:6-33, the `normalize=True`
  * constructor flag, twentyfortyeight/envs/twentyfortyeight.py:80-81) for a whole batch; within 1 ulp (float32) of the
@@ -222,6 +226,28 @@ ENV2048_EXPORT int env2048_step_sequence_plan(uint64_t n, uint32_t count, uint32
  * 6.5-6.7 us instead of 7.7-7.9 us per 2^20-board step in long sequences (count = 50: -10 %, 20: break-even; smaller batches and
  * batches beyond the Infinity Cache lose, hence the bounds).  Results are bit-identical.  env2048_step_sequence_plan reports
  * the decision.
+ *
+ * The direct route.  A sequence of count >= 8 steps (ENV2048_DIRECT_MIN_STEPS) over n <= 2^21 boards that asks for no legal /
+ * obs output (and carries none of NO_DIRECT, STORES_WRITE_THROUGH, TILE_*), on a stream that is not being captured, does not go
+ * through the HIP runtime at all: the library writes the `count` kernel-dispatch packets of each chain (two half-batch chains
+ * from 2^18 boards, else one) into user-mode queues of its own -- created on a device's first such call together with a second
+ * copy of the step kernels loaded through ROCr -- from the calling thread alone (0.13-0.25 us of host time per packet: no
+ * helper thread).  Only the first packet of a chain carries an acquire fence and only the last a release fence (system scope);
+ * between them the boards never leave the XCD L2 their workgroups run on: block k owns the same boards in every launch, and a
+ * queue deals workgroup k of every dispatch to the same XCD for as long as no queue is created or destroyed on the device.
+ * That holds in practice, not by contract, so it is CHECKED: the first launch records every workgroup's XCD (and copies the
+ * boards it loads into a snapshot buffer of the library, 16 n bytes of device memory kept per device), every later launch
+ * compares; after one mismatch anywhere in the sequence the call puts the snapshot back and runs the sequence again through
+ * the stream route, so the caller gets the same bytes either way (env2048_direct_stats counts the reruns).  5.3-5.5 us per
+ * 2^20-board step at count = 200 and 6.3-6.5 at count = 20, where the stream route needs 7.0-8.0 and 9.0-9.2.  Results are
+ * bit-identical.
+ *   SEMANTICS ON THIS ROUTE: the call first waits until everything enqueued on `stream` has completed (hipStreamSynchronize if
+ *   the stream is busy), and RETURNS WHEN THE SEQUENCE HAS COMPLETED -- every output is in memory, visible to the host, to
+ *   `stream` and to any other stream.  That is stronger than the asynchronous contract above, not different from it for a
+ *   caller that synchronises anyway; a caller that wants the call to return at once passes ENV2048_FLAG_NO_DIRECT.  The
+ *   calling thread polls for completion (about 8 us per step), then sleeps in the runtime.  Calls on one device are
+ *   serialised.  The route switches itself off (and env2048_direct_info says why) where it cannot run: no large-BAR access to
+ *   device memory, a device that is not gfx950 with 8 XCDs, ENV2048_DIRECT=0 in the environment.
  * [replaces: the env.step calls of the move loop, reinforce/training/self_play.py:314-368]
  */
 ENV2048_EXPORT int env2048_step_sequence(int device, void *stream, uint64_t n, uint64_t env_base, uint8_t *boards,
@@ -258,6 +284,23 @@ typedef struct env2048_helper_info {
     uint64_t jobs, cpu_ns;
 } env2048_helper_info;
 ENV2048_EXPORT int env2048_helper_stats(int device, env2048_helper_info *out);
+
+/*
+ * The direct route of env2048_step_sequence on `device`: available (1 = ready; the call starts the route up if this is its
+ * first use on the device -- two queues, 256 KiB of argument blocks), `reason` (why not, or what it found), and counters:
+ * sequences run, their steps and packets, calls that were eligible by size and flags but had to take the stream route (a
+ * captured stream), sequences that had to be run again on the stream route (see env2048_step_sequence), the number of chains
+ * of the last sequence and its duration ON THE DEVICE (first packet's start to last packet's end, from the queues' dispatch
+ * timestamps; 0 when ENV2048_DIRECT_TIMING=0).  env2048_direct_eligible answers, without touching a device, whether a call
+ * of this shape would be offered to the route (extras != 0: legal / obs / max_exp / normalised reward are asked for).
+ */
+typedef struct env2048_direct_info {
+    uint32_t available, last_chains;
+    uint64_t calls, steps, packets, declined, reruns, last_gpu_ns;
+    char reason[160];
+} env2048_direct_info;
+ENV2048_EXPORT int env2048_direct_stats(int device, env2048_direct_info *out);
+ENV2048_EXPORT int env2048_direct_eligible(uint64_t n, uint32_t count, uint32_t flags, int32_t extras);
 
 /*
  * The reinforce/game form of one transition, fused: boards are int32 tile VALUES (n x 16, in

@@ -17,7 +17,7 @@ REPO = PKG.parent
 CSRC = PKG / 'csrc'
 SOURCES = [CSRC / name for name in ('step_kernels.hip', 'rollout_kernels.hip', 'state_i32_kernels.hip', 'search_kernels.hip',
                                     'transform_kernels.hip', 'nxn_kernels.hip')]
-HEADERS = sorted(CSRC.glob('*.hpp')) + [REPO / 'include' / 'env2048.h']
+HEADERS = sorted(CSRC.glob('*.hpp')) + [REPO / 'include' / 'env2048.h', CSRC / 'direct_image.S']
 LIB = PKG / 'lib' / 'libenv2048.so'
 ARCH = 'gfx950'
 COMMON_FLAGS = [f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden', '-pthread', '-DENV2048_BUILDING',
@@ -60,13 +60,21 @@ def build_library(force: bool = False, verbose: bool = False, extra_flags: list[
     flags = COMMON_FLAGS + (extra_flags or [])
     with tempfile.TemporaryDirectory(prefix='env2048_build_') as tmpdir:
         objects = [Path(tmpdir) / (s.stem + '.o') for s in SOURCES]
-        with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:
+        # the step kernels once more as a BARE code object (device code only, same flags): direct_dispatch.hpp loads it through
+        # ROCr for the queues the library drives itself; direct_image.S links it into the shared object as read-only data
+        image = Path(tmpdir) / 'step_kernels.hsaco'
+        image_object = Path(tmpdir) / 'direct_image.o'
+        with ThreadPoolExecutor(max_workers=min(len(SOURCES) + 1, os.cpu_count() or 1)) as pool:
             jobs = [pool.submit(_run, [hipcc(), *flags, '-c', str(s), '-o', str(o)], verbose) for s, o in zip(SOURCES, objects)]
+            jobs.append(pool.submit(_run, [hipcc(), *flags, '--offload-device-only', '--no-gpu-bundle-output', str(SOURCES[0]), '-o', str(image)],
+                                    verbose))
             for job in jobs:
                 job.result()
+        _run(['gcc', '-c', f'-DENV2048_DIRECT_IMAGE="{image}"', str(CSRC / 'direct_image.S'), '-o', str(image_object)], verbose)
         tmp = target.with_suffix('.so.tmp%d' % os.getpid())
         try:
-            _run([hipcc(), f'--offload-arch={ARCH}', '-shared', '-fPIC', '-pthread', *[str(o) for o in objects], '-o', str(tmp)], verbose)
+            _run([hipcc(), f'--offload-arch={ARCH}', '-shared', '-fPIC', '-pthread', *[str(o) for o in objects], str(image_object), '-L/opt/rocm/lib',
+                  '-lhsa-runtime64', '-o', str(tmp)], verbose)
             os.replace(tmp, target)
         finally:
             tmp.unlink(missing_ok=True)

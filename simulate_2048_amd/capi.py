@@ -12,7 +12,7 @@ from __future__ import annotations
 import ctypes
 from pathlib import Path
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 OK = 0
 ERR_INVALID_ARG = -1
@@ -31,6 +31,7 @@ FLAG_REWARD_LOG2_F32 = 64
 FLAG_TILE_SMALL = 128
 FLAG_TILE_LARGE = 256
 FLAG_SINGLE_CHAIN = 512
+FLAG_NO_DIRECT = 1024
 
 LIB_PATH = Path(__file__).resolve().parent / 'lib' / 'libenv2048.so'
 
@@ -62,6 +63,13 @@ class HelperInfo(ctypes.Structure):
     _fields_ = [('created', _u32), ('spin_us', _u32), ('jobs', _u64), ('cpu_ns', _u64)]
 
 
+class DirectInfo(ctypes.Structure):
+    """``env2048_direct_info`` of include/env2048.h: the direct-dispatch route of env2048_step_sequence on one device."""
+
+    _fields_ = [('available', _u32), ('last_chains', _u32), ('calls', _u64), ('steps', _u64), ('packets', _u64), ('declined', _u64),
+                ('reruns', _u64), ('last_gpu_ns', _u64), ('reason', ctypes.c_char * 160)]
+
+
 EPISODES_FROZEN = 1
 EPISODES_REWARD_F32 = 2
 ROLLOUT_STATS_WORDS = 40
@@ -87,6 +95,8 @@ PROTOTYPES = {
     'env2048_step_sequence': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, ctypes.POINTER(_ptr), _ptr, _ptr, _ptr, _ptr, _u64, _u64, _u64,
                                         _u32, _u32]),
     'env2048_helper_stats': (_c_int, [_c_int, ctypes.POINTER(HelperInfo)]),
+    'env2048_direct_stats': (_c_int, [_c_int, ctypes.POINTER(DirectInfo)]),
+    'env2048_direct_eligible': (_c_int, [_u64, _u32, _u32, ctypes.c_int32]),
     'env2048_step_state_i32': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _u64, _u64]),
     'env2048_step_state_i32_to': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _u64,
                                             _u64]),
@@ -233,6 +243,22 @@ class Library:
         """``actions``: None or a ctypes array ``(c_void_p * count)`` of device pointers, one per step."""
         self._check(self._dll.env2048_step_sequence(device, stream, n, env_base, boards, actions, reward, done, legal, obs,
                                                     row_stride, seed, step_index, count, flags))
+
+    def direct_stats(self, device: int) -> dict:
+        """The direct-dispatch route of env2048_step_sequence on ``device`` (started up by this call if it is its first use):
+        {'available', 'reason', 'calls', 'steps', 'packets', 'declined', 'reruns', 'last_chains', 'last_gpu_ns'}."""
+        info = DirectInfo()
+        self._check(self._dll.env2048_direct_stats(device, ctypes.byref(info)))
+        return {'available': bool(info.available), 'reason': info.reason.decode(errors='replace'), 'calls': int(info.calls), 'steps': int(info.steps),
+                'packets': int(info.packets), 'declined': int(info.declined), 'reruns': int(info.reruns), 'last_chains': int(info.last_chains),
+                'last_gpu_ns': int(info.last_gpu_ns)}
+
+    def direct_eligible(self, n: int, count: int, flags: int, extras: bool = False) -> bool:
+        """Would env2048_step_sequence offer a call of this shape to the direct route?  (sizes and flags only; no device call)"""
+        rc = self._dll.env2048_direct_eligible(n, count, flags, 1 if extras else 0)
+        if rc < 0:
+            raise Env2048Error(rc, self.last_error())
+        return rc == 1
 
     def helper_stats(self, device: int) -> dict:
         """The helper thread of ``device`` (env2048_step_sequence's second chain): {'created', 'spin_us', 'jobs', 'cpu_ns'}.

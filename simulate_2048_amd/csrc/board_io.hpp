@@ -13,13 +13,34 @@
 
 namespace env2048 {
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ Board load_board(const uint8_t *boards, uint64_t i)
 {
-    uint4 v = reinterpret_cast<const uint4 *>(boards)[i];
+    const uint4 v = reinterpret_cast<const uint4 *>(boards)[i];
     return Board{v.x, v.y, v.z, v.w};
 }
 
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// Agent-scope board loads for the launches of a direct-dispatch chain (step_block<..., RESIDENT>): buffer_load_dwordx4 ... sc1
+// goes past the CU's vector L1 to the XCD's L2.  (16-byte loads have no agent-scope form the compiler tracks other than the
+// buffer intrinsic with cache-policy bit 4 = sc1 on gfx94x / gfx950; `nt` global loads measured 6 % slower on the
+// write-through path and are not an architectural L1 bypass.)  The descriptor covers one wave's tile.
+struct TileBuffer {
+    __amdgpu_buffer_rsrc_t rsrc;
+};
+__device__ __forceinline__ TileBuffer make_tile_buffer(uint8_t *boards, uint64_t tile0, uint64_t tile_boards_here)
+{
+    uint8_t *base = boards + 16u * tile0;  // (wave-uniform; the read-first-lanes make that provable to the compiler)
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)base);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)base >> 32));
+    const uint32_t bytes = __builtin_amdgcn_readfirstlane((uint32_t)(16u * tile_boards_here));
+    return TileBuffer{__builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((uintptr_t)hi << 32) | lo), 0, (int)bytes, 0x00020000)};
+}
+__device__ __forceinline__ Board load_board_agent(const TileBuffer &tile, uint32_t board_in_tile)
+{
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(tile.rsrc, (int)(16u * board_in_tile), 0, /*sc1*/ 16);
+    return Board{v.x, v.y, v.z, v.w};
+}
 
 // Write-through (sc1) stores: the line is not left dirty in the XCD's L2, so the end-of-kernel L2
 // write-back -- which sits on the critical path of back-to-back step launches -- has nothing to do

@@ -14,6 +14,7 @@
 #include "philox_strip.hpp"
 #include "step_planner.hpp"
 #include "helper_thread.hpp"
+#include "direct_dispatch.hpp"
 
 using namespace env2048;
 using namespace env2048::host;
@@ -58,6 +59,7 @@ struct StepArgs {
     RngKey key;
     uint32_t flags;
     uint8_t *max_exp;  // log2(max tile) of the board after move + spawn, BEFORE an auto-reset replaces it
+    uint8_t *snapshot = nullptr;  // RESIDENT only: where the first launch of a direct-dispatch chain copies the boards it loads
 };
 
 __device__ __forceinline__ DirSelectors load_selectors(const uint4 *dir_lds, uint32_t action)
@@ -98,7 +100,10 @@ __device__ __forceinline__ void reset_queued(const StepArgs &a, uint64_t block0,
 // ENV2048_EXP_ABLATE (bit 0 no game logic, bit 1 no Philox, bit 2 no reward/done stores, bit 3 terminal
 // boards queued but not rebuilt) and ENV2048_EXP_STAMPS (five s_memrealtime stamps + HW_ID per wave into
 // the obs buffer) exist for tools/microbench only.
-template <bool EXTRAS, bool FULL, bool RANDOM, int BOARDS_PER_LANE>
+// RESIDENT (the direct-dispatch chain of direct_dispatch.hpp, launches whose packets carry no cache fences): boards are loaded
+// at agent scope (sc1 buffer loads: past this CU's vector L1, which nothing invalidates between such launches and which may
+// hold the tile as ANOTHER launch's workgroup on this CU left it; the XCD's L2 is the home of the tile for the whole chain).
+template <bool EXTRAS, bool FULL, bool RANDOM, int BOARDS_PER_LANE, bool RESIDENT = false>
 __device__ __forceinline__ void step_block(const StepArgs &a, uint4 *dir_lds, uint32_t (*word_lds)[word_strip_words(BOARDS_PER_LANE)],
                                            uint32_t *queue_state, uint16_t *reset_slot)
 {
@@ -123,12 +128,20 @@ __device__ __forceinline__ void step_block(const StepArgs &a, uint4 *dir_lds, ui
     Board bd[BOARDS_PER_LANE];
     uint32_t act[BOARDS_PER_LANE];
     constexpr int HALF = BOARDS_PER_LANE / 2 > 0 ? BOARDS_PER_LANE / 2 : 1;
+    // (RESIDENT: the tile as a buffer -- a wave-uniform descriptor over its 16 * TILE_BOARDS bytes, clipped at the end of the
+    // batch, so a lane beyond it reads zeros; the lane's byte offset travels in the 32-bit voffset)
+    const uint64_t tile_boards_here = FULL ? (uint64_t)TILE_BOARDS : (tile0 < a.n ? (a.n - tile0 < TILE_BOARDS ? a.n - tile0 : TILE_BOARDS) : 0u);
+    TileBuffer tile;
+    if constexpr (RESIDENT) tile = make_tile_buffer(a.boards, tile0, tile_boards_here);
     auto issue_loads = [&](int j) {
         const uint64_t i = tile0 + 64u * j + lane;
         bd[j] = Board{0u, 0u, 0u, 0u};
         act[j] = 0u;
         if (FULL || i < a.n) {
-            bd[j] = load_board(a.boards, i);
+            if constexpr (RESIDENT)
+                bd[j] = load_board_agent(tile, 64u * j + lane);
+            else
+                bd[j] = load_board(a.boards, i);
             if (!RANDOM) act[j] = a.actions[i];
         }
     };
@@ -183,6 +196,10 @@ __device__ __forceinline__ void step_block(const StepArgs &a, uint4 *dir_lds, ui
     bool done[BOARDS_PER_LANE];
     auto compute = [&](int j) {
         bool changed;
+        if constexpr (RESIDENT) {  // (wave-uniform: only the first launch of a chain carries a snapshot pointer)
+            const uint64_t i = tile0 + 64u * j + lane;
+            if (a.snapshot && (FULL || i < a.n)) store_board(a.snapshot, i, bd[j]);
+        }
 #if defined(ENV2048_EXP_ABLATE) && (ENV2048_EXP_ABLATE & 1)  // timing-only build: no game logic
         reward[j] = sel[j].fA + word[j];
         changed = false;
@@ -379,6 +396,50 @@ __global__ __launch_bounds__(BLOCK) void step_many_kernel(const FusedTable table
 }
 
 __global__ void advance_counter_kernel(unsigned long long *counter, unsigned long long delta) { *counter += delta; }
+
+// The step kernel of a DIRECT-DISPATCH chain (direct_dispatch.hpp): K dependent launches of one part of a batch written as AQL
+// packets into a queue of the library's own, the packets between the first and the last WITHOUT cache fences.  What makes that
+// correct: block k owns the same boards in every launch, and as long as workgroup k keeps landing on the same XCD the tile is
+// only ever touched through ONE XCD's L2, which stays its home for the whole chain (plain write-back stores; nothing leaves
+// the chip between steps but the write-once rows).  Across CUs inside the XCD the tile may move from launch to launch: hence
+// the agent-scope loads (step_block<..., RESIDENT>).  reward / done are written and never read; actions are read-only for the
+// chain.  "Keeps landing on the same XCD" is checked, not assumed -- see step_resident_body.
+constexpr uint32_t RESIDENT_ESTABLISH = 1u;      // first launch of a chain: record the XCD of every workgroup, snapshot the boards
+constexpr uint32_t RESIDENT_PRETEND_MOVED = 2u;  // (test hook of direct_dispatch.hpp) this launch's workgroups claim another XCD
+
+template <bool RANDOM, int BPL>
+__device__ __forceinline__ void step_resident_body(uint8_t *boards, const uint8_t *actions, uint64_t n, uint64_t env_base, uint32_t flags,
+                                                   uint32_t seed_lo, uint32_t seed_hi, uint32_t step_lo, uint32_t step_hi, int32_t *reward,
+                                                   uint8_t *done, uint32_t mode, uint32_t *owner, uint32_t *placement_error, uint8_t *snapshot)
+{
+    // Where am I, and is that where this block's boards live?  The first launch of a chain (it reads the boards from memory:
+    // its packet carries the acquire) writes the answer through to memory; every later launch reads it back past the caches it
+    // cannot trust for data another launch wrote (agent scope: L2-served after the first miss) and compares AFTER the step --
+    // the load's latency hides under the step, and a mismatch voids the whole sequence anyway (direct_dispatch.hpp reruns it).
+    uint32_t xcc_id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+    xcc_id = (xcc_id & 0xfu) ^ ((mode & RESIDENT_PRETEND_MOVED) ? 1u : 0u);
+    uint32_t home = xcc_id;
+    if (mode & RESIDENT_ESTABLISH) {
+        if (threadIdx.x == 0u) __hip_atomic_store(owner + blockIdx.x, xcc_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        home = __hip_atomic_load(owner + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    StepArgs a{n, env_base, boards, actions, reward, done, nullptr, nullptr, RngKey{seed_lo, seed_hi, step_lo, step_hi}, flags, nullptr};
+    a.snapshot = (mode & RESIDENT_ESTABLISH) ? snapshot : nullptr;
+    __shared__ uint4 dir_lds[8];
+    __shared__ __attribute__((aligned(16))) uint32_t word_lds[WAVES_PER_BLOCK][word_strip_words(BPL)];
+    __shared__ uint32_t queue_state;
+    __shared__ uint16_t reset_slot[block_boards(BPL)];
+    const uint64_t block0 = (uint64_t)blockIdx.x * block_boards(BPL);
+    if (block0 + block_boards(BPL) <= a.n)
+        step_block<false, true, RANDOM, BPL, true>(a, dir_lds, word_lds, &queue_state, reset_slot);
+    else
+        step_block<false, false, RANDOM, BPL, true>(a, dir_lds, word_lds, &queue_state, reset_slot);
+    if (home != xcc_id && threadIdx.x == 0u)  // (block + 1, the XCD this workgroup ran on, the XCD its boards live on)
+        __hip_atomic_store(placement_error, (1u + (blockIdx.x & 0xffffu)) | (xcc_id << 16) | ((home & 0xffu) << 24), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+}
 // [step-kernel-source-end]
 
 struct ResetArgs {
@@ -404,7 +465,7 @@ __global__ __launch_bounds__(BLOCK) void reset_kernel(ResetArgs a)
 void launch_step(const env2048_step_args &a, hipStream_t stream)
 {
     uint32_t kernel_flags = a.flags & ~(ENV2048_FLAG_STORES_WRITE_THROUGH | ENV2048_FLAG_STORES_WRITE_BACK | ENV2048_FLAG_TILE_SMALL |
-                                        ENV2048_FLAG_TILE_LARGE | ENV2048_FLAG_SINGLE_CHAIN);
+                                        ENV2048_FLAG_TILE_LARGE | ENV2048_FLAG_SINGLE_CHAIN | ENV2048_FLAG_NO_DIRECT);
     if (!misaligned(a.reward, 16) && !misaligned(a.done, 4)) kernel_flags |= INTERNAL_FLAG_WIDE_OUTPUTS;
     if (plan_write_through(a.n, a.flags)) kernel_flags |= INTERNAL_FLAG_WRITE_THROUGH;
 #ifdef ENV2048_EXP_STAMPS
@@ -452,7 +513,7 @@ void launch_group(const env2048_step_args *args, uint64_t first, uint64_t last, 
         const env2048_step_args &a = args[k];
         if (a.n == 0) continue;
         uint32_t kernel_flags = a.flags & ~(ENV2048_FLAG_STORES_WRITE_THROUGH | ENV2048_FLAG_STORES_WRITE_BACK | ENV2048_FLAG_TILE_SMALL |
-                                            ENV2048_FLAG_TILE_LARGE | ENV2048_FLAG_SINGLE_CHAIN);
+                                            ENV2048_FLAG_TILE_LARGE | ENV2048_FLAG_SINGLE_CHAIN | ENV2048_FLAG_NO_DIRECT);
         if (!misaligned(a.reward, 16) && !misaligned(a.done, 4)) kernel_flags |= INTERNAL_FLAG_WIDE_OUTPUTS;
         if (plan_write_through(total, a.flags)) kernel_flags |= INTERNAL_FLAG_WRITE_THROUGH;
         const uint32_t blocks = (uint32_t)((a.n + block_boards(bpl) - 1) / block_boards(bpl));
@@ -527,6 +588,26 @@ inline bool want_two_chains(uint64_t n, uint32_t count, uint32_t flags) { return
 #endif
 
 }  // namespace
+
+// [step-kernel-source-begin]
+// The entry points of the direct-dispatch code object carry C names: direct_dispatch.hpp finds them by name in the image it
+// loads through ROCr (the HIP runtime never launches them).
+#define ENV2048_RESIDENT_KERNEL(NAME, RANDOM, BPL)                                                                                              \
+    extern "C" __global__ __launch_bounds__(BLOCK) void NAME(uint8_t *boards, const uint8_t *actions, uint64_t n, uint64_t env_base, uint32_t flags, \
+                                                             uint32_t seed_lo, uint32_t seed_hi, uint32_t step_lo, uint32_t step_hi, int32_t *reward, \
+                                                             uint8_t *done, uint32_t mode, uint32_t *owner, uint32_t *placement_error,          \
+                                                             uint8_t *snapshot)                                                                 \
+    {                                                                                                                                           \
+        step_resident_body<RANDOM, BPL>(boards, actions, n, env_base, flags, seed_lo, seed_hi, step_lo, step_hi, reward, done, mode, owner,     \
+                                        placement_error, snapshot);                                                                             \
+    }
+ENV2048_RESIDENT_KERNEL(env2048_step_resident_small, false, 1)
+ENV2048_RESIDENT_KERNEL(env2048_step_resident_small_random, true, 1)
+ENV2048_RESIDENT_KERNEL(env2048_step_resident_large, false, BOARDS_PER_LANE)
+ENV2048_RESIDENT_KERNEL(env2048_step_resident_large_random, true, BOARDS_PER_LANE)
+#undef ENV2048_RESIDENT_KERNEL
+
+// [step-kernel-source-end]
 
 extern "C" {
 
@@ -640,6 +721,13 @@ int env2048_step_sequence(int device, void *stream, uint64_t n, uint64_t env_bas
     DeviceScope scope(device);
     if (scope.rc) return scope.rc;
     hipStream_t main_stream = (hipStream_t)stream;
+    // The direct route (direct_dispatch.hpp): the sequence as AQL packets on the library's own queues, boards resident in the
+    // XCD L2s between the first and the last launch.  NOT_TAKEN: nothing was enqueued, the stream route below runs the call.
+    if (direct::eligible(n, count, flags, legal || obs || (flags & ENV2048_FLAG_REWARD_LOG2_F32))) {
+        const direct::SequenceArgs seq{n, env_base, boards, actions, reward, done, row_stride, seed, step_index, count, flags};
+        const int rc = direct::step_sequence(device, main_stream, seq);
+        if (rc != direct::NOT_TAKEN && rc != direct::RERUN) return rc;  // (RERUN: the boards are as before the call -- the launches below redo it)
+    }
     bool two_chains = want_two_chains(n, count, flags);
     // Another thread of the process may have a global-mode stream capture open: the calls below that are not plain launches
     // (capture query, stream / event creation) would invalidate it, so this thread takes the relaxed mode while it makes them.
@@ -712,6 +800,34 @@ int env2048_helper_stats(int device, env2048_helper_info *out)
     out->jobs = h ? h->jobs() : 0u;
     out->cpu_ns = h ? h->cpu_ns() : 0u;
     return ENV2048_OK;
+}
+
+// The direct route of `device` (direct_dispatch.hpp): starts it up on first use.
+int env2048_direct_stats(int device, env2048_direct_info *out)
+{
+    if (!out) return fail(ENV2048_ERR_INVALID_ARG, "env2048_direct_stats: out is NULL");
+    DeviceScope scope(device);
+    if (scope.rc) return scope.rc;
+    direct::Device *d = direct::device_for(device);
+    memset(out, 0, sizeof *out);
+    if (!d) return fail(ENV2048_ERR_DEVICE, "env2048_direct_stats: device %d out of range", device);
+    std::lock_guard<std::mutex> call(d->call_mutex);
+    out->available = d->ok ? 1u : 0u;
+    out->last_chains = d->last_chains;
+    out->reruns = d->reruns;
+    out->calls = d->calls;
+    out->steps = d->steps;
+    out->packets = d->packets;
+    out->declined = d->declined;
+    out->last_gpu_ns = d->last_gpu_ns;
+    snprintf(out->reason, sizeof out->reason, "%s", d->reason);
+    return ENV2048_OK;
+}
+
+int env2048_direct_eligible(uint64_t n, uint32_t count, uint32_t flags, int32_t extras)
+{
+    if (flags & ~STEP_FLAGS) return fail(ENV2048_ERR_INVALID_ARG, "env2048_direct_eligible: unknown flag bits 0x%x", flags);
+    return direct::eligible(n, count, flags, extras != 0) ? 1 : 0;
 }
 
 int env2048_step_sequence_plan(uint64_t n, uint32_t count, uint32_t flags, int32_t *chains, int32_t *boards_per_lane, int32_t *write_through)

@@ -46,7 +46,7 @@ constexpr uint32_t obs_format(uint32_t flags) { return (flags >> 2) & 3u; }
 
 constexpr uint32_t STEP_FLAGS = ENV2048_FLAG_AUTO_RESET | ENV2048_FLAG_RANDOM_ACTIONS | ENV2048_FLAG_OBS_F16 | ENV2048_FLAG_OBS_BF16 |
                                 ENV2048_FLAG_STORES_WRITE_THROUGH | ENV2048_FLAG_STORES_WRITE_BACK | ENV2048_FLAG_REWARD_LOG2_F32 |
-                                ENV2048_FLAG_TILE_SMALL | ENV2048_FLAG_TILE_LARGE | ENV2048_FLAG_SINGLE_CHAIN;
+                                ENV2048_FLAG_TILE_SMALL | ENV2048_FLAG_TILE_LARGE | ENV2048_FLAG_SINGLE_CHAIN | ENV2048_FLAG_NO_DIRECT;
 
 // env2048_step_sequence: when K dependent steps of one batch run as two half-batch chains (step_kernels.hip)
 constexpr uint64_t SPLIT_MIN_BOARDS = 1ull << 20;  // below: a half (< 2^19 boards) is latency- / launch-bound on its own (2^19: 6.1 vs 5.5 us)

@@ -395,6 +395,13 @@ class OracleLibrary:
             c += (2 * after[a]['changed'].astype(np.uint32) * (after[a]['boards'] == 0).sum(axis=1).astype(np.uint32))
         _view(counts, n, np.uint32)[:] = c
 
+    def direct_stats(self, device):
+        return {'available': False, 'reason': 'the oracle stand-in has no queues', 'calls': 0, 'steps': 0, 'packets': 0, 'declined': 0, 'reruns': 0,
+                'last_chains': 0, 'last_gpu_ns': 0}
+
+    def direct_eligible(self, n, count, flags, extras=False):
+        return False
+
     def expand_scratch_words(self, n):
         return (n + capi.EXPAND_OFFSETS_BLOCK - 1) // capi.EXPAND_OFFSETS_BLOCK + 1
 

@@ -1,0 +1,287 @@
+"""
+The direct-dispatch route of env2048_step_sequence (csrc/direct_dispatch.hpp): the sequence as AQL packets on queues of the
+library's own, boards resident in the XCD L2s between the first and the last launch.  Parity chain: the route's results ==
+the stream route's (ENV2048_FLAG_NO_DIRECT: the same call as launches on the HIP stream) bit for bit at every size class --
+one chain, two chains, ragged ends, both tilings, sequences longer than the argument-block ring -- and == the oracle where the
+oracle finishes in seconds.  Plus what the route promises the caller: ordered behind the stream, complete on return, captured
+streams left to HIP, counters.  Caller loop served: reinforce/training/self_play.py:314-368 (reference).
+"""
+
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from simulate_2048_amd import capi
+
+DEV = 0
+SEED = 0x2048
+AUTO, RANDOM, NO_DIRECT = capi.FLAG_AUTO_RESET, capi.FLAG_RANDOM_ACTIONS, capi.FLAG_NO_DIRECT
+
+
+def test_eligibility_is_a_function_of_sizes_and_flags():
+    """(no device) what is offered to the route: >= 8 steps, <= 2^21 boards, plain outputs, no hint that contradicts it."""
+    lib = capi.Library()
+    assert lib.direct_eligible(1 << 20, 20, AUTO) and lib.direct_eligible(1 << 16, 8, AUTO | RANDOM) and lib.direct_eligible(1 << 21, 200, 0)
+    assert not lib.direct_eligible(1 << 20, 7, AUTO)                 # short sequences stay asynchronous launches
+    assert not lib.direct_eligible((1 << 21) + 1, 200, AUTO)         # the boards must fit the L2s
+    assert not lib.direct_eligible(1 << 20, 20, AUTO, extras=True)   # legal / obs / max_exp / normalised reward
+    assert not lib.direct_eligible(1 << 20, 20, AUTO | NO_DIRECT)
+    assert not lib.direct_eligible(1 << 20, 20, AUTO | capi.FLAG_STORES_WRITE_THROUGH)
+    assert not lib.direct_eligible(1 << 20, 20, AUTO | capi.FLAG_TILE_SMALL) and not lib.direct_eligible(1 << 20, 20, AUTO | capi.FLAG_TILE_LARGE)
+    assert lib.direct_eligible(1 << 20, 20, AUTO | capi.FLAG_STORES_WRITE_BACK | capi.FLAG_SINGLE_CHAIN)
+    assert not lib.direct_eligible(0, 20, AUTO)
+    with pytest.raises(capi.Env2048Error):
+        lib.direct_eligible(1 << 20, 20, 1 << 20)
+    header = (capi.LIB_PATH.parent.parent.parent / 'include' / 'env2048.h').read_text()
+    assert f'#define ENV2048_FLAG_NO_DIRECT {NO_DIRECT}u' in header
+
+
+gpu = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def lib():
+    L = capi.library()
+    assert L.device_count() >= 1
+    return L
+
+
+@pytest.fixture(scope='module')
+def route(lib):
+    info = lib.direct_stats(DEV)
+    if not info['available'] and any(s in info['reason'] for s in ('not host-visible', 'disabled by ENV2048_DIRECT')):
+        pytest.skip('direct route unavailable on this box: ' + info['reason'])
+    assert info['available'], 'the direct route did not start on this MI355X: ' + info['reason']
+    return info
+
+
+def stream():
+    return torch.cuda.current_stream(DEV).cuda_stream
+
+
+def p(t):
+    return None if t is None else t.data_ptr()
+
+
+def midgame(lib, n, env_base=0):
+    b = torch.empty((n, 16), dtype=torch.uint8, device='cuda')
+    d = torch.empty((n,), dtype=torch.uint8, device='cuda')
+    lib.reset(DEV, stream(), n, env_base, p(b), p(d), SEED, 0)
+    lib.rollout(DEV, stream(), n, env_base, p(b), SEED, 0, 64, None, None, None, AUTO | RANDOM)
+    torch.cuda.synchronize()
+    return b
+
+
+def run(lib, start, T, flags, env_base, stride, acts, with_reward=True, step0=500):
+    """One env2048_step_sequence call on a copy of `start` -> (boards, reward rows, done rows)."""
+    n = start.shape[0]
+    rows = T if stride else 1
+    b = start.clone()
+    r = torch.full((rows, max(stride, n)), -7, dtype=torch.int32, device='cuda') if with_reward else None
+    d = torch.full((rows, max(stride, n)), 9, dtype=torch.uint8, device='cuda')
+    table = None if acts is None else (ctypes.c_void_p * T)(*[a.data_ptr() for a in acts])
+    lib.step_sequence(DEV, stream(), n, env_base, p(b), table, p(r), p(d), None, None, stride, SEED, step0, T, flags)
+    return b, r, d
+
+
+@gpu
+@pytest.mark.parametrize('n,T,stride_kind,random_actions,auto', [
+    (65536, 24, 'rows', False, True),          # one chain, small tiling
+    (4099, 40, 'overwrite', False, True),      # ragged: a last block with a bounds-checked tail
+    ((1 << 18) + 3 * 2048 + 5, 16, 'rows', False, True),   # two chains, the halves in the small tiling, ragged second half
+    (1 << 20, 20, 'overwrite', False, True),   # the headline shape: two chains, large tiling
+    (1 << 20, 12, 'rows', True, True),         # moves drawn in the kernel
+    ((1 << 20) + 2048 + 77, 9, 'padded', False, False),  # ragged large tiling, padded rows, no auto-reset
+    (1 << 21, 8, 'overwrite', False, True),    # the largest batch the route takes
+])
+def test_direct_route_equals_stream_route(lib, route, n, T, stride_kind, random_actions, auto):
+    flags = (AUTO if auto else 0) | (RANDOM if random_actions else 0)
+    assert lib.direct_eligible(n, T, flags)
+    rng = np.random.default_rng(n + T)
+    start = midgame(lib, n, env_base=11)
+    acts = None if random_actions else [torch.from_numpy(rng.integers(0, 4, size=n).astype(np.uint8)).cuda() for _ in range(min(T, 8))]
+    acts = None if acts is None else [acts[t % len(acts)] for t in range(T)]
+    stride = {'rows': n, 'overwrite': 0, 'padded': n + 123}[stride_kind]
+    before = lib.direct_stats(DEV)
+    b1, r1, d1 = run(lib, start, T, flags, 11, stride, acts)
+    after = lib.direct_stats(DEV)
+    assert after['calls'] == before['calls'] + 1 and after['steps'] == before['steps'] + T, after
+    assert after['last_chains'] == (2 if n >= 1 << 18 else 1) and after['packets'] == before['packets'] + T * after['last_chains']
+    assert after['available'], after['reason']
+    # (no synchronisation here: the call returns with its results complete -- the copies below are ordered behind nothing)
+    host_boards = b1.cpu()
+    b2, r2, d2 = run(lib, start, T, flags | NO_DIRECT, 11, stride, acts)
+    assert lib.direct_stats(DEV)['calls'] == after['calls']   # the second call went through the stream
+    torch.cuda.synchronize()
+    assert torch.equal(host_boards, b2.cpu())
+    assert torch.equal(r1, r2) and torch.equal(d1, d2)   # every row, and the padding beyond n untouched by both
+    if stride_kind == 'padded':
+        assert bool((r1[:, n:] == -7).all()) and bool((d1[:, n:] == 9).all())
+    if n <= 1 << 18 and not random_actions:   # ... and the oracle, step by step
+        ref = start.cpu().numpy().copy()
+        for t in range(T):
+            want = oracle.step_batch(ref, acts[t].cpu().numpy(), SEED, 500 + t, env_base=11, flags=flags)
+            ref = want['boards']
+            if stride:
+                assert np.array_equal(r1[t, :n].cpu().numpy(), want['reward']) and np.array_equal(d1[t, :n].cpu().numpy(), want['done']), t
+        assert np.array_equal(host_boards.numpy(), ref)
+    if after['last_gpu_ns']:
+        assert 0.5e3 * T < after['last_gpu_ns'] < 1e9   # a plausible device-side duration (0.5 us per step ... 1 s)
+
+
+@gpu
+def test_sequences_longer_than_the_argument_ring(lib, route):
+    """1300 steps = 6 segments of argument blocks through a ring of 4: blocks are rewritten while the sequence runs."""
+    n, T = 8192, 1300
+    start = midgame(lib, n)
+    flags = AUTO | RANDOM
+    b1, r1, d1 = run(lib, start, T, flags, 0, 0, None)
+    b2, r2, d2 = run(lib, start, T, flags | NO_DIRECT, 0, 0, None)
+    torch.cuda.synchronize()
+    assert torch.equal(b1, b2) and torch.equal(r1, r2) and torch.equal(d1, d2)
+    b3, _, d3 = run(lib, start, T, flags, 0, 0, None, with_reward=False)   # reward may be NULL
+    assert torch.equal(b3, b2) and torch.equal(d3, d2)
+    ref = oracle_rollout(start.cpu().numpy(), T, 500)
+    assert np.array_equal(b1.cpu().numpy(), ref)
+
+
+def oracle_rollout(boards, T, step0):
+    for t in range(T):
+        boards = oracle.step_batch(boards, None, SEED, step0 + t, env_base=0, flags=AUTO | RANDOM)['boards']
+    return boards
+
+
+@gpu
+def test_the_call_is_ordered_behind_the_stream_and_complete_on_return(lib, route):
+    """Work already on the caller's stream comes first (the queues know nothing of the stream: the call waits for it), and
+    everything after the call sees the results -- the host, this stream, another stream."""
+    n, T = 1 << 18, 10
+    rng = np.random.default_rng(3)
+    acts = [torch.from_numpy(rng.integers(0, 4, size=n).astype(np.uint8)).cuda() for _ in range(T)]
+    table = (ctypes.c_void_p * T)(*[a.data_ptr() for a in acts])
+    start = midgame(lib, n)
+    # reference: everything on the stream
+    ref = start.clone()
+    rr = torch.zeros((n,), dtype=torch.int32, device='cuda')
+    dd = torch.zeros((n,), dtype=torch.uint8, device='cuda')
+    for t in range(3):
+        lib.step(DEV, stream(), n, 0, p(ref), p(acts[t]), p(rr), p(dd), None, None, SEED, 40 + t, AUTO)
+    lib.step_sequence(DEV, stream(), n, 0, p(ref), table, p(rr), p(dd), None, None, 0, SEED, 43, T, AUTO | NO_DIRECT)
+    lib.step(DEV, stream(), n, 0, p(ref), p(acts[0]), p(rr), p(dd), None, None, SEED, 43 + T, AUTO)
+    torch.cuda.synchronize()
+    # the same with the sequence on the direct route, no synchronisation anywhere: three asynchronous launches (plus a large
+    # fill that keeps the stream busy), the sequence, one more launch
+    b = start.clone()
+    r = torch.zeros((n,), dtype=torch.int32, device='cuda')
+    d = torch.zeros((n,), dtype=torch.uint8, device='cuda')
+    ballast = torch.empty((1 << 28,), dtype=torch.uint8, device='cuda')
+    calls = lib.direct_stats(DEV)['calls']
+    ballast.fill_(1)
+    for t in range(3):
+        lib.step(DEV, stream(), n, 0, p(b), p(acts[t]), p(r), p(d), None, None, SEED, 40 + t, AUTO)
+    lib.step_sequence(DEV, stream(), n, 0, p(b), table, p(r), p(d), None, None, 0, SEED, 43, T, AUTO)
+    assert lib.direct_stats(DEV)['calls'] == calls + 1
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):   # another stream, no event between: the results are in memory already
+        seen_by_side = b.clone()
+    lib.step(DEV, stream(), n, 0, p(b), p(acts[0]), p(r), p(d), None, None, SEED, 43 + T, AUTO)
+    torch.cuda.synchronize()
+    assert torch.equal(b, ref) and torch.equal(r, rr) and torch.equal(d, dd)
+    lib.step(DEV, stream(), n, 0, p(seen_by_side), p(acts[0]), p(r), p(d), None, None, SEED, 43 + T, AUTO)
+    torch.cuda.synchronize()
+    assert torch.equal(seen_by_side, ref)
+
+
+@gpu
+def test_a_captured_stream_keeps_the_stream_route(lib, route):
+    """A graph capture records launches; the direct route cannot be recorded: the call declines and the capture gets K launches."""
+    n, T = 1 << 16, 8
+    start = midgame(lib, n)
+    b = start.clone()
+    r = torch.zeros((n,), dtype=torch.int32, device='cuda')
+    d = torch.zeros((n,), dtype=torch.uint8, device='cuda')
+    before = lib.direct_stats(DEV)
+    graph = torch.cuda.CUDAGraph()
+    capture_stream = torch.cuda.Stream()
+    with torch.cuda.stream(capture_stream):
+        graph.capture_begin()
+        lib.step_sequence(DEV, capture_stream.cuda_stream, n, 0, p(b), None, p(r), p(d), None, None, 0, SEED, 7, T, AUTO | RANDOM)
+        graph.capture_end()
+    after = lib.direct_stats(DEV)
+    assert after['calls'] == before['calls'] and after['declined'] == before['declined'] + 1
+    graph.replay()
+    torch.cuda.synchronize()
+    want, _, _ = run(lib, start, T, AUTO | RANDOM | NO_DIRECT, 0, 0, None, step0=7)
+    torch.cuda.synchronize()
+    assert torch.equal(b, want)
+
+
+@gpu
+def test_two_threads_share_the_route(lib, route):
+    """Calls on one device are serialised by the route: two threads stepping different batches both get their own results."""
+    import threading
+
+    n, T = 1 << 17, 30
+    starts = [midgame(lib, n, env_base=k * n) for k in range(2)]
+    want = [run(lib, s, T, AUTO | RANDOM | NO_DIRECT, k * n, 0, None) for k, s in enumerate(starts)]
+    torch.cuda.synchronize()
+    got = [None, None]
+    streams = [torch.cuda.Stream() for _ in range(2)]
+
+    def work(k):
+        with torch.cuda.stream(streams[k]):
+            for _ in range(3):
+                got[k] = run(lib, starts[k], T, AUTO | RANDOM, k * n, 0, None)
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    for k in range(2):
+        assert torch.equal(got[k][0], want[k][0]) and torch.equal(got[k][1], want[k][1]) and torch.equal(got[k][2], want[k][2])
+
+
+RERUN_SCRIPT = r'''
+import ctypes, sys
+import torch
+from simulate_2048_amd import capi
+lib = capi.library()
+n, T, SEED = (1 << 18) + 4096, 12, 77
+s = torch.cuda.current_stream().cuda_stream
+b = torch.empty((n, 16), dtype=torch.uint8, device='cuda'); d = torch.empty((n,), dtype=torch.uint8, device='cuda')
+lib.reset(0, s, n, 0, b.data_ptr(), d.data_ptr(), SEED, 0)
+lib.rollout(0, s, n, 0, b.data_ptr(), SEED, 0, 64, None, None, None, 3)
+torch.cuda.synchronize()
+out = []
+for flags in (3, 3 | capi.FLAG_NO_DIRECT):
+    bb = b.clone(); r = torch.zeros((T, n), dtype=torch.int32, device='cuda'); dd = torch.zeros((T, n), dtype=torch.uint8, device='cuda')
+    lib.step_sequence(0, s, n, 0, bb.data_ptr(), None, r.data_ptr(), dd.data_ptr(), None, None, n, SEED, 100, T, flags)
+    torch.cuda.synchronize()
+    out.append((bb, r, dd))
+info = lib.direct_stats(0)
+same = all(torch.equal(x, y) for x, y in zip(*out))
+print('RESULT', int(same), info['calls'], info['reruns'], int(info['available']), info['reason'])
+'''
+
+
+@gpu
+def test_a_sequence_whose_workgroups_change_xcds_is_rerun_on_the_stream(lib, route):
+    """The contract the route checks instead of assuming: a launch in the middle of the sequence claims (test hook) to run on
+    other XCDs than the first launch recorded -> the call restores the snapshot, runs the sequence as stream launches, and the
+    caller sees the same bytes; the route stays available."""
+    import os
+    import subprocess
+    import sys
+
+    env = dict(os.environ, ENV2048_DIRECT_TEST_MOVE_AT='5', PYTHONPATH=str(capi.LIB_PATH.parent.parent.parent))
+    proc = subprocess.run([sys.executable, '-c', RERUN_SCRIPT], capture_output=True, text=True, env=env, timeout=300)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    line = [x for x in proc.stdout.splitlines() if x.startswith('RESULT')][0].split(' ', 5)
+    assert line[1] == '1', 'results differ after a rerun'
+    assert line[2] == '1' and line[3] == '1' and line[4] == '1', line   # one direct call, one rerun, route still available
+    assert 'last rerun' in line[5]
