@@ -86,6 +86,10 @@ def parse_args(argv=None):
                     'thread + stream per device) instead of one rank per GPU; no torch.distributed at all')
     ap.add_argument('--shards-on-device-0', action='store_true', help='with --single-process: put all --gpus shards on device 0 (REHEARSAL of '
                     'the fan-out on a box with fewer GPUs; not a scaling measurement)')
+    ap.add_argument('--no-direct', action='store_true', help='A/B aid: ENV2048_FLAG_NO_DIRECT on the timed env2048_step_sequence calls (the '
+                    'stream route: HIP launches instead of the library\'s own queues)')
+    ap.add_argument('--stream-route-child', action='store_true', help='(internal) print the stream route\'s numbers of the other_configs legs; '
+                    'bench.py starts itself this way with ENV2048_DIRECT=0')
     ap.add_argument('--single-chain', action='store_true', help='A/B aid: ENV2048_FLAG_SINGLE_CHAIN on the timed env2048_step_sequence calls '
                     '(never split the batch into two half-batch chains)')
     ap.add_argument('--dist-backend', default='nccl', help="'nccl' (= RCCL, one GPU per rank); 'gloo' = REHEARSAL of the "
@@ -277,6 +281,11 @@ def load_kernel_stats(leg: str):
     except Exception:
         return None
     ks['stale'] = table.get('kernel_source_sha') != kernel_source_sha()
+    if leg == 'direct':
+        ks['note'] = ('direct route: two half-batch chains of env2048_step_resident_* launches on the library\'s own queues; the profiler '
+                      'intercepts those queues like any other, its average is the duration of ONE half-batch kernel (two are in flight '
+                      'in the timed run, so the step period is about one kernel duration)')
+        return ks
     ks['note'] = ('one chain: the profiler isolates the whole-batch kernels; their average is the launch duration itself and is what '
                   'roofline.avg_launch_us of a one-chain run (K-step event time / K, which also holds the gaps between launches) has to '
                   'agree with' if leg != 'resident' else
@@ -303,7 +312,7 @@ def valu_ceiling(waves_per_simd: int = 4):
         return VALU_PEAK_GINSTR_FALLBACK, 'fallback constant of bench.py (profiles/valu_ceiling.json not readable)', None
 
 
-def build_roofline(args, lib, n: int, flags: int, launch_s: float, obs_bytes: int) -> dict:
+def build_roofline(args, lib, n: int, flags: int, launch_s: float, obs_bytes: int, route=None) -> dict:
     """The roofline object of a run whose dominant kernel is one env2048_step launch over n boards taking launch_s:
     SURVEY 8(d)'s definition at the top level (algorithmic bytes / launch time against the HBM peak), the VALU-issue analysis
     of the cache-resident regime under `valu`."""
@@ -314,17 +323,32 @@ def build_roofline(args, lib, n: int, flags: int, launch_s: float, obs_bytes: in
     # the library's own launch policy (env2048_step_sequence_plan), not a copy of its size rules: the timed region is one
     # env2048_step_sequence call, which may run the batch as two half-batch chains on two streams
     plan = lib.step_sequence_plan(n, args.steps, flags)
-    leg = 'resident' if plan['chains'] == 2 else 'resident_one_chain'  # counters and kernel stats of the SHAPE that is timed
+    direct = bool(route and route.get('direct'))
+    if direct:  # the library's own queues: two half-batch chains of resident launches (csrc/direct_dispatch.hpp)
+        plan = dict(plan, route='direct', chains=route['chains'], write_through=False,
+                    boards_per_lane=lib.step_plan(n if route['chains'] == 1 else n - (n // 2) // 2048 * 2048, 0)['boards_per_lane'])
+        if route.get('device_s_per_step'):
+            event_s, launch_s = launch_s, route['device_s_per_step']
+    else:
+        plan = dict(plan, route='stream')
+    leg = 'direct' if direct else 'resident' if plan['chains'] == 2 else 'resident_one_chain'  # counters / kernel stats of the SHAPE that is timed
+    algo_gbs = bytes_per_launch / launch_s / 1e9
     prof = None if args.extras else load_step_profile(n, leg)
     tiling = plan['boards_per_lane']
-    kernel = f'step_kernel<false, false, {tiling}>' if not args.extras else f'step_kernel<true, false, {tiling}>'
+    kernel = (f'env2048_step_resident_{"large" if tiling == 4 else "small"}' if direct else
+              f'step_kernel<false, false, {tiling}>' if not args.extras else f'step_kernel<true, false, {tiling}>')
     roofline = {
         'bound': 'hbm',
         'achieved': algo_gbs,
         'peak': HBM_PEAK_GBS,
         'unit': 'GB/s',
         'frac': algo_gbs / HBM_PEAK_GBS,
-        'regime': (f'cache-resident: the {working_set / 2**20:.0f} MiB working set of back-to-back steps lives in the 256 MiB Infinity Cache, so this '
+        'regime': (f'L2-resident: between the first and the last launch of a sequence the {n * 16 / 2**20:.0f} MiB of boards never leave the eight '
+                   f'4 MiB XCD L2s (no cache fence on the packets between; `traffic` counts what still crosses the fabric per step: the action '
+                   f'row in, the reward / done rows out), so this fraction (algorithmic bytes / device-side step period / 8 TB/s, SURVEY 8(d)) '
+                   f'is an EQUIVALENT, not bytes that crossed the HBM pins; the true HBM fraction of the step kernel is roofline.hbm_cold'
+                   if direct else
+                   f'cache-resident: the {working_set / 2**20:.0f} MiB working set of back-to-back steps lives in the 256 MiB Infinity Cache, so this '
                    f'fraction (algorithmic bytes / launch time / 8 TB/s, SURVEY 8(d)) is an EQUIVALENT, not bytes that crossed the HBM pins; the '
                    f'true HBM fraction of this kernel is roofline.hbm_cold' if resident else
                    'HBM: the working set exceeds the Infinity Cache'),
@@ -333,9 +357,13 @@ def build_roofline(args, lib, n: int, flags: int, launch_s: float, obs_bytes: in
         'launches_per_step': plan['chains'],
         'boards_per_kernel_launch': n if plan['chains'] == 1 else n - (n // 2) // 2048 * 2048,
         'avg_launch_us': launch_s * 1e6,
-        'avg_launch_us_means': 'HIP-event time of the K-step region / K = the period of one step over the whole batch' +
-                               ('' if plan['chains'] == 1 else '; the step is two half-batch launches on two streams that overlap each '
-                                'other, each lasting about one period (the rocprofv3 average of the half-batch kernel)'),
+        'avg_launch_us_means': ('device-side period of one step over the whole batch: (end of the last packet - start of the first packet) / K from the '
+                                'dispatch timestamps of the library\'s queues (env2048_direct_stats.last_gpu_ns; HIP events cannot be recorded on those '
+                                'queues -- the event time of the region around the synchronous call is timing.event_us_per_step); the step is two '
+                                'half-batch launches on two queues that overlap each other' if direct and route.get('device_s_per_step') else
+                                'HIP-event time of the K-step region / K = the period of one step over the whole batch' +
+                                ('' if plan['chains'] == 1 else '; the step is two half-batch launches on two streams that overlap each '
+                                 'other, each lasting about one period (the rocprofv3 average of the half-batch kernel)')),
         'algorithmic_bytes_per_launch': bytes_per_launch,
         'traffic': None if prof is None else prof.get('fabric_bytes_per_launch'),  # (the table is scaled to one step over the whole batch)
         'traffic_kind': 'fabric bytes per step over the whole batch (2*FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes of the timed '
@@ -343,6 +371,9 @@ def build_roofline(args, lib, n: int, flags: int, launch_s: float, obs_bytes: in
         'traffic_source': None if prof is None else dict(source=prof.get('source'), leg=leg, stale=prof['stale']),
         'rocprof_kernel_stats': load_kernel_stats(leg),
     }
+    if direct:
+        roofline['route'] = {'direct': True, 'reruns': route.get('reruns'), 'state': route.get('state'),
+                             'event_us_per_step_around_the_call': event_s * 1e6 if route.get('device_s_per_step') else None}
     if resident and prof is not None and prof.get('valu_insts_per_launch'):
         valu_per_step = prof['valu_insts_per_launch']  # (scaled to one step over the whole batch by tools/summarize_profiles.py)
         ginstr = valu_per_step / launch_s / 1e9
@@ -438,7 +469,7 @@ def reduce_timings(comm: RankComm, walls, events, K: int) -> dict:
 
 
 def assemble_result(args, world: int, n: int, timings: dict, blocks: int, enqueue_us: float, roofline: dict, *, rehearsal: bool = False,
-                    other=None, cpu=None) -> dict:
+                    other=None, cpu=None, route=None) -> dict:
     """The one JSON object rank 0 prints (the driver's contract): `value` = boards x K x ranks / the median block's wall time
     (per block: the slowest rank)."""
     K, W = args.steps, args.warmup
@@ -460,8 +491,11 @@ def assemble_result(args, world: int, n: int, timings: dict, blocks: int, enqueu
             'workload': workload_text(n),
             'boards_per_gpu': n,
             'global_boards': n * world,
-            'launch_mode': 'env2048_step_sequence: the K steps enqueued from C by one call (two half-batch chains of K launches each when the '
-                           'library plans it so: roofline.launch_plan)',
+            'launch_mode': ('env2048_step_sequence, direct route: one call writes the K kernel-dispatch packets of each of two half-batch chains into '
+                            'the library\'s own user-mode queues (no HIP launch, boards resident in the XCD L2s between the first and the last '
+                            'packet) and returns when they have completed' if route and route.get('direct') else
+                            'env2048_step_sequence: the K steps enqueued from C by one call (two half-batch chains of K launches each when the '
+                            'library plans it so: roofline.launch_plan)'),
             'sharding': 'contiguous env-index slices, one process per GPU, no collective on the hot path',
             'outputs': 'board,reward,done' + (f',legal,obs({args.obs_dtype})' if args.extras else ''),
         },
@@ -551,7 +585,7 @@ def run_rank(args) -> None:
         stream = torch.cuda.current_stream(device)
         h = stream.cuda_stream
         p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
-        flags = env.flags | (capi.FLAG_SINGLE_CHAIN if args.single_chain else 0)
+        flags = env.flags | (capi.FLAG_SINGLE_CHAIN if args.single_chain else 0) | (capi.FLAG_NO_DIRECT if args.no_direct else 0)
 
         tables = {}
 
@@ -581,6 +615,7 @@ def run_rank(args) -> None:
         for phase in range(8):
             action_table(K, phase)
         enqueue_times = []
+        route_calls, device_times = [lib.direct_stats(device_index)['calls']], []
 
         def timed_block(count: int, with_events: bool = True):
             """One timed region: barrier + synchronize | K steps | synchronize.  Blocks alternate between two instruments: the
@@ -602,6 +637,10 @@ def run_rank(args) -> None:
             torch.cuda.synchronize()
             wall = time.perf_counter() - t0
             enqueue_times.append(enqueued / max(count, 1))
+            if with_events:  # (outside the timed region) the route the call took and, on the direct route, its duration on the device
+                info = lib.direct_stats(device_index)
+                route_calls.append(info['calls'])
+                device_times.append(info['last_gpu_ns'] * 1e-9 if len(route_calls) > 1 and route_calls[-1] > route_calls[-2] else 0.0)
             return wall, (ev0.elapsed_time(ev1) * 1e-3 if with_events else None)
 
         if args.only_cold:
@@ -621,6 +660,11 @@ def run_rank(args) -> None:
         barrier()
         timings = reduce_timings(comm, walls, events, K)
         launch_s = timings['launch_s']
+        # the route the timed calls took (env2048_direct_stats): on the direct route the launch duration is the DEVICE-side one
+        info = lib.direct_stats(device_index)
+        direct_blocks = [d for d in device_times[-blocks:] if d > 0]
+        route = {'direct': len(direct_blocks) == blocks and info['calls'] > route_calls[0], 'chains': info['last_chains'], 'reruns': info['reruns'],
+                 'state': info['reason'], 'device_s_per_step': (statistics.median(direct_blocks) / K) if direct_blocks else None}
 
         # ---- HBM-cold leg: same launch size, round-robin over disjoint buffer sets that exceed the Infinity Cache -------
         cold = None
@@ -633,12 +677,12 @@ def run_rank(args) -> None:
             other = other_configs(torch, lib, device, device_index, h)
 
         if rank == 0:
-            roofline = build_roofline(args, lib, n, flags, launch_s, obs_bytes)
+            roofline = build_roofline(args, lib, n, flags, launch_s, obs_bytes, route=route)
             if cold is not None:
                 roofline['hbm_cold'] = cold
             cpu = cpu_baseline(boards_midgame, args.cpu_seconds) if boards_midgame is not None else None
             emit(json.dumps(assemble_result(args, world, n, timings, blocks, statistics.median(enqueue_times) * 1e6, roofline,
-                                            rehearsal=rehearsal, other=other, cpu=cpu)))
+                                            rehearsal=rehearsal, other=other, cpu=cpu, route=route)))
 
     try:
         body()
@@ -788,6 +832,7 @@ def other_configs(torch, lib, device, device_index, h) -> dict:
     from simulate_2048_amd.batch import BatchedEnv2048
 
     out = {}
+    stream_side = stream_route_numbers() if lib.direct_stats(device_index)['available'] else {}
     # configs[0]: one board, 1000 random-action steps through the TwentyFortyEight env API (reset on done) -- the mirror runs
     # every step as one kernel launch on pinned host operands + one polled completion word
     import numpy as np
@@ -823,6 +868,7 @@ def other_configs(torch, lib, device, device_index, h) -> dict:
     table = (ctypes.c_void_p * count)(*[pool[t & 7].data_ptr() for t in range(count)])
     stream = torch.cuda.current_stream(device)
     times = []
+    calls_before = lib.direct_stats(device_index)['calls']
     for rep in range(4):
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
@@ -834,6 +880,7 @@ def other_configs(torch, lib, device, device_index, h) -> dict:
         torch.cuda.synchronize()
         times.append((time.perf_counter() - t0, ev0.elapsed_time(ev1) * 1e-3))
     wall, ev = sorted(times)[len(times) // 2]
+    route1 = 'direct' if lib.direct_stats(device_index)['calls'] > calls_before else 'stream'
     # the same per-step launches as a REPLAYABLE hipGraph: the step index lives in device memory (step_counter), so every
     # replay continues the random stream; the host then costs one graph launch per 200 steps instead of 200 kernel launches
     genv = BatchedEnv2048(n1, SEED, device=device, auto_reset=True, device_step_counter=True)
@@ -887,8 +934,12 @@ def other_configs(torch, lib, device, device_index, h) -> dict:
     out['configs[1]'] = {
         'workload': '65 536 parallel boards, uint8 log2-packed, uniform random host actions, auto-reset, 1 GPU',
         'value': n1 * count / wall, 'unit': 'board-steps/s', 'us_per_step_wall': wall / count * 1e6, 'us_per_step_event': ev / count * 1e6,
+        'route': route1 + (': one env2048_step_sequence call of 2000 steps on the library\'s own queue (one chain of resident launches, no cache '
+                           'fence between them)' if route1 == 'direct' else ''),
+        'as_stream_launches': stream_side.get('configs[1]'),
         'bound': 'launch rate: 1 MiB of boards is cache-resident and a launch (one-board-per-lane tiling, 128 workgroups) is shorter than '
-                 'the host + command-processor cost of a dependent launch (see timing.host_enqueue_us_per_launch)',
+                 'the command-processor cost of a dependent launch (and, on the stream route, than the host cost of enqueuing it: '
+                 'timing.host_enqueue_us_per_launch)',
         'as_replayed_hipgraph': {'value': n1 * captured * 10 / gwall, 'unit': 'board-steps/s', 'us_per_step_wall': gwall / (captured * 10) * 1e6,
                                  'us_per_step_event': gev / (captured * 10) * 1e6, 'steps_replayed_check': replayed == captured * 41,
                                  'note': f'{captured} step launches + one counter-advance node captured once (device-side step counter), graph replayed: '
@@ -909,19 +960,24 @@ def other_configs(torch, lib, device, device_index, h) -> dict:
     flags = capi.FLAG_AUTO_RESET | capi.FLAG_RANDOM_ACTIONS
     reward_rows = torch.zeros((T, n4), dtype=torch.int32, device=device)
     done_rows = torch.zeros((T, n4), dtype=torch.uint8, device=device)
-    step_times = []
-    for rep in range(3):  # (the first repetition also pays for the library's one-time second-chain stream / thread, if this is
-        a.boards.copy_(start)  # the first long sequence of the process; the median of three does not)
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        ev0.record(stream)
-        lib.step_sequence(device_index, h, n4, 0, a.boards.data_ptr(), None, reward_rows.data_ptr(), done_rows.data_ptr(), None, None,
-                          n4, SEED, 0, T, flags)
-        ev1.record(stream)
-        torch.cuda.synchronize()
-        step_times.append((time.perf_counter() - t0, ev0.elapsed_time(ev1) * 1e-3))
-    wall_steps, ev_steps = sorted(step_times)[1]
+    by_route = {}
+    calls_before = lib.direct_stats(device_index)['calls']
+    for route_name, extra in (('default', 0),):
+        step_times = []
+        for rep in range(3):  # (the first repetition also pays for the library's one-time second-chain stream / thread, if this is
+            a.boards.copy_(start)  # the first long sequence of the process; the median of three does not)
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ev0.record(stream)
+            lib.step_sequence(device_index, h, n4, 0, a.boards.data_ptr(), None, reward_rows.data_ptr(), done_rows.data_ptr(), None, None,
+                              n4, SEED, 0, T, flags | extra)
+            ev1.record(stream)
+            torch.cuda.synchronize()
+            step_times.append((time.perf_counter() - t0, ev0.elapsed_time(ev1) * 1e-3))
+        by_route[route_name] = sorted(step_times)[1]
+    wall_steps, ev_steps = by_route['default']
+    route4 = 'direct' if lib.direct_stats(device_index)['calls'] > calls_before else 'stream'
     sum_steps = int(reward_rows.sum(dtype=torch.int64))
     eps_steps = int(done_rows.sum(dtype=torch.int64))
     invalid = float(((reward_rows == 0) & (done_rows == 0)).float().mean())  # upper bound on the invalid-move share (valid moves can score 0)
@@ -967,7 +1023,9 @@ def other_configs(torch, lib, device, device_index, h) -> dict:
     out['configs[4]'] = {
         'workload': '1 048 576 boards x 512-step rollout, Philox tile spawn, on-device uniform random actions, auto-reset on terminal',
         'as_512_step_launches': {'value': n4 * T / wall_steps, 'unit': 'board-steps/s', 'ms_total_wall': wall_steps * 1e3,
-                                 'us_per_step_event': ev_steps / T * 1e6, 'records': 'reward and done rows [512, 2^20] written in HBM'},
+                                 'us_per_step_event': ev_steps / T * 1e6, 'records': 'reward and done rows [512, 2^20] written in HBM',
+                                 'route': route4 + (' (the library\'s own queues: 2 x 512 resident launches)' if route4 == 'direct' else ''),
+                                 'on_the_stream_route': stream_side.get('configs[4]')},
         'as_one_rollout_kernel': {'value': n4 * T / wall_roll, 'unit': 'board-steps/s', 'ms_total_wall': wall_roll * 1e3,
                                   'ms_total_event': ev_roll * 1e3, 'bound': 'VALU issue (boards stay in registers: 44 B per env per 512 steps)'},
         'as_one_replay_kernel_host_actions': {'value': n4 * T / ev_replay, 'unit': 'board-steps/s', 'ms_total_event': ev_replay * 1e3,
@@ -979,7 +1037,7 @@ def other_configs(torch, lib, device, device_index, h) -> dict:
                        'zero_reward_nonterminal_fraction': invalid},
     }
     del a, b
-    out['configs[2]_long_sequence'] = long_sequence_leg(torch, lib, device, device_index, h)
+    out['configs[2]_long_sequence'] = long_sequence_leg(torch, lib, device, device_index, h, stream_side=stream_side)
     out['configs[2]_with_legal_obs'] = legal_obs_leg(torch, lib, device, device_index, h)
     return out
 
@@ -1015,29 +1073,53 @@ def _midgame_env(torch, device, n, **kw):
     return env, pool
 
 
-def long_sequence_leg(torch, lib, device, device_index, h, n: int = 1 << 20, K: int = 200) -> dict:
-    """The headline workload (BASELINE configs[2]) as ONE env2048_step_sequence call of K = 200 steps -- long enough for the
-    library to run the batch as two half-batch chains (from K = 32), which the driver's --steps 20 headline never does -- next
-    to the same call with ENV2048_FLAG_SINGLE_CHAIN, and what the library's helper thread cost over a K = 2000 call."""
+def long_sequence_leg(torch, lib, device, device_index, h, n: int = 1 << 20, K: int = 200, stream_side=None, stream_only: bool = False) -> dict:
+    """The headline workload (BASELINE configs[2]) as ONE env2048_step_sequence call of K = 200 steps on every route the library
+    has: the default (the direct route where it is available), the stream route as two half-batch chains (ENV2048_FLAG_NO_DIRECT)
+    and as one chain (+ ENV2048_FLAG_SINGLE_CHAIN); and what the stream route's helper thread cost over a K = 2000 call."""
     from simulate_2048_amd import capi
 
     env, pool = _midgame_env(torch, device, n)
     stream = torch.cuda.current_stream(device)
     table = (ctypes.c_void_p * K)(*[pool[t & 7].data_ptr() for t in range(K)])
     out = {'workload': workload_text(n) + f'; one env2048_step_sequence call of K = {K} steps', 'K': K}
-    for name, extra in (('two_chains_default', 0), ('single_chain', capi.FLAG_SINGLE_CHAIN)):
+    direct_here = lib.direct_stats(device_index)['available']
+    # With the direct route up, the library's two queues sit on two of the four hardware pipes of the compute engine and two HIP
+    # streams of this process may then share one (a 2-chain stream sequence measured 23.6 instead of 7 us per step next to
+    # them): the stream route's own numbers therefore come from a CHILD process that runs with ENV2048_DIRECT=0
+    # (stream_route_numbers), not from this one.
+    legs = [('default', 0)] if direct_here and not stream_only else []
+    if stream_only or not direct_here:
+        legs += [('two_chains_default', capi.FLAG_NO_DIRECT), ('single_chain', capi.FLAG_NO_DIRECT | capi.FLAG_SINGLE_CHAIN)]
+    for k, (name, extra) in enumerate(legs):
         flags = env.flags | extra
-        wall1, ev1 = _timed_sequence(torch, lib, stream, device_index, h, env, table, K, flags, 1000 + 100 * K * (1 if extra else 0))
-        wall, ev = _timed_sequence(torch, lib, stream, device_index, h, env, table, K, flags, 50_000 + 100 * K * (1 if extra else 0), calls=5)
+        calls_before = lib.direct_stats(device_index)['calls']
+        wall1, ev1 = _timed_sequence(torch, lib, stream, device_index, h, env, table, K, flags, 1000 + 100 * K * k)
+        wall, ev = _timed_sequence(torch, lib, stream, device_index, h, env, table, K, flags, 50_000 + 100 * K * k, calls=5)
+        info = lib.direct_stats(device_index)
+        took_direct = info['calls'] > calls_before
         gbs = ALGO_BYTES_PER_STEP * n / (ev / K) / 1e9
-        out[name] = {'launch_plan': lib.step_sequence_plan(n, K, flags), 'event_us_per_step': ev / K * 1e6, 'wall_us_per_step': wall / K * 1e6,
+        out[name] = {'route': 'direct (the library\'s own queues, boards L2-resident between the first and the last launch of a call)'
+                              if took_direct else 'stream (HIP launches)',
+                     'launch_plan': dict(lib.step_sequence_plan(n, K, flags), **({'chains': info['last_chains'], 'write_through': False} if took_direct else {})),
+                     'device_us_per_step_last_call': info['last_gpu_ns'] / K * 1e-3 if took_direct and info['last_gpu_ns'] else None,
+                     'event_us_per_step': ev / K * 1e6, 'wall_us_per_step': wall / K * 1e6,
                      'value': n * K / wall, 'unit': 'board-steps/s', 'timed_region': f'5 consecutive calls of K = {K} steps between two synchronisations',
                      'one_call_between_synchronisations': {'event_us_per_step': ev1 / K * 1e6, 'wall_us_per_step': wall1 / K * 1e6,
                                                            'note': 'a single 1.5 ms call from an idle GPU: fork / join of the second chain '
                                                                    'and the clock ramp are not amortised'},
                      'roofline': {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
                                   'regime': 'cache-resident equivalent (algorithmic bytes / event time per step; see roofline.regime)'}}
-    out['two_chains_speedup'] = out['single_chain']['event_us_per_step'] / out['two_chains_default']['event_us_per_step']
+    if stream_side and 'configs[2]_long_sequence' in stream_side:  # the stream route's legs, measured by the child process
+        for key in ('two_chains_default', 'single_chain', 'two_chains_speedup', 'helper_thread'):
+            out[key] = stream_side['configs[2]_long_sequence'].get(key)
+        out['stream_route_measured_in'] = stream_side.get('where')
+    if out.get('single_chain') and out.get('two_chains_default'):
+        out['two_chains_speedup'] = out['single_chain']['event_us_per_step'] / out['two_chains_default']['event_us_per_step']
+    if out.get('default') and out.get('two_chains_default'):
+        out['direct_speedup_over_two_stream_chains'] = out['two_chains_default']['wall_us_per_step'] / out['default']['wall_us_per_step']
+    if 'two_chains_default' not in [name for name, _ in legs]:
+        return out
     # the helper thread that enqueues the second chain: CPU time it consumed over a K = 2000 call (its poll window included)
     K2 = 2000
     table2 = (ctypes.c_void_p * K2)(*[pool[t & 7].data_ptr() for t in range(K2)])
@@ -1045,7 +1127,7 @@ def long_sequence_leg(torch, lib, device, device_index, h, n: int = 1 << 20, K: 
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     lib.step_sequence(device_index, h, n, env.env_base, env.boards.data_ptr(), table2, env.reward.data_ptr(), env.done.data_ptr(), None, None, 0,
-                      SEED, 50_000, K2, env.flags)
+                      SEED, 50_000, K2, env.flags | capi.FLAG_NO_DIRECT)
     enqueued = time.perf_counter() - t0
     torch.cuda.synchronize()
     wall2 = time.perf_counter() - t0
@@ -1084,6 +1166,99 @@ def legal_obs_leg(torch, lib, device, device_index, h, n: int = 1 << 20, K: int 
                                             f'Infinity Cache (algorithmic bytes / event time per step)'}}
         del env, pool
     return out
+
+
+def stream_route_numbers(timeout: float = 420.0) -> dict:
+    """The stream route's numbers for the legs of other_configs, measured by a CHILD process that runs with ENV2048_DIRECT=0 (no
+    queues of the library's own next to the HIP streams) while this process idles.  {} plus a note when the child fails."""
+    env = dict(os.environ, ENV2048_DIRECT='0')
+    for key in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(key, None)
+    try:
+        proc = subprocess.run([sys.executable, str(Path(__file__).resolve()), '--stream-route-child'], env=env, capture_output=True, text=True,
+                              timeout=timeout)
+        lines = [x for x in proc.stdout.splitlines() if x.startswith('{')]
+        if proc.returncode != 0 or not lines:
+            return {'error': f'the child process failed (rc {proc.returncode}): {proc.stderr[-300:]}'}
+        return json.loads(lines[-1])
+    except Exception as exc:  # (a missing number must not cost the run its headline)
+        return {'error': f'{type(exc).__name__}: {exc}'}
+
+
+def stream_route_child() -> None:
+    """`bench.py --stream-route-child` (started by stream_route_numbers with ENV2048_DIRECT=0): the legs of other_configs on the
+    stream route -- configs[1] as 2000 launches, configs[4] as 2 x 512 launches, configs[2] as one K = 200 sequence (two chains and
+    one) with the helper thread's cost -- as one JSON line."""
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+    import torch
+
+    from simulate_2048_amd import capi
+    from simulate_2048_amd.batch import BatchedEnv2048
+
+    device = torch.device('cuda', 0)
+    torch.cuda.set_device(device)
+    lib = capi.library()
+    stream = torch.cuda.current_stream(device)
+    h = stream.cuda_stream
+    out = {'where': 'a child process of bench.py with ENV2048_DIRECT=0 (direct route: ' + lib.direct_stats(0)['reason'] + ')'}
+
+    def timed(call, reps=4):
+        times = []
+        for rep in range(reps):
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ev0.record(stream)
+            call(rep)
+            ev1.record(stream)
+            torch.cuda.synchronize()
+            times.append((time.perf_counter() - t0, ev0.elapsed_time(ev1) * 1e-3))
+        return sorted(times)[len(times) // 2]
+
+    n1, count = 1 << 16, 2000
+    env, pool = _midgame_env(torch, device, n1)
+    table = (ctypes.c_void_p * count)(*[pool[t & 7].data_ptr() for t in range(count)])
+    wall, ev = timed(lambda rep: lib.step_sequence(0, h, n1, 0, env.boards.data_ptr(), table, env.reward.data_ptr(), env.done.data_ptr(), None, None,
+                                                   0, SEED, 64 + rep * count, count, env.flags))
+    out['configs[1]'] = {'value': n1 * count / wall, 'unit': 'board-steps/s', 'us_per_step_wall': wall / count * 1e6, 'us_per_step_event': ev / count * 1e6,
+                         'note': 'the same call in a process without the direct route: 2000 HIP launches'}
+    del env, pool
+    n4, T = 1 << 20, 512
+    a = BatchedEnv2048(n4, SEED, device=device, auto_reset=True)
+    a.reset()
+    start = a.boards.clone()
+    reward_rows = torch.zeros((T, n4), dtype=torch.int32, device=device)
+    done_rows = torch.zeros((T, n4), dtype=torch.uint8, device=device)
+
+    def rows_call(rep):
+        lib.step_sequence(0, h, n4, 0, a.boards.data_ptr(), None, reward_rows.data_ptr(), done_rows.data_ptr(), None, None, n4, SEED, 0, T,
+                          capi.FLAG_AUTO_RESET | capi.FLAG_RANDOM_ACTIONS)
+
+    def rows_timed(rep):
+        a.boards.copy_(start)
+        torch.cuda.synchronize()
+        rows_call(rep)
+
+    rows_call(0)  # (pays for the second chain's stream / helper thread)
+    times = []
+    for rep in range(3):
+        a.boards.copy_(start)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        rows_call(rep)
+        ev1.record(stream)
+        torch.cuda.synchronize()
+        times.append((time.perf_counter() - t0, ev0.elapsed_time(ev1) * 1e-3))
+    wall, ev = sorted(times)[1]
+    out['configs[4]'] = {'value': n4 * T / wall, 'unit': 'board-steps/s', 'ms_total_wall': wall * 1e3, 'us_per_step_event': ev / T * 1e6,
+                         'note': 'the same call in a process without the direct route: 2 x 512 HIP launches (two streams, helper thread)'}
+    del a, start, reward_rows, done_rows
+    out['configs[2]_long_sequence'] = long_sequence_leg(torch, lib, device, 0, h, stream_only=True)
+    os.write(result_fd, (json.dumps(out) + '\n').encode())
 
 
 def assemble_single_process_result(args, walls, per_device_ms, roofline: dict) -> dict:
@@ -1168,6 +1343,9 @@ def run_single_process(args) -> None:
 
 def main():
     args = parse_args()
+    if args.stream_route_child:
+        stream_route_child()
+        return
     if args.single_process:
         run_single_process(args)
         return

@@ -57,6 +57,12 @@ namespace direct {
 constexpr int NOT_TAKEN = 1;  // step_sequence(): nothing was enqueued, this call is not for the direct route (the caller takes the HIP route)
 constexpr int RERUN = 2;      // step_sequence(): the sequence ran, a workgroup changed XCDs, the boards are back at their state before the call
 constexpr int CHAINS = 2;
+// Hardware queues are dealt to the four pipes of the compute engine in the order they are created, and two queues on ONE pipe do
+// not run side by side (two chains on queues created four apart: 14-18 us per step instead of 5.4, profiles/r05_j_*).  The
+// library therefore takes a whole round of four -- it uses the first two -- so that the HIP runtime's own queues, created before
+// or after, keep the pipes they would have had without it (with only two, a process's third HIP stream landed on the pipe of its
+// first: a 2-chain stream sequence next to the library's queues took 23.6 us per step).
+constexpr int QUEUES_CREATED = 4;
 constexpr uint32_t QUEUE_PACKETS = 1024;
 constexpr uint32_t SEGMENT_STEPS = 256;               // argument blocks are written (and flushed) a segment at a time
 constexpr uint32_t RING_SEGMENTS = 4;                 // ... into a ring of this many segments per chain
@@ -71,13 +77,12 @@ struct ResidentArgs {
     uint64_t boards, actions, n, env_base;
     uint32_t flags, seed_lo, seed_hi, step_lo, step_hi, pad0;
     uint64_t reward, done;
-    uint32_t mode, pad1;  // RESIDENT_* bits of step_kernels.hip
+    uint32_t mode, pad1;  // RESIDENT_PRETEND_MOVED of step_kernels.hip (test hook), else 0
     uint64_t owner, placement_error, snapshot;
 };
 static_assert(sizeof(ResidentArgs) == 104 && offsetof(ResidentArgs, reward) == 56 && offsetof(ResidentArgs, mode) == 72 &&
                   offsetof(ResidentArgs, owner) == 80 && offsetof(ResidentArgs, placement_error) == 88 && offsetof(ResidentArgs, snapshot) == 96,
               "argument layout of env2048_step_resident_* (step_kernels.hip)");
-constexpr uint32_t MODE_ESTABLISH = 1u;  // first launch of a chain: record the XCD of every workgroup, snapshot the boards
 constexpr uint32_t MODE_PRETEND_MOVED = 2u;  // (test hook) the workgroups of this launch claim to run on another XCD
 
 struct KernelRef {
@@ -98,8 +103,8 @@ struct Device {
     std::mutex call_mutex;  // one direct sequence at a time per device
     hsa_agent_t gpu{}, cpu{};
     hsa_amd_memory_pool_t local_pool{}, host_pool{};
-    hsa_queue_t *queue[CHAINS] = {};
-    KernelRef resident[2][2];  // [small tiling][random actions]
+    hsa_queue_t *queue[QUEUES_CREATED] = {};  // [0, CHAINS) carry the chains, the rest only hold their pipes
+    KernelRef resident[2][2][2];  // [small tiling][random actions][first launch of a chain]
     hsa_executable_t executable{};
     hsa_code_object_reader_t reader{};
     uint8_t *ring[CHAINS] = {};                        // argument blocks: device memory, host-visible through the BAR
@@ -299,18 +304,23 @@ inline Device *create(int device)
     if (st == HSA_STATUS_SUCCESS) st = hsa_executable_load_agent_code_object(d->executable, d->gpu, d->reader, nullptr, nullptr);
     if (st == HSA_STATUS_SUCCESS) st = hsa_executable_freeze(d->executable, nullptr);
     if (st != HSA_STATUS_SUCCESS) return set_reason(d, "loading the code object", st), d;
-    const char *names[2][2] = {{"env2048_step_resident_large.kd", "env2048_step_resident_large_random.kd"},
-                               {"env2048_step_resident_small.kd", "env2048_step_resident_small_random.kd"}};
     for (int s = 0; s < 2; ++s)
         for (int r = 0; r < 2; ++r)
-            if (!lookup(d, names[s][r], &d->resident[s][r]) || d->resident[s][r].kernarg != sizeof(ResidentArgs) || d->resident[s][r].priv != 0) {
-                snprintf(d->reason, sizeof d->reason, "kernel %s missing or of another shape", names[s][r]);
-                return d;
+            for (int f = 0; f < 2; ++f) {
+                char name[96];
+                snprintf(name, sizeof name, "env2048_step_resident_%s%s%s.kd", s ? "small" : "large", r ? "_random" : "", f ? "_first" : "");
+                KernelRef &k = d->resident[s][r][f];
+                if (!lookup(d, name, &k) || k.kernarg != sizeof(ResidentArgs) || k.priv != 0) {
+                    snprintf(d->reason, sizeof d->reason, "kernel %s missing or of another shape", name);
+                    return d;
+                }
             }
     // queues, signals, memory
-    for (int c = 0; c < CHAINS; ++c) {
-        st = hsa_queue_create(d->gpu, QUEUE_PACKETS, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &d->queue[c]);
+    for (int q = 0; q < QUEUES_CREATED; ++q) {
+        st = hsa_queue_create(d->gpu, q < CHAINS ? QUEUE_PACKETS : 64u, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &d->queue[q]);
         if (st != HSA_STATUS_SUCCESS) return set_reason(d, "hsa_queue_create", st), d;
+    }
+    for (int c = 0; c < CHAINS; ++c) {
         for (uint32_t s = 0; s < RING_SEGMENTS; ++s)
             if ((st = hsa_signal_create(0, 0, nullptr, &d->segment_signal[c][s])) != HSA_STATUS_SUCCESS) return set_reason(d, "hsa_signal_create", st), d;
         if ((st = hsa_signal_create(0, 0, nullptr, &d->first_signal[c])) != HSA_STATUS_SUCCESS) return set_reason(d, "hsa_signal_create", st), d;
@@ -475,7 +485,7 @@ inline int step_sequence(int device, hipStream_t stream, const SequenceArgs &a)
                 r.step_hi = (uint32_t)(step >> 32);
                 r.reward = a.reward ? (uint64_t)(uintptr_t)(a.reward + row + off) : 0;
                 r.done = (uint64_t)(uintptr_t)(a.done + row + off);
-                r.mode = (first + t == 0 ? MODE_ESTABLISH : 0u) | (pretend_moved_at >= 0 && (long)(first + t) == pretend_moved_at ? MODE_PRETEND_MOVED : 0u);
+                r.mode = pretend_moved_at >= 0 && (long)(first + t) == pretend_moved_at ? MODE_PRETEND_MOVED : 0u;
                 r.owner = (uint64_t)(uintptr_t)d->owner[c];
                 r.placement_error = (uint64_t)(uintptr_t)d->placement_error;
                 r.snapshot = (uint64_t)(uintptr_t)(d->snapshot + 16 * off);
@@ -488,7 +498,7 @@ inline int step_sequence(int device, hipStream_t stream, const SequenceArgs &a)
         for (uint32_t t = 0; t < steps; ++t) {
             const bool first_packet = first_segment && t == 0, last_packet = last_segment && t + 1 == steps, segment_end = t + 1 == steps;
             for (int c = 0; c < chains; ++c) {
-                const KernelRef &k = d->resident[part_small[c] ? 1 : 0][random_actions ? 1 : 0];
+                const KernelRef &k = d->resident[part_small[c] ? 1 : 0][random_actions ? 1 : 0][first_packet ? 1 : 0];
                 hsa_signal_t completion = no_signal;
                 if (segment_end) {
                     completion = d->segment_signal[c][segment_slot[c]];

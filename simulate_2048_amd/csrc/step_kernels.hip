@@ -103,7 +103,7 @@ __device__ __forceinline__ void reset_queued(const StepArgs &a, uint64_t block0,
 // RESIDENT (the direct-dispatch chain of direct_dispatch.hpp, launches whose packets carry no cache fences): boards are loaded
 // at agent scope (sc1 buffer loads: past this CU's vector L1, which nothing invalidates between such launches and which may
 // hold the tile as ANOTHER launch's workgroup on this CU left it; the XCD's L2 is the home of the tile for the whole chain).
-template <bool EXTRAS, bool FULL, bool RANDOM, int BOARDS_PER_LANE, bool RESIDENT = false>
+template <bool EXTRAS, bool FULL, bool RANDOM, int BOARDS_PER_LANE, bool RESIDENT = false, bool SNAPSHOT = false>
 __device__ __forceinline__ void step_block(const StepArgs &a, uint4 *dir_lds, uint32_t (*word_lds)[word_strip_words(BOARDS_PER_LANE)],
                                            uint32_t *queue_state, uint16_t *reset_slot)
 {
@@ -196,9 +196,9 @@ __device__ __forceinline__ void step_block(const StepArgs &a, uint4 *dir_lds, ui
     bool done[BOARDS_PER_LANE];
     auto compute = [&](int j) {
         bool changed;
-        if constexpr (RESIDENT) {  // (wave-uniform: only the first launch of a chain carries a snapshot pointer)
+        if constexpr (SNAPSHOT) {  // (the first launch of a direct-dispatch chain: the boards as the sequence found them)
             const uint64_t i = tile0 + 64u * j + lane;
-            if (a.snapshot && (FULL || i < a.n)) store_board(a.snapshot, i, bd[j]);
+            if (FULL || i < a.n) store_board(a.snapshot, i, bd[j]);
         }
 #if defined(ENV2048_EXP_ABLATE) && (ENV2048_EXP_ABLATE & 1)  // timing-only build: no game logic
         reward[j] = sel[j].fA + word[j];
@@ -404,10 +404,9 @@ __global__ void advance_counter_kernel(unsigned long long *counter, unsigned lon
 // the chip between steps but the write-once rows).  Across CUs inside the XCD the tile may move from launch to launch: hence
 // the agent-scope loads (step_block<..., RESIDENT>).  reward / done are written and never read; actions are read-only for the
 // chain.  "Keeps landing on the same XCD" is checked, not assumed -- see step_resident_body.
-constexpr uint32_t RESIDENT_ESTABLISH = 1u;      // first launch of a chain: record the XCD of every workgroup, snapshot the boards
 constexpr uint32_t RESIDENT_PRETEND_MOVED = 2u;  // (test hook of direct_dispatch.hpp) this launch's workgroups claim another XCD
 
-template <bool RANDOM, int BPL>
+template <bool RANDOM, int BPL, bool FIRST>
 __device__ __forceinline__ void step_resident_body(uint8_t *boards, const uint8_t *actions, uint64_t n, uint64_t env_base, uint32_t flags,
                                                    uint32_t seed_lo, uint32_t seed_hi, uint32_t step_lo, uint32_t step_hi, int32_t *reward,
                                                    uint8_t *done, uint32_t mode, uint32_t *owner, uint32_t *placement_error, uint8_t *snapshot)
@@ -420,22 +419,22 @@ __device__ __forceinline__ void step_resident_body(uint8_t *boards, const uint8_
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
     xcc_id = (xcc_id & 0xfu) ^ ((mode & RESIDENT_PRETEND_MOVED) ? 1u : 0u);
     uint32_t home = xcc_id;
-    if (mode & RESIDENT_ESTABLISH) {
+    if constexpr (FIRST) {
         if (threadIdx.x == 0u) __hip_atomic_store(owner + blockIdx.x, xcc_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
         home = __hip_atomic_load(owner + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     StepArgs a{n, env_base, boards, actions, reward, done, nullptr, nullptr, RngKey{seed_lo, seed_hi, step_lo, step_hi}, flags, nullptr};
-    a.snapshot = (mode & RESIDENT_ESTABLISH) ? snapshot : nullptr;
+    a.snapshot = snapshot;
     __shared__ uint4 dir_lds[8];
     __shared__ __attribute__((aligned(16))) uint32_t word_lds[WAVES_PER_BLOCK][word_strip_words(BPL)];
     __shared__ uint32_t queue_state;
     __shared__ uint16_t reset_slot[block_boards(BPL)];
     const uint64_t block0 = (uint64_t)blockIdx.x * block_boards(BPL);
     if (block0 + block_boards(BPL) <= a.n)
-        step_block<false, true, RANDOM, BPL, true>(a, dir_lds, word_lds, &queue_state, reset_slot);
+        step_block<false, true, RANDOM, BPL, true, FIRST>(a, dir_lds, word_lds, &queue_state, reset_slot);
     else
-        step_block<false, false, RANDOM, BPL, true>(a, dir_lds, word_lds, &queue_state, reset_slot);
+        step_block<false, false, RANDOM, BPL, true, FIRST>(a, dir_lds, word_lds, &queue_state, reset_slot);
     if (home != xcc_id && threadIdx.x == 0u)  // (block + 1, the XCD this workgroup ran on, the XCD its boards live on)
         __hip_atomic_store(placement_error, (1u + (blockIdx.x & 0xffffu)) | (xcc_id << 16) | ((home & 0xffu) << 24), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_SYSTEM);
@@ -592,19 +591,24 @@ inline bool want_two_chains(uint64_t n, uint32_t count, uint32_t flags) { return
 // [step-kernel-source-begin]
 // The entry points of the direct-dispatch code object carry C names: direct_dispatch.hpp finds them by name in the image it
 // loads through ROCr (the HIP runtime never launches them).
-#define ENV2048_RESIDENT_KERNEL(NAME, RANDOM, BPL)                                                                                              \
+#define ENV2048_RESIDENT_KERNEL(NAME, RANDOM, BPL, FIRST)                                                                                            \
     extern "C" __global__ __launch_bounds__(BLOCK) void NAME(uint8_t *boards, const uint8_t *actions, uint64_t n, uint64_t env_base, uint32_t flags, \
                                                              uint32_t seed_lo, uint32_t seed_hi, uint32_t step_lo, uint32_t step_hi, int32_t *reward, \
                                                              uint8_t *done, uint32_t mode, uint32_t *owner, uint32_t *placement_error,          \
                                                              uint8_t *snapshot)                                                                 \
     {                                                                                                                                           \
-        step_resident_body<RANDOM, BPL>(boards, actions, n, env_base, flags, seed_lo, seed_hi, step_lo, step_hi, reward, done, mode, owner,     \
+        step_resident_body<RANDOM, BPL, FIRST>(boards, actions, n, env_base, flags, seed_lo, seed_hi, step_lo, step_hi, reward, done, mode, owner,     \
                                         placement_error, snapshot);                                                                             \
     }
-ENV2048_RESIDENT_KERNEL(env2048_step_resident_small, false, 1)
-ENV2048_RESIDENT_KERNEL(env2048_step_resident_small_random, true, 1)
-ENV2048_RESIDENT_KERNEL(env2048_step_resident_large, false, BOARDS_PER_LANE)
-ENV2048_RESIDENT_KERNEL(env2048_step_resident_large_random, true, BOARDS_PER_LANE)
+// (_first: the launch that opens a chain -- it records every workgroup's XCD and copies the boards it loads into the snapshot)
+ENV2048_RESIDENT_KERNEL(env2048_step_resident_small, false, 1, false)
+ENV2048_RESIDENT_KERNEL(env2048_step_resident_small_random, true, 1, false)
+ENV2048_RESIDENT_KERNEL(env2048_step_resident_large, false, BOARDS_PER_LANE, false)
+ENV2048_RESIDENT_KERNEL(env2048_step_resident_large_random, true, BOARDS_PER_LANE, false)
+ENV2048_RESIDENT_KERNEL(env2048_step_resident_small_first, false, 1, true)
+ENV2048_RESIDENT_KERNEL(env2048_step_resident_small_random_first, true, 1, true)
+ENV2048_RESIDENT_KERNEL(env2048_step_resident_large_first, false, BOARDS_PER_LANE, true)
+ENV2048_RESIDENT_KERNEL(env2048_step_resident_large_random_first, true, BOARDS_PER_LANE, true)
 #undef ENV2048_RESIDENT_KERNEL
 
 // [step-kernel-source-end]

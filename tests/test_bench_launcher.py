@@ -88,7 +88,7 @@ def test_profile_table_is_keyed_by_kernel_source():
 
     text = (REPO / 'simulate_2048_amd' / 'csrc' / 'step_kernels.hip').read_text()
     regions = re.findall(r'\[step-kernel-source-begin\](.*?)\[step-kernel-source-end\]', text, flags=re.S)
-    assert len(regions) == 2 and 'void step_kernel(' in regions[0] and 'void launch_step(' in regions[1]
+    assert len(regions) == 3 and 'void step_kernel(' in regions[0] and 'void launch_step(' in regions[1] and 'env2048_step_resident_large' in regions[2]
     assert 'rollout_kernel' not in ''.join(regions) and 'expectimax_ply_kernel' not in ''.join(regions)
     path = REPO / 'profiles' / 'step_pmc.json'
     if path.exists():
@@ -96,7 +96,7 @@ def test_profile_table_is_keyed_by_kernel_source():
         assert set(table) >= {'kernel_source_sha', 'entries'}
         for key, entry in table['entries'].items():
             leg, boards = key.split(':')
-            assert leg in ('resident', 'resident_one_chain', 'cold', 'cold_separate') and int(boards) > 0
+            assert leg in ('direct', 'resident', 'resident_one_chain', 'cold', 'cold_separate') and int(boards) > 0
             assert entry['fabric_bytes_per_launch'] > 0 and (REPO / entry['source']).exists()
         prof = bench.load_step_profile(1 << 20, 'resident')
         assert prof is None or prof['stale'] == (table['kernel_source_sha'] != sha)

@@ -65,15 +65,15 @@ struct StepKernarg {
     uint64_t reward, done, legal, obs, max_exp, step_counter;
 };
 static_assert(sizeof(StepKernarg) == 104 && offsetof(StepKernarg, reward) == 56 && offsetof(StepKernarg, step_counter) == 96, "kernarg layout");
-// ... and of env2048_step_resident_* (88 bytes)
+// ... and of env2048_step_resident_* (104 bytes; csrc/direct_dispatch.hpp is the product's user of these kernels)
 struct ResidentKernarg {
     uint64_t boards, actions, n, env_base;
     uint32_t flags, seed_lo, seed_hi, step_lo, step_hi, pad;
     uint64_t reward, done;
-    uint32_t xcc0, pad2;
-    uint64_t placement_error;
+    uint32_t mode, pad2;  // bit 0: first launch of a chain (records every workgroup's XCD, snapshots the boards)
+    uint64_t owner, placement_error, snapshot;
 };
-static_assert(sizeof(ResidentKernarg) == 88 && offsetof(ResidentKernarg, xcc0) == 72 && offsetof(ResidentKernarg, placement_error) == 80, "kernarg layout");
+static_assert(sizeof(ResidentKernarg) == 104 && offsetof(ResidentKernarg, mode) == 72 && offsetof(ResidentKernarg, snapshot) == 96, "kernarg layout");
 constexpr size_t KERNARG_STRIDE = 128;
 
 static hsa_agent_t g_gpu{};
@@ -306,34 +306,25 @@ int main(int argc, char **argv)
     constexpr int MAX_PARTS = 4;
     hsa_queue_t *queues[MAX_PARTS] = {queue[0], queue[1], nullptr, nullptr};
     for (int i = 2; i < MAX_PARTS; ++i) HSACHECK(hsa_queue_create(g_gpu, 1024, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &queues[i]));
-    uint32_t xcc0[MAX_PARTS] = {};
+    // AQL_PAIR="a,b": the 2-chain variants run on queues a and b of EIGHT queues created in order (do two queues created four apart
+    // share a hardware pipe?  profiles/r05_j_*)
+    if (const char *pair = getenv("AQL_PAIR")) {
+        hsa_queue_t *all[8] = {queues[0], queues[1], queues[2], queues[3], nullptr, nullptr, nullptr, nullptr};
+        for (int i = 4; i < 8; ++i) HSACHECK(hsa_queue_create(g_gpu, 1024, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &all[i]));
+        int a = 0, b = 1;
+        sscanf(pair, "%d,%d", &a, &b);
+        queues[0] = all[a & 7];
+        queues[1] = all[b & 7];
+        printf("2-chain variants on queues %d and %d of 8\n", a & 7, b & 7);
+    }
     uint32_t *placement_error = nullptr;  // pinned host word the resident kernels report a misplaced workgroup into
     HSACHECK(hsa_amd_memory_pool_allocate(g_kernarg_pool, 4096, 0, (void **)&placement_error));
     HSACHECK(hsa_amd_agents_allow_access(1, &g_gpu, nullptr, placement_error));
     *placement_error = 0;
-    if (resident_kernel) {
-        const Kernel probe = get_kernel(exe, "env2048_xcc_probe.kd");
-        uint32_t *out = nullptr;
-        uint8_t *args = nullptr;
-        HIPCHECK(hipMalloc(&out, 4096));
-        HIPCHECK(hipMalloc(&args, 256));
-        HIPCHECK(hipMemcpy(args, &out, 8, hipMemcpyHostToDevice));
-        hsa_signal_t sig;
-        HSACHECK(hsa_signal_create(1, 0, nullptr, &sig));
-        for (int i = 0; i < MAX_PARTS; ++i) {
-            hsa_signal_store_relaxed(sig, 1);
-            dispatch(queues[i], probe, 16, (uint64_t)args, header(true, SYSTEM, SYSTEM), sig);
-            while (hsa_signal_wait_scacquire(sig, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_ACTIVE) >= 1) {
-            }
-            uint32_t got16[16];
-            HIPCHECK(hipMemcpy(got16, out, sizeof got16, hipMemcpyDeviceToHost));
-            xcc0[i] = got16[0];
-            for (int k = 0; k < 16; ++k)
-                if (got16[k] != ((got16[0] + k) & 7u)) printf("queue %d: workgroup %d on XCD %u, not round-robin\n", i, k, got16[k]);
-        }
-        printf("XCD of workgroup 0 per queue: %u %u %u %u\n", xcc0[0], xcc0[1], xcc0[2], xcc0[3]);
-        hsa_signal_destroy(sig);
-    }
+    uint32_t *owner_table = nullptr;  // [part][workgroup]: the XCD the first launch of a chain found each workgroup on
+    uint8_t *snapshot = nullptr;
+    HIPCHECK(hipMalloc(&owner_table, MAX_PARTS * 4096 * 4));
+    HIPCHECK(hipMalloc(&snapshot, 16 * n));
     const uint64_t total_blocks = n / block_boards(bpl);
     auto part_first_block = [&](int parts, int p) { return total_blocks * (uint64_t)p / (uint64_t)parts; };
     auto table_slot = [&](int parts, int p, uint32_t t) { return ((size_t)(parts * (parts - 1) / 2 + p) * K + t) * KERNARG_STRIDE; };
@@ -358,9 +349,11 @@ int main(int argc, char **argv)
                 a.done = (uint64_t)(done_rows + row + off);
                 if (resident_kernel) {
                     ResidentKernarg ra{};
-                    memcpy(&ra, &a, offsetof(ResidentKernarg, xcc0));  // (the two layouts agree up to `done`)
-                    ra.xcc0 = xcc0[p];
+                    memcpy(&ra, &a, offsetof(ResidentKernarg, mode));  // (the two layouts agree up to `done`)
+                    ra.mode = t == 0 ? 1u : 0u;
+                    ra.owner = (uint64_t)(owner_table + 4096 * p);
                     ra.placement_error = (uint64_t)placement_error;
+                    ra.snapshot = (uint64_t)(snapshot + 16 * off);
                     memcpy(blocks_host.data() + table_slot(parts, p, t), &ra, sizeof ra);
                 } else
                     memcpy(blocks_host.data() + table_slot(parts, p, t), &a, sizeof a);
@@ -438,10 +431,11 @@ int main(int argc, char **argv)
         run_variant(1, SYSTEM, true);
         run_variant(1, AGENT, false);
     }
-    for (int parts = 1; parts <= MAX_PARTS; ++parts) {
+    for (int parts = 1; parts <= (getenv("AQL_PAIR") ? 2 : MAX_PARTS); ++parts) {
         run_variant(parts, AGENT, true);
         run_variant(parts, NONE, true);
     }
+    if (getenv("AQL_PAIR")) return 0;
 
     // ---- which XCD does workgroup k of a dispatch run on, queue by queue? --------------------------------------------------
     // (CU masks do not pin a queue to an XCD -- hsa_amd_queue_cu_set_mask is applied inside every XCD alike, profiles/r05_b_*; the

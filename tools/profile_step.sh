@@ -14,21 +14,29 @@ cd /tmp
 RES="python3 $R/bench.py --no-cpu-baseline --no-cold --no-other-configs"
 COLD="python3 $R/bench.py --no-cpu-baseline --only-cold"
 # kernel stats over the SAME step counts as the default bench run, so that the averages are comparable
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_resident -- $RES > $O/stats_resident.json 2> $O/stats_resident.err
+# the default run takes the DIRECT route (the library's own queues); --no-direct = the stream route (two chains; --single-chain: one)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_direct -- $RES > $O/stats_direct.json 2> $O/stats_direct.err
+echo "stats direct rc=$?"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_resident -- $RES --no-direct > $O/stats_resident.json 2> $O/stats_resident.err
 echo "stats resident rc=$?"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_onechain -- $RES --single-chain > $O/stats_onechain.json 2> $O/stats_onechain.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_onechain -- $RES --no-direct --single-chain > $O/stats_onechain.json 2> $O/stats_onechain.err
 echo "stats resident (one chain) rc=$?"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cold -- $COLD > $O/stats_cold.json 2> $O/stats_cold.err
 echo "stats cold rc=$?"
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU" "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE"; do
   name=$(echo $set | tr " " "_" | cut -c1-32)
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc_resident_$name -- $RES --steps 300 --warmup 100 --max-blocks 3 > $O/pmc_resident_$name.json 2> $O/pmc_resident_$name.err || echo "PMC pass failed: resident $set"
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc_direct_$name -- $RES --steps 300 --warmup 100 --max-blocks 3 > $O/pmc_direct_$name.json 2> $O/pmc_direct_$name.err || echo "PMC pass failed: direct $set"
+  echo "pmc direct $name done"
+done
+for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU" "TCC_HIT_sum TCC_MISS_sum"; do
+  name=$(echo $set | tr " " "_" | cut -c1-32)
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc_resident_$name -- $RES --no-direct --steps 300 --warmup 100 --max-blocks 3 > $O/pmc_resident_$name.json 2> $O/pmc_resident_$name.err || echo "PMC pass failed: resident $set"
   echo "pmc resident $name done"
 done
 # the one-chain shape (whole-batch launches): what the driver's --steps 20 run times (K < 32 never splits)
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU" "TCC_HIT_sum TCC_MISS_sum"; do
   name=$(echo $set | tr " " "_" | cut -c1-32)
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc_onechain_$name -- $RES --single-chain --steps 300 --warmup 100 --max-blocks 3 > $O/pmc_onechain_$name.json 2> $O/pmc_onechain_$name.err || echo "PMC pass failed: one chain $set"
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc_onechain_$name -- $RES --no-direct --single-chain --steps 300 --warmup 100 --max-blocks 3 > $O/pmc_onechain_$name.json 2> $O/pmc_onechain_$name.err || echo "PMC pass failed: one chain $set"
   echo "pmc onechain $name done"
 done
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_VALU"; do
@@ -45,5 +53,5 @@ echo "summary rc=$?"
 cp $O/summary/step_pmc.json $R/profiles/step_pmc.json
 python3 bench.py > $O/summary/${LABEL}_bench_default.json 2> $O/bench_default.err
 echo "bench default rc=$?"
-python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/summary/${LABEL}_bench_driver_shape.json 2> $O/bench_driver_shape.err
+python3 bench.py --steps 20 --warmup 5 > $O/summary/${LABEL}_bench_driver_shape.json 2> $O/bench_driver_shape.err
 echo "bench driver-shape rc=$?"

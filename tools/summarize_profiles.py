@@ -27,7 +27,8 @@ BOARDS = 1 << 20
 # leg -> (rocprof run it comes from, kernel): the --only-cold run holds BOTH cold forms.  Every figure is scaled to ONE 2^20-board
 # step (record): a launch's share is boards-per-launch / 2^20, read off its grid size (512-thread blocks of 2048 boards: 4 boards
 # per work-item) -- 1/30 of a shared cold launch, and TWO launches per step where env2048_step_sequence runs two half-batch chains.
-LEGS = {'resident': ('resident', KERNEL), 'resident_one_chain': ('onechain', KERNEL), 'cold': ('cold', SHARED),
+DIRECT = 'env2048_step_resident_large'  # the resident variant the direct route dispatches on the library's own queues
+LEGS = {'direct': ('direct', DIRECT), 'resident': ('resident', KERNEL), 'resident_one_chain': ('onechain', KERNEL), 'cold': ('cold', SHARED),
         'cold_separate': ('cold', KERNEL)}  # resident_one_chain: bench.py --single-chain (whole-batch launches: what a K < 32 run times)
 
 
