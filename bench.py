@@ -88,8 +88,6 @@ def parse_args(argv=None):
                     'the fan-out on a box with fewer GPUs; not a scaling measurement)')
     ap.add_argument('--no-direct', action='store_true', help='A/B aid: ENV2048_FLAG_NO_DIRECT on the timed env2048_step_sequence calls (the '
                     'stream route: HIP launches instead of the library\'s own queues)')
-    ap.add_argument('--stream-route-child', action='store_true', help='(internal) print the stream route\'s numbers of the other_configs legs; '
-                    'bench.py starts itself this way with ENV2048_DIRECT=0')
     ap.add_argument('--single-chain', action='store_true', help='A/B aid: ENV2048_FLAG_SINGLE_CHAIN on the timed env2048_step_sequence calls '
                     '(never split the batch into two half-batch chains)')
     ap.add_argument('--dist-backend', default='nccl', help="'nccl' (= RCCL, one GPU per rank); 'gloo' = REHEARSAL of the "
@@ -615,7 +613,7 @@ def run_rank(args) -> None:
         for phase in range(8):
             action_table(K, phase)
         enqueue_times = []
-        route_calls, device_times = [lib.direct_stats(device_index)['calls']], []
+        route_calls, device_times = [0], []  # (filled in below: querying the direct route starts it)
 
         def timed_block(count: int, with_events: bool = True):
             """One timed region: barrier + synchronize | K steps | synchronize.  Blocks alternate between two instruments: the
@@ -648,6 +646,10 @@ def run_rank(args) -> None:
             if rank == 0:
                 emit(json.dumps({'hbm_cold': cold}))
             return
+        stream_side = None
+        if not args.no_other_configs and world == 1 and not args.extras and not args.no_direct:
+            stream_side = stream_route_legs(torch, lib, device, device_index, h)  # (before anything can start the direct route)
+        route_calls[0] = lib.direct_stats(device_index)['calls']
         run_steps(W)
         torch.cuda.synchronize()
         # how many blocks: cover --min-ms of GPU time (the same count on every rank: calibrate on the max over ranks)
@@ -674,7 +676,7 @@ def run_rank(args) -> None:
         # ---- BASELINE configs[1] and configs[4], single GPU only (reported next to the headline, not as `value`) ---------
         other = None
         if not args.no_other_configs and world == 1 and not args.extras:
-            other = other_configs(torch, lib, device, device_index, h)
+            other = other_configs(torch, lib, device, device_index, h, stream_side=stream_side)
 
         if rank == 0:
             roofline = build_roofline(args, lib, n, flags, launch_s, obs_bytes, route=route)
@@ -824,7 +826,7 @@ def measured_copy_ceiling(torch, device):
                                       f'{"non-temporal" if best[2] else "temporal"} accesses', 'sweep_GB/s': sweep}
 
 
-def other_configs(torch, lib, device, device_index, h) -> dict:
+def other_configs(torch, lib, device, device_index, h, stream_side=None) -> dict:
     """BASELINE configs[1] (65 536 boards) and configs[4] (2^20 boards x 512-step rollout, Philox spawn, auto-reset,
     on-device random actions) on this GPU -- measured both as 512 step launches and as one fused env2048_rollout,
     with the cross-check SURVEY 8(d) config 5 asks for (identical boards, sum of rewards and episode counts)."""
@@ -832,7 +834,7 @@ def other_configs(torch, lib, device, device_index, h) -> dict:
     from simulate_2048_amd.batch import BatchedEnv2048
 
     out = {}
-    stream_side = stream_route_numbers() if lib.direct_stats(device_index)['available'] else {}
+    stream_side = stream_side or {}
     # configs[0]: one board, 1000 random-action steps through the TwentyFortyEight env API (reset on done) -- the mirror runs
     # every step as one kernel launch on pinned host operands + one polled completion word
     import numpy as np
@@ -1083,20 +1085,17 @@ def long_sequence_leg(torch, lib, device, device_index, h, n: int = 1 << 20, K: 
     stream = torch.cuda.current_stream(device)
     table = (ctypes.c_void_p * K)(*[pool[t & 7].data_ptr() for t in range(K)])
     out = {'workload': workload_text(n) + f'; one env2048_step_sequence call of K = {K} steps', 'K': K}
-    direct_here = lib.direct_stats(device_index)['available']
-    # With the direct route up, the library's two queues sit on two of the four hardware pipes of the compute engine and two HIP
-    # streams of this process may then share one (a 2-chain stream sequence measured 23.6 instead of 7 us per step next to
-    # them): the stream route's own numbers therefore come from a CHILD process that runs with ENV2048_DIRECT=0
-    # (stream_route_numbers), not from this one.
+    direct_here = False if stream_only else lib.direct_stats(device_index)['available']  # (the query would start the route: not in a stream-only pass)
+    # (the stream route's legs come from stream_route_legs, run before the library's queues exist -- see there)
     legs = [('default', 0)] if direct_here and not stream_only else []
     if stream_only or not direct_here:
         legs += [('two_chains_default', capi.FLAG_NO_DIRECT), ('single_chain', capi.FLAG_NO_DIRECT | capi.FLAG_SINGLE_CHAIN)]
     for k, (name, extra) in enumerate(legs):
         flags = env.flags | extra
-        calls_before = lib.direct_stats(device_index)['calls']
+        calls_before = 0 if stream_only else lib.direct_stats(device_index)['calls']
         wall1, ev1 = _timed_sequence(torch, lib, stream, device_index, h, env, table, K, flags, 1000 + 100 * K * k)
         wall, ev = _timed_sequence(torch, lib, stream, device_index, h, env, table, K, flags, 50_000 + 100 * K * k, calls=5)
-        info = lib.direct_stats(device_index)
+        info = {'calls': 0, 'last_chains': 0, 'last_gpu_ns': 0} if stream_only else lib.direct_stats(device_index)
         took_direct = info['calls'] > calls_before
         gbs = ALGO_BYTES_PER_STEP * n / (ev / K) / 1e9
         out[name] = {'route': 'direct (the library\'s own queues, boards L2-resident between the first and the last launch of a call)'
@@ -1168,41 +1167,25 @@ def legal_obs_leg(torch, lib, device, device_index, h, n: int = 1 << 20, K: int 
     return out
 
 
-def stream_route_numbers(timeout: float = 420.0) -> dict:
-    """The stream route's numbers for the legs of other_configs, measured by a CHILD process that runs with ENV2048_DIRECT=0 (no
-    queues of the library's own next to the HIP streams) while this process idles.  {} plus a note when the child fails."""
-    env = dict(os.environ, ENV2048_DIRECT='0')
-    for key in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
-        env.pop(key, None)
-    try:
-        proc = subprocess.run([sys.executable, str(Path(__file__).resolve()), '--stream-route-child'], env=env, capture_output=True, text=True,
-                              timeout=timeout)
-        lines = [x for x in proc.stdout.splitlines() if x.startswith('{')]
-        if proc.returncode != 0 or not lines:
-            return {'error': f'the child process failed (rc {proc.returncode}): {proc.stderr[-300:]}'}
-        return json.loads(lines[-1])
-    except Exception as exc:  # (a missing number must not cost the run its headline)
-        return {'error': f'{type(exc).__name__}: {exc}'}
-
-
-def stream_route_child() -> None:
-    """`bench.py --stream-route-child` (started by stream_route_numbers with ENV2048_DIRECT=0): the legs of other_configs on the
-    stream route -- configs[1] as 2000 launches, configs[4] as 2 x 512 launches, configs[2] as one K = 200 sequence (two chains and
-    one) with the helper thread's cost -- as one JSON line."""
-    sys.stdout.flush()
-    result_fd = os.dup(1)
-    os.dup2(2, 1)
-    import torch
-
+def stream_route_legs(torch, lib, device, device_index, h) -> dict:
+    """The legs of other_configs on the STREAM route (ENV2048_FLAG_NO_DIRECT: HIP launches) -- configs[1] as 2000 launches,
+    configs[4] as 2 x 512 launches, configs[2] as one K = 200 sequence (two chains and one) with the helper thread's cost.  Run by
+    run_rank BEFORE the first call that could start the direct route: once the library's queues exist, two HIP streams of the
+    process can end up on one hardware pipe (a 2-chain stream sequence next to them measured 11-24 us per step instead of 6.6;
+    DESIGN section 4, "pipes"), which would misstate the stream route as a process without the direct route sees it."""
     from simulate_2048_amd import capi
     from simulate_2048_amd.batch import BatchedEnv2048
 
-    device = torch.device('cuda', 0)
-    torch.cuda.set_device(device)
-    lib = capi.library()
     stream = torch.cuda.current_stream(device)
-    h = stream.cuda_stream
-    out = {'where': 'a child process of bench.py with ENV2048_DIRECT=0 (direct route: ' + lib.direct_stats(0)['reason'] + ')'}
+    no_direct = capi.FLAG_NO_DIRECT
+    out = {'where': 'this process, before the direct route was started (ENV2048_FLAG_NO_DIRECT on every call; the library had created no queue yet)'}
+    # these legs are the first GPU work of the process: bring the clocks up first (0.1 s of 2^20-board steps), as the headline's
+    # own blocks do for the legs that follow it -- the launch-bound 65 536-board leg measured 4.5 instead of 3.2 us per step cold
+    warm, _ = _midgame_env(torch, device, 1 << 20)
+    lib.step_sequence(device_index, h, warm.num_envs, 0, warm.boards.data_ptr(), None, warm.reward.data_ptr(), warm.done.data_ptr(), None, None, 0, SEED,
+                      1 << 40, 12000, warm.flags | capi.FLAG_RANDOM_ACTIONS | no_direct | capi.FLAG_SINGLE_CHAIN)
+    torch.cuda.synchronize()
+    del warm
 
     def timed(call, reps=4):
         times = []
@@ -1220,10 +1203,10 @@ def stream_route_child() -> None:
     n1, count = 1 << 16, 2000
     env, pool = _midgame_env(torch, device, n1)
     table = (ctypes.c_void_p * count)(*[pool[t & 7].data_ptr() for t in range(count)])
-    wall, ev = timed(lambda rep: lib.step_sequence(0, h, n1, 0, env.boards.data_ptr(), table, env.reward.data_ptr(), env.done.data_ptr(), None, None,
-                                                   0, SEED, 64 + rep * count, count, env.flags))
+    wall, ev = timed(lambda rep: lib.step_sequence(device_index, h, n1, 0, env.boards.data_ptr(), table, env.reward.data_ptr(), env.done.data_ptr(),
+                                                   None, None, 0, SEED, 64 + rep * count, count, env.flags | no_direct))
     out['configs[1]'] = {'value': n1 * count / wall, 'unit': 'board-steps/s', 'us_per_step_wall': wall / count * 1e6, 'us_per_step_event': ev / count * 1e6,
-                         'note': 'the same call in a process without the direct route: 2000 HIP launches'}
+                         'note': 'the same call on the stream route: 2000 HIP launches'}
     del env, pool
     n4, T = 1 << 20, 512
     a = BatchedEnv2048(n4, SEED, device=device, auto_reset=True)
@@ -1233,13 +1216,8 @@ def stream_route_child() -> None:
     done_rows = torch.zeros((T, n4), dtype=torch.uint8, device=device)
 
     def rows_call(rep):
-        lib.step_sequence(0, h, n4, 0, a.boards.data_ptr(), None, reward_rows.data_ptr(), done_rows.data_ptr(), None, None, n4, SEED, 0, T,
-                          capi.FLAG_AUTO_RESET | capi.FLAG_RANDOM_ACTIONS)
-
-    def rows_timed(rep):
-        a.boards.copy_(start)
-        torch.cuda.synchronize()
-        rows_call(rep)
+        lib.step_sequence(device_index, h, n4, 0, a.boards.data_ptr(), None, reward_rows.data_ptr(), done_rows.data_ptr(), None, None, n4, SEED, 0, T,
+                          capi.FLAG_AUTO_RESET | capi.FLAG_RANDOM_ACTIONS | no_direct)
 
     rows_call(0)  # (pays for the second chain's stream / helper thread)
     times = []
@@ -1255,10 +1233,10 @@ def stream_route_child() -> None:
         times.append((time.perf_counter() - t0, ev0.elapsed_time(ev1) * 1e-3))
     wall, ev = sorted(times)[1]
     out['configs[4]'] = {'value': n4 * T / wall, 'unit': 'board-steps/s', 'ms_total_wall': wall * 1e3, 'us_per_step_event': ev / T * 1e6,
-                         'note': 'the same call in a process without the direct route: 2 x 512 HIP launches (two streams, helper thread)'}
+                         'note': 'the same call on the stream route: 2 x 512 HIP launches (two streams, helper thread)'}
     del a, start, reward_rows, done_rows
-    out['configs[2]_long_sequence'] = long_sequence_leg(torch, lib, device, 0, h, stream_only=True)
-    os.write(result_fd, (json.dumps(out) + '\n').encode())
+    out['configs[2]_long_sequence'] = long_sequence_leg(torch, lib, device, device_index, h, stream_only=True)
+    return out
 
 
 def assemble_single_process_result(args, walls, per_device_ms, roofline: dict) -> dict:
@@ -1336,16 +1314,15 @@ def run_single_process(args) -> None:
         env.shards[g].boards.data_ptr(), tables_for(K, 0)[g], env.shards[g].reward.data_ptr(), env.shards[g].done.data_ptr(), None, None, 0,
         SEED, 10_000_000, K, env.shards[g].flags))
     launch_s = statistics.median(per_device_ms) * 1e-3 / K
-    out = assemble_single_process_result(args, walls, per_device_ms, build_roofline(args, lib, n, env.shards[0].flags, launch_s, 4))
+    info = lib.direct_stats(0)
+    route = {'direct': info['calls'] > 0, 'chains': info['last_chains'], 'reruns': info['reruns'], 'state': info['reason'], 'device_s_per_step': None}
+    out = assemble_single_process_result(args, walls, per_device_ms, build_roofline(args, lib, n, env.shards[0].flags, launch_s, 4, route=route))
     env.close()
     os.write(result_fd, (json.dumps(out) + '\n').encode())
 
 
 def main():
     args = parse_args()
-    if args.stream_route_child:
-        stream_route_child()
-        return
     if args.single_process:
         run_single_process(args)
         return
