@@ -111,7 +111,6 @@ struct Device {
     uint64_t next_block[CHAINS] = {};                  // blocks ever written per chain (slot = index % ring size)
     hsa_signal_t segment_signal[CHAINS][RING_SEGMENTS];  // completion of the last packet of the segment that last used this part of the ring
     bool segment_pending[CHAINS][RING_SEGMENTS] = {};
-    hsa_signal_t first_signal[CHAINS];                 // (timing only: start of the first packet of a call)
     volatile uint32_t *placement_error = nullptr;      // pinned host word
     uint32_t *owner[CHAINS] = {};                      // device: XCD of workgroup k in the first launch of the current sequence
     uint8_t *snapshot = nullptr;                       // device: the boards as the current sequence found them (hipMalloc, grown on demand)
@@ -323,7 +322,6 @@ inline Device *create(int device)
     for (int c = 0; c < CHAINS; ++c) {
         for (uint32_t s = 0; s < RING_SEGMENTS; ++s)
             if ((st = hsa_signal_create(0, 0, nullptr, &d->segment_signal[c][s])) != HSA_STATUS_SUCCESS) return set_reason(d, "hsa_signal_create", st), d;
-        if ((st = hsa_signal_create(0, 0, nullptr, &d->first_signal[c])) != HSA_STATUS_SUCCESS) return set_reason(d, "hsa_signal_create", st), d;
         void *ring = nullptr;
         st = hsa_amd_memory_pool_allocate(d->local_pool, (size_t)RING_SEGMENTS * SEGMENT_STEPS * BLOCK_STRIDE + MAX_BLOCKS_PER_PART * 4, 0, &ring);
         if (st == HSA_STATUS_SUCCESS) {
@@ -455,8 +453,11 @@ inline int step_sequence(int device, hipStream_t stream, const SequenceArgs &a)
     const hsa_signal_t no_signal{0};
     bool timed_out = false;
 
-    for (uint32_t first = 0; first < a.count && !timed_out; first += SEGMENT_STEPS) {
-        const uint32_t steps = a.count - first < SEGMENT_STEPS ? a.count - first : SEGMENT_STEPS;
+    hsa_signal_t first_signal_used[CHAINS] = {}, last_signal_used[CHAINS] = {};  // (timing: what the first / last packet of each chain signals)
+    // Segments: the first is ONE step (its argument blocks are flushed and its packets ring the doorbells before the rest of the
+    // blocks are written: the device starts 2-3 us earlier), the others up to SEGMENT_STEPS.
+    for (uint32_t first = 0, steps = 0; first < a.count && !timed_out; first += steps) {
+        steps = first == 0 ? 1u : (a.count - first < SEGMENT_STEPS ? a.count - first : SEGMENT_STEPS);
         const bool first_segment = first == 0, last_segment = first + steps == a.count;
         uint32_t segment_slot[CHAINS];
         // 1. the argument blocks of this segment (the part of the ring they go to is free once the segment that used it last is done)
@@ -504,10 +505,9 @@ inline int step_sequence(int device, hipStream_t stream, const SequenceArgs &a)
                     completion = d->segment_signal[c][segment_slot[c]];
                     hsa_signal_store_relaxed(completion, 1);
                     d->segment_pending[c][segment_slot[c]] = true;
-                } else if (first_packet && d->timing) {
-                    completion = d->first_signal[c];
-                    hsa_signal_store_relaxed(completion, 1);
                 }
+                if (first_packet) first_signal_used[c] = completion;  // (the first segment is one step long: its packet ends a segment)
+                if (last_packet) last_signal_used[c] = completion;
                 push_packet(d->queue[c], k, part_blocks[c], (uint64_t)(uintptr_t)(d->ring[c] + ((d->next_block[c] + t) % ring_blocks) * BLOCK_STRIDE),
                             packet_header(first_packet, last_packet), completion);
             }
@@ -529,13 +529,11 @@ inline int step_sequence(int device, hipStream_t stream, const SequenceArgs &a)
     }
     if (d->timing) {  // device-side duration of the call: first packet's start to last packet's end, the longer of the chains
         static const bool debug = getenv("ENV2048_DIRECT_DEBUG") != nullptr;
-        const uint32_t last_slot_of = (uint32_t)(((d->next_block[0] / SEGMENT_STEPS) + RING_SEGMENTS - 1) % RING_SEGMENTS);
         uint64_t longest = 0;
         for (int c = 0; c < chains; ++c) {
             hsa_amd_profiling_dispatch_time_t t0{}, t1{};
-            const hsa_signal_t first_sig = a.count > 1 ? d->first_signal[c] : d->segment_signal[c][last_slot_of];
-            const hsa_status_t s0 = hsa_amd_profiling_get_dispatch_time(d->gpu, first_sig, &t0);
-            const hsa_status_t s1 = hsa_amd_profiling_get_dispatch_time(d->gpu, d->segment_signal[c][last_slot_of], &t1);
+            const hsa_status_t s0 = hsa_amd_profiling_get_dispatch_time(d->gpu, first_signal_used[c], &t0);
+            const hsa_status_t s1 = hsa_amd_profiling_get_dispatch_time(d->gpu, last_signal_used[c], &t1);
             if (debug)
                 fprintf(stderr, "[direct] chain %d: first packet %llu .. %llu (status %d), last packet %llu .. %llu (status %d), %llu ticks/s\n", c,
                         (unsigned long long)t0.start, (unsigned long long)t0.end, (int)s0, (unsigned long long)t1.start, (unsigned long long)t1.end, (int)s1,
