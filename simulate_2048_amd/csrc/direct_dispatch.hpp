@@ -10,9 +10,10 @@
 // shared object, build.py), owns two user-mode queues per device and writes the kernel-dispatch packets itself:
 //   * 0.13-0.25 us of host time per packet: the calling thread feeds both chains, no helper thread, no fork / join events;
 //   * the boards stay in the XCD L2s for the whole sequence.  Block k of a part owns the same boards in every launch, and a queue
-//     deals workgroup k of a dispatch to XCD (k + s) % 8 (tools/aql_probe.cpp, profiles/r05_c_*) -- with an s that holds as long
-//     as no queue is created or destroyed on the device (it moved by one when the HIP runtime created its first queue after
-//     ours: profiles/r05_g_*), i.e. in practice for the length of a sequence, but NOT by contract.  So only the first packet of
+//     deals workgroup k of a dispatch to XCD (k + s) % 8 (tools/aql_probe.cpp, profiles/r05_c_*) -- with an s that nothing documents
+//     as fixed: it was seen to move once, between this route's start-up and its first sequence, after the HIP runtime had started
+//     its own queues (profiles/r05_g_*), and never again in 24 000 fuzzed sequences with queues being created and destroyed all the
+//     while, in this process and in another (profiles/r05_o .. r05_q).  So only the first packet of
 //     a chain acquires and only the last releases (system scope), the packets between carry the barrier bit and NO fence, and
 //     the contract is checked instead of assumed: in the first launch every workgroup records the XCD it runs on (and the
 //     boards it loads go into a snapshot buffer of the library); in every later launch every workgroup compares.  One mismatch
@@ -547,8 +548,7 @@ inline int step_sequence(int device, hipStream_t stream, const SequenceArgs &a)
     d->steps += a.count;
     d->last_chains = (uint32_t)chains;
     if (*d->placement_error != 0) {
-        // A workgroup ran on another XCD than the one whose L2 holds its tile (a queue was created or destroyed on the device while
-        // the sequence ran): whatever the chain computed from then on may rest on stale boards.  Back to the snapshot the first
+        // A workgroup ran on another XCD than the one whose L2 holds its tile: whatever the chain computed from then on may rest on stale boards.  Back to the snapshot the first
         // launch took; the caller runs the sequence again as launches on its stream.
         const uint32_t word = *d->placement_error;
         ++d->reruns;
