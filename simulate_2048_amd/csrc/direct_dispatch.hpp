@@ -400,6 +400,9 @@ inline int step_sequence(int device, hipStream_t stream, const SequenceArgs &a)
     if (!d || !d->ok) return NOT_TAKEN;
     std::lock_guard<std::mutex> call(d->call_mutex);
     if (!d->ok) return NOT_TAKEN;  // (switched off by the call this one waited for)
+    static const bool timeline = getenv("ENV2048_DIRECT_DEBUG") != nullptr;  // (diagnostic: where the host's microseconds go)
+    const double t_enter = timeline ? now_us() : 0.0;
+    double t_stream = 0.0, t_first_packets = 0.0, t_all_packets = 0.0;
     hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
     if (stream && (hipStreamIsCapturing(stream, &capture) != hipSuccess || capture != hipStreamCaptureStatusNone)) {
         (void)hipGetLastError();
@@ -425,6 +428,7 @@ inline int step_sequence(int device, hipStream_t stream, const SequenceArgs &a)
     if (e == hipErrorNotReady) e = hipStreamSynchronize(stream);
     if (e != hipSuccess) return hip_fail(e, "env2048_step_sequence: waiting for the caller's stream");
 
+    if (timeline) t_stream = now_us();
     static const long pretend_moved_at = getenv("ENV2048_DIRECT_TEST_MOVE_AT") ? atol(getenv("ENV2048_DIRECT_TEST_MOVE_AT")) : -1;  // (test hook)
     const bool random_actions = (a.flags & ENV2048_FLAG_RANDOM_ACTIONS) != 0u;
     const int chains = chains_for(a.n);
@@ -448,7 +452,8 @@ inline int step_sequence(int device, hipStream_t stream, const SequenceArgs &a)
             }
         }
     }
-    const uint32_t kernel_flags = (a.flags & (ENV2048_FLAG_AUTO_RESET | ENV2048_FLAG_RANDOM_ACTIONS));  // plain stores, narrow outputs
+    uint32_t kernel_flags = (a.flags & (ENV2048_FLAG_AUTO_RESET | ENV2048_FLAG_RANDOM_ACTIONS));  // plain stores
+    if (!misaligned(a.reward, 16) && !misaligned(a.done, 4) && a.row_stride % 4 == 0) kernel_flags |= INTERNAL_FLAG_WIDE_OUTPUTS;  // reward / done rows leave as 16-byte / 4-byte stores
     *d->placement_error = 0;
     const uint32_t ring_blocks = RING_SEGMENTS * SEGMENT_STEPS;
     const hsa_signal_t no_signal{0};
@@ -513,9 +518,11 @@ inline int step_sequence(int device, hipStream_t stream, const SequenceArgs &a)
                             packet_header(first_packet, last_packet), completion);
             }
         }
+        if (timeline && first_segment) t_first_packets = now_us();
         for (int c = 0; c < chains; ++c) d->next_block[c] += SEGMENT_STEPS;  // (a segment always occupies one whole part of the ring)
         d->packets += (uint64_t)steps * chains;
     }
+    if (timeline) t_all_packets = now_us();
     // 3. the results are in memory when the last packets have completed (their release fence is part of completing)
     for (int c = 0; c < chains; ++c)
         for (uint32_t s = 0; s < RING_SEGMENTS; ++s)
@@ -528,6 +535,9 @@ inline int step_sequence(int device, hipStream_t stream, const SequenceArgs &a)
         set_reason(d, "a direct sequence did not complete in time: route switched off", HSA_STATUS_SUCCESS);
         return fail(ENV2048_ERR_DEVICE, "env2048_step_sequence: the direct-dispatch sequence did not complete (route switched off for this device)");
     }
+    if (timeline)
+        fprintf(stderr, "[direct] K = %u: stream idle after %.2f us, first packets out after %.2f, all packets after %.2f, complete after %.2f\n", a.count,
+                t_stream - t_enter, t_first_packets - t_enter, t_all_packets - t_enter, now_us() - t_enter);
     if (d->timing) {  // device-side duration of the call: first packet's start to last packet's end, the longer of the chains
         static const bool debug = getenv("ENV2048_DIRECT_DEBUG") != nullptr;
         uint64_t longest = 0;

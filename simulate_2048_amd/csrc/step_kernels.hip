@@ -117,7 +117,8 @@ __device__ __forceinline__ void step_block(const StepArgs &a, uint4 *dir_lds, ui
     const bool auto_reset = (a.flags & ENV2048_FLAG_AUTO_RESET) != 0u;
     const bool through = (a.flags & INTERNAL_FLAG_WRITE_THROUGH) != 0u;
     // the LDS transposition of reward/done only pays together with write-through stores (measured)
-    const bool wide_outputs = through && FULL && BOARDS_PER_LANE >= 2 && (a.flags & INTERNAL_FLAG_WIDE_OUTPUTS) != 0u;
+    // (... and with the resident launches of the direct route, as plain wide stores: 5.22 vs 5.30 us per 2^20-board step, profiles/r05_r_*)
+    const bool wide_outputs = (through || RESIDENT) && FULL && BOARDS_PER_LANE >= 2 && (a.flags & INTERNAL_FLAG_WIDE_OUTPUTS) != 0u;
 
 #ifdef ENV2048_EXP_STAMPS  // diagnostic build: wave timeline stamps into the (otherwise unused) obs buffer
     uint64_t stamp0 = __builtin_amdgcn_s_memrealtime(), stamp1 = 0, stamp2 = 0, stamp3 = 0, stamp4 = 0;
@@ -286,8 +287,13 @@ __device__ __forceinline__ void step_block(const StepArgs &a, uint4 *dir_lds, ui
         if (BOARDS_PER_LANE == 4 || lane < (uint32_t)TILE_BOARDS / 4u) {  // (with two boards per lane the first 32 lanes carry the tile)
             const uint4 r4 = reinterpret_cast<const uint4 *>(strip)[lane];
             const uint32_t d4 = reinterpret_cast<const uint32_t *>(done_bytes)[lane];
-            if (a.reward) store_x4_through(a.reward + tile0 + 4u * lane, u32x4{r4.x, r4.y, r4.z, r4.w});
-            store_x1_through(a.done + tile0 + 4u * lane, d4);
+            if (through) {
+                if (a.reward) store_x4_through(a.reward + tile0 + 4u * lane, u32x4{r4.x, r4.y, r4.z, r4.w});
+                store_x1_through(a.done + tile0 + 4u * lane, d4);
+            } else {
+                if (a.reward) reinterpret_cast<uint4 *>(a.reward + tile0)[lane] = r4;
+                reinterpret_cast<uint32_t *>(a.done + tile0)[lane] = d4;
+            }
         }
     }
 #endif

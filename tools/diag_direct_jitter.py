@@ -1,12 +1,12 @@
 """How steady is the two-chain overlap of the direct route?  Distribution of the device-side and wall time of many K-step calls
-(2^20 boards, mid-game, host actions).  usage: python tools/diag_direct_jitter.py [K=20] [calls=300]"""
+(2^20 boards, mid-game, host actions).  usage: python tools/diag_direct_jitter.py [K=20] [calls=300]   (ENV2048_LIB=<path>: another build of the library)"""
 import ctypes, sys, time, json, os
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from simulate_2048_amd import capi
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 calls = int(sys.argv[2]) if len(sys.argv) > 2 else 300
-lib = capi.library(); n = 1 << 20
+lib = capi.Library(os.environ['ENV2048_LIB']) if os.environ.get('ENV2048_LIB') else capi.library(); n = 1 << 20
 rng = np.random.default_rng(1)
 b = torch.zeros((n, 16), dtype=torch.uint8, device='cuda'); d = torch.zeros((n,), dtype=torch.uint8, device='cuda'); r = torch.zeros((n,), dtype=torch.int32, device='cuda')
 s = torch.cuda.current_stream().cuda_stream

@@ -25,7 +25,13 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 and not sys.argv[1].startswith(
 if '--churn' in sys.argv:
     import threading
 
-    churn = ctypes.CDLL(str(Path(__file__).resolve().parent / 'libqueue_churn.so'))
+    import subprocess
+
+    churn_lib = Path(__file__).resolve().parent / 'libqueue_churn.so'
+    if not churn_lib.exists():
+        subprocess.run(['gcc', '-O2', '-shared', '-fPIC', str(churn_lib.with_name('queue_churn.c')), '-I/opt/rocm/include', '-L/opt/rocm/lib', '-lhsa-runtime64',
+                        '-o', str(churn_lib)], check=True)
+    churn = ctypes.CDLL(str(churn_lib))
     threading.Thread(target=lambda: churn.queue_churn(1_000_000, 700), daemon=True).start()
 t0 = last = time.time()
 counts = {'calls': 0, 'steps': 0, 'board_steps': 0, 'oracle_checked': 0, 'two_chain_calls': 0, 'busy_stream_calls': 0}
