@@ -301,6 +301,16 @@ typedef struct env2048_direct_info {
 } env2048_direct_info;
 ENV2048_EXPORT int env2048_direct_stats(int device, env2048_direct_info *out);
 ENV2048_EXPORT int env2048_direct_eligible(uint64_t n, uint32_t count, uint32_t flags, int32_t extras);
+/* How the direct route would run a sequence (no device is touched): eligible (as above); the chains (1 or 2) and for each the
+ * boards it steps -- part c = [part_first[c], part_first[c + 1]) -- with the workgroups and boards per lane of its launches; and
+ * the segments the argument blocks are written in (the first is one step, the rest at most segment_steps). */
+typedef struct env2048_direct_plan_info {
+    uint32_t eligible, chains;
+    uint64_t part_first[3];
+    uint32_t part_blocks[2], part_boards_per_lane[2];
+    uint32_t segments, segment_steps;
+} env2048_direct_plan_info;
+ENV2048_EXPORT int env2048_direct_plan(uint64_t n, uint32_t count, uint32_t flags, int32_t extras, env2048_direct_plan_info *out);
 
 /*
  * The reinforce/game form of one transition, fused: boards are int32 tile VALUES (n x 16, in

@@ -63,6 +63,13 @@ class HelperInfo(ctypes.Structure):
     _fields_ = [('created', _u32), ('spin_us', _u32), ('jobs', _u64), ('cpu_ns', _u64)]
 
 
+class DirectPlanInfo(ctypes.Structure):
+    """``env2048_direct_plan_info`` of include/env2048.h."""
+
+    _fields_ = [('eligible', _u32), ('chains', _u32), ('part_first', _u64 * 3), ('part_blocks', _u32 * 2), ('part_boards_per_lane', _u32 * 2),
+                ('segments', _u32), ('segment_steps', _u32)]
+
+
 class DirectInfo(ctypes.Structure):
     """``env2048_direct_info`` of include/env2048.h: the direct-dispatch route of env2048_step_sequence on one device."""
 
@@ -97,6 +104,7 @@ PROTOTYPES = {
     'env2048_helper_stats': (_c_int, [_c_int, ctypes.POINTER(HelperInfo)]),
     'env2048_direct_stats': (_c_int, [_c_int, ctypes.POINTER(DirectInfo)]),
     'env2048_direct_eligible': (_c_int, [_u64, _u32, _u32, ctypes.c_int32]),
+    'env2048_direct_plan': (_c_int, [_u64, _u32, _u32, ctypes.c_int32, ctypes.POINTER(DirectPlanInfo)]),
     'env2048_step_state_i32': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _u64, _u64]),
     'env2048_step_state_i32_to': (_c_int, [_c_int, _ptr, _u64, _u64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _u64,
                                             _u64]),
@@ -259,6 +267,16 @@ class Library:
         if rc < 0:
             raise Env2048Error(rc, self.last_error())
         return rc == 1
+
+    def direct_plan(self, n: int, count: int, flags: int, extras: bool = False) -> dict:
+        """How the direct route would run a sequence: {'eligible', 'chains', 'parts': [(first board, boards, workgroups, boards per lane)],
+        'segments', 'segment_steps'}.  No device call."""
+        info = DirectPlanInfo()
+        self._check(self._dll.env2048_direct_plan(n, count, flags, 1 if extras else 0, ctypes.byref(info)))
+        parts = [(int(info.part_first[c]), int(info.part_first[c + 1] - info.part_first[c]), int(info.part_blocks[c]), int(info.part_boards_per_lane[c]))
+                 for c in range(info.chains)]
+        return {'eligible': bool(info.eligible), 'chains': int(info.chains), 'parts': parts, 'segments': int(info.segments),
+                'segment_steps': int(info.segment_steps)}
 
     def helper_stats(self, device: int) -> dict:
         """The helper thread of ``device`` (env2048_step_sequence's second chain): {'created', 'spin_us', 'jobs', 'cpu_ns'}.

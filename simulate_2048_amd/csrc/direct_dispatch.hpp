@@ -380,6 +380,39 @@ inline bool eligible(uint64_t n, uint32_t count, uint32_t flags, bool extras)
 }
 inline int chains_for(uint64_t n) { return n >= TWO_CHAINS_MIN_BOARDS ? CHAINS : 1; }
 
+// How a batch of n boards is cut into the parts the chains step (pure; env2048_direct_plan reports it): one part below
+// TWO_CHAINS_MIN_BOARDS, else two, the second starting on a block boundary of the large tiling; a part's tiling follows ITS size, as a
+// launch of that size would.  false: a part would need more workgroups than the owner table holds (never for n <= RESIDENT_MAX_BOARDS).
+struct Parts {
+    int chains;
+    uint64_t first[CHAINS + 1];  // part c = boards [first[c], first[c + 1])
+    bool small[CHAINS];
+    uint32_t blocks[CHAINS];
+};
+inline bool plan_parts(uint64_t n, Parts *p)
+{
+    p->chains = chains_for(n);
+    const uint64_t half = p->chains == 2 ? (n / 2) / block_boards(BOARDS_PER_LANE) * block_boards(BOARDS_PER_LANE) : n;
+    p->first[0] = 0;
+    p->first[1] = p->chains == 2 ? half : n;
+    p->first[p->chains] = n;
+    for (int c = 0; c < p->chains; ++c) {
+        const uint64_t n_part = p->first[c + 1] - p->first[c];
+        p->small[c] = plan_small_tiling(n_part, 0);
+        const int bpl = p->small[c] ? 1 : BOARDS_PER_LANE;
+        p->blocks[c] = (uint32_t)((n_part + block_boards(bpl) - 1) / block_boards(bpl));
+        if (p->blocks[c] > MAX_BLOCKS_PER_PART) return false;
+    }
+    return true;
+}
+// Steps of the segment that starts at step `first` of a `count`-step sequence: the first segment is ONE step (its argument blocks
+// are flushed and its packets ring the doorbells before the rest of the blocks are written: the device starts 2-3 us earlier), the
+// others up to SEGMENT_STEPS.
+inline uint32_t segment_steps(uint32_t first, uint32_t count)
+{
+    return first == 0 ? 1u : (count - first < SEGMENT_STEPS ? count - first : SEGMENT_STEPS);
+}
+
 struct SequenceArgs {
     uint64_t n, env_base;
     uint8_t *boards;
@@ -431,27 +464,15 @@ inline int step_sequence(int device, hipStream_t stream, const SequenceArgs &a)
     if (timeline) t_stream = now_us();
     static const long pretend_moved_at = getenv("ENV2048_DIRECT_TEST_MOVE_AT") ? atol(getenv("ENV2048_DIRECT_TEST_MOVE_AT")) : -1;  // (test hook)
     const bool random_actions = (a.flags & ENV2048_FLAG_RANDOM_ACTIONS) != 0u;
-    const int chains = chains_for(a.n);
-    // parts: whole blocks of the tiling each part runs in (a part's tiling follows ITS size, as a launch of that size would)
-    uint64_t part_first[CHAINS + 1];
-    bool part_small[CHAINS];
-    uint32_t part_blocks[CHAINS];
-    {
-        const uint64_t half = chains == 2 ? (a.n / 2) / block_boards(BOARDS_PER_LANE) * block_boards(BOARDS_PER_LANE) : a.n;
-        part_first[0] = 0;
-        part_first[1] = chains == 2 ? half : a.n;
-        part_first[chains] = a.n;
-        for (int c = 0; c < chains; ++c) {
-            const uint64_t n_part = part_first[c + 1] - part_first[c];
-            part_small[c] = plan_small_tiling(n_part, 0);
-            const int bpl = part_small[c] ? 1 : BOARDS_PER_LANE;
-            part_blocks[c] = (uint32_t)((n_part + block_boards(bpl) - 1) / block_boards(bpl));
-            if (part_blocks[c] > MAX_BLOCKS_PER_PART) {
-                ++d->declined;
-                return NOT_TAKEN;
-            }
-        }
+    Parts parts;
+    if (!plan_parts(a.n, &parts)) {
+        ++d->declined;
+        return NOT_TAKEN;
     }
+    const uint64_t *const part_first = parts.first;
+    const bool *const part_small = parts.small;
+    const uint32_t *const part_blocks = parts.blocks;
+    const int chains = parts.chains;
     uint32_t kernel_flags = (a.flags & (ENV2048_FLAG_AUTO_RESET | ENV2048_FLAG_RANDOM_ACTIONS));  // plain stores
     if (!misaligned(a.reward, 16) && !misaligned(a.done, 4) && a.row_stride % 4 == 0) kernel_flags |= INTERNAL_FLAG_WIDE_OUTPUTS;  // reward / done rows leave as 16-byte / 4-byte stores
     *d->placement_error = 0;
@@ -460,10 +481,8 @@ inline int step_sequence(int device, hipStream_t stream, const SequenceArgs &a)
     bool timed_out = false;
 
     hsa_signal_t first_signal_used[CHAINS] = {}, last_signal_used[CHAINS] = {};  // (timing: what the first / last packet of each chain signals)
-    // Segments: the first is ONE step (its argument blocks are flushed and its packets ring the doorbells before the rest of the
-    // blocks are written: the device starts 2-3 us earlier), the others up to SEGMENT_STEPS.
     for (uint32_t first = 0, steps = 0; first < a.count && !timed_out; first += steps) {
-        steps = first == 0 ? 1u : (a.count - first < SEGMENT_STEPS ? a.count - first : SEGMENT_STEPS);
+        steps = segment_steps(first, a.count);
         const bool first_segment = first == 0, last_segment = first + steps == a.count;
         uint32_t segment_slot[CHAINS];
         // 1. the argument blocks of this segment (the part of the ring they go to is free once the segment that used it last is done)

@@ -840,6 +840,25 @@ int env2048_direct_eligible(uint64_t n, uint32_t count, uint32_t flags, int32_t 
     return direct::eligible(n, count, flags, extras != 0) ? 1 : 0;
 }
 
+int env2048_direct_plan(uint64_t n, uint32_t count, uint32_t flags, int32_t extras, env2048_direct_plan_info *out)
+{
+    if (!out) return fail(ENV2048_ERR_INVALID_ARG, "env2048_direct_plan: out is NULL");
+    if (flags & ~STEP_FLAGS) return fail(ENV2048_ERR_INVALID_ARG, "env2048_direct_plan: unknown flag bits 0x%x", flags);
+    memset(out, 0, sizeof *out);
+    direct::Parts parts;
+    out->eligible = direct::eligible(n, count, flags, extras != 0) && direct::plan_parts(n, &parts) ? 1u : 0u;
+    if (!out->eligible) return ENV2048_OK;
+    out->chains = (uint32_t)parts.chains;
+    for (int c = 0; c <= parts.chains; ++c) out->part_first[c] = parts.first[c];
+    for (int c = 0; c < parts.chains; ++c) {
+        out->part_blocks[c] = parts.blocks[c];
+        out->part_boards_per_lane[c] = parts.small[c] ? 1u : (uint32_t)BOARDS_PER_LANE;
+    }
+    out->segment_steps = direct::SEGMENT_STEPS;
+    for (uint32_t first = 0; first < count; first += direct::segment_steps(first, count)) ++out->segments;
+    return ENV2048_OK;
+}
+
 int env2048_step_sequence_plan(uint64_t n, uint32_t count, uint32_t flags, int32_t *chains, int32_t *boards_per_lane, int32_t *write_through)
 {
     if (flags & ~STEP_FLAGS) return fail(ENV2048_ERR_INVALID_ARG, "env2048_step_sequence_plan: unknown flag bits 0x%x", flags);

@@ -402,6 +402,9 @@ class OracleLibrary:
     def direct_eligible(self, n, count, flags, extras=False):
         return False
 
+    def direct_plan(self, n, count, flags, extras=False):
+        return {'eligible': False, 'chains': 0, 'parts': [], 'segments': 0, 'segment_steps': 0}
+
     def expand_scratch_words(self, n):
         return (n + capi.EXPAND_OFFSETS_BLOCK - 1) // capi.EXPAND_OFFSETS_BLOCK + 1
 

@@ -39,6 +39,41 @@ def test_eligibility_is_a_function_of_sizes_and_flags():
     assert f'#define ENV2048_FLAG_NO_DIRECT {NO_DIRECT}u' in header
 
 
+def test_the_plan_of_a_direct_sequence_covers_the_batch_and_the_steps():
+    """(no device) env2048_direct_plan over every size class: the parts tile [0, n) exactly, the second starts on a block boundary of
+    the large tiling, every part's workgroups cover it in its own tiling without a whole block to spare, one chain below 2^18 boards,
+    and the segments are 1 + ceil((K - 1) / 256)."""
+    from hypothesis import given, settings
+    from hypothesis import strategies as st
+
+    lib = capi.Library()
+    sizes = st.one_of(st.integers(1, 5000), st.integers((1 << 18) - 3000, (1 << 18) + 3000), st.integers(1 << 18, 1 << 21),
+                      st.sampled_from([1, 511, 512, 513, 2048, 65536, 1 << 18, 1 << 19, (1 << 19) + 1, 1 << 20, (1 << 21) - 1, 1 << 21]))
+
+    @settings(max_examples=400, deadline=None)
+    @given(n=sizes, count=st.integers(8, 5000), random_actions=st.booleans())
+    def check(n, count, random_actions):
+        flags = AUTO | (RANDOM if random_actions else 0)
+        plan = lib.direct_plan(n, count, flags)
+        assert plan['eligible'] == lib.direct_eligible(n, count, flags) and plan['eligible']
+        assert plan['chains'] == (2 if n >= 1 << 18 else 1) == len(plan['parts'])
+        at = 0
+        for k, (first, boards, blocks, bpl) in enumerate(plan['parts']):
+            assert first == at and boards > 0
+            at += boards
+            block = 512 * bpl   # boards per workgroup: 8 waves x 64 lanes x boards per lane
+            assert bpl == (1 if boards <= 1 << 18 else 4) == lib.step_plan(boards, 0)['boards_per_lane']
+            assert (blocks - 1) * block < boards <= blocks * block and blocks <= 2048
+            if k == 1:
+                assert first % 2048 == 0 and abs(first - n // 2) < 2048   # the halves differ by less than a block
+        assert at == n
+        assert plan['segments'] == 1 + -(-(count - 1) // 256) and plan['segment_steps'] == 256
+
+    check()
+    assert lib.direct_plan(1 << 22, 20, AUTO) == {'eligible': False, 'chains': 0, 'parts': [], 'segments': 0, 'segment_steps': 0}
+    assert not lib.direct_plan(1 << 20, 20, AUTO, extras=True)['eligible']
+
+
 gpu = pytest.mark.gpu
 
 
