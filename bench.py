@@ -325,6 +325,8 @@ def build_roofline(args, lib, n: int, flags: int, launch_s: float, obs_bytes: in
     if direct:  # the library's own queues: two half-batch chains of resident launches (csrc/direct_dispatch.hpp)
         plan = dict(plan, route='direct', chains=route['chains'], write_through=False,
                     boards_per_lane=lib.step_plan(n if route['chains'] == 1 else n - (n // 2) // 2048 * 2048, 0)['boards_per_lane'])
+        if route.get('device_s_per_step') and not 0.5 * launch_s <= route['device_s_per_step'] <= 1.02 * launch_s:
+            route = dict(route, device_s_per_step=None, device_time_rejected='the dispatch timestamps disagree with the event time around the call')
         if route.get('device_s_per_step'):
             event_s, launch_s = launch_s, route['device_s_per_step']
     else:

@@ -480,7 +480,19 @@ inline int step_sequence(int device, hipStream_t stream, const SequenceArgs &a)
     const hsa_signal_t no_signal{0};
     bool timed_out = false;
 
-    hsa_signal_t first_signal_used[CHAINS] = {}, last_signal_used[CHAINS] = {};  // (timing: what the first / last packet of each chain signals)
+    // (timing: what the first / last packet of each chain signals; the first packet's start is read before its signal -- the one of the
+    // ring part its one-step segment occupies -- is given to a later segment of a long sequence)
+    hsa_signal_t first_signal_used[CHAINS] = {}, last_signal_used[CHAINS] = {};
+    uint32_t first_slot[CHAINS] = {};
+    uint64_t first_start[CHAINS] = {};
+    bool first_start_known[CHAINS] = {};
+    auto note_first_start = [&](int c) {
+        hsa_amd_profiling_dispatch_time_t t{};
+        if (d->timing && !first_start_known[c] && first_signal_used[c].handle &&
+            hsa_amd_profiling_get_dispatch_time(d->gpu, first_signal_used[c], &t) == HSA_STATUS_SUCCESS)
+            first_start[c] = t.start;
+        first_start_known[c] = true;
+    };
     for (uint32_t first = 0, steps = 0; first < a.count && !timed_out; first += steps) {
         steps = segment_steps(first, a.count);
         const bool first_segment = first == 0, last_segment = first + steps == a.count;
@@ -491,7 +503,9 @@ inline int step_sequence(int device, hipStream_t stream, const SequenceArgs &a)
             if (d->segment_pending[c][segment_slot[c]]) {
                 if (!wait_signal(d->segment_signal[c][segment_slot[c]], 200.0, 30e6)) timed_out = true;
                 d->segment_pending[c][segment_slot[c]] = false;
+                if (!first_segment && segment_slot[c] == first_slot[c]) note_first_start(c);  // (before this slot's signal is rearmed below)
             }
+            if (first_segment) first_slot[c] = segment_slot[c];
         }
         if (timed_out) break;
         for (int c = 0; c < chains; ++c) {
@@ -562,7 +576,9 @@ inline int step_sequence(int device, hipStream_t stream, const SequenceArgs &a)
         uint64_t longest = 0;
         for (int c = 0; c < chains; ++c) {
             hsa_amd_profiling_dispatch_time_t t0{}, t1{};
-            const hsa_status_t s0 = hsa_amd_profiling_get_dispatch_time(d->gpu, first_signal_used[c], &t0);
+            note_first_start(c);
+            t0.start = first_start[c];
+            const hsa_status_t s0 = first_start[c] ? HSA_STATUS_SUCCESS : HSA_STATUS_ERROR;
             const hsa_status_t s1 = hsa_amd_profiling_get_dispatch_time(d->gpu, last_signal_used[c], &t1);
             if (debug)
                 fprintf(stderr, "[direct] chain %d: first packet %llu .. %llu (status %d), last packet %llu .. %llu (status %d), %llu ticks/s\n", c,

@@ -174,6 +174,8 @@ def test_sequences_longer_than_the_argument_ring(lib, route):
     start = midgame(lib, n)
     flags = AUTO | RANDOM
     b1, r1, d1 = run(lib, start, T, flags, 0, 0, None)
+    gpu_ns = lib.direct_stats(DEV)['last_gpu_ns']
+    assert gpu_ns == 0 or 1e3 * T < gpu_ns < 1e9, gpu_ns   # first packet's start .. last packet's end, although the first packet's signal was reused
     b2, r2, d2 = run(lib, start, T, flags | NO_DIRECT, 0, 0, None)
     torch.cuda.synchronize()
     assert torch.equal(b1, b2) and torch.equal(r1, r2) and torch.equal(d1, d2)
