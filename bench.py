@@ -1172,9 +1172,9 @@ def legal_obs_leg(torch, lib, device, device_index, h, n: int = 1 << 20, K: int 
 def stream_route_legs(torch, lib, device, device_index, h) -> dict:
     """The legs of other_configs on the STREAM route (ENV2048_FLAG_NO_DIRECT: HIP launches) -- configs[1] as 2000 launches,
     configs[4] as 2 x 512 launches, configs[2] as one K = 200 sequence (two chains and one) with the helper thread's cost.  Run by
-    run_rank BEFORE the first call that could start the direct route: once the library's queues exist, two HIP streams of the
-    process can end up on one hardware pipe (a 2-chain stream sequence next to them measured 11-24 us per step instead of 6.6;
-    DESIGN section 4, "pipes"), which would misstate the stream route as a process without the direct route sees it."""
+    run_rank BEFORE anything else of the run: the two-chain stream sequence needs its two HIP streams on two hardware pipes, and
+    a process that has created more than four HIP streams (the later legs of this file do) puts two of them on one (11 us per
+    step instead of 6.6-7, with or without the library's own queues: tools/diag_pipe_sharing.py, profiles/r05_w_*)."""
     from simulate_2048_amd import capi
     from simulate_2048_amd.batch import BatchedEnv2048
 

@@ -61,8 +61,10 @@ constexpr int CHAINS = 2;
 // Hardware queues are dealt to the four pipes of the compute engine in the order they are created, and two queues on ONE pipe do
 // not run side by side (two chains on queues created four apart: 14-18 us per step instead of 5.4, profiles/r05_j_*).  The
 // library therefore takes a whole round of four -- it uses the first two -- so that the HIP runtime's own queues, created before
-// or after, keep the pipes they would have had without it (with only two, a process's third HIP stream landed on the pipe of its
-// first: a 2-chain stream sequence next to the library's queues took 23.6 us per step).
+// or after, keep the pipes they would have had without it: with only two, a process's third HIP stream landed on the pipe of its
+// first (a 2-chain stream sequence next to the library's queues took 23.6 us per step); with four the same sequence takes 7.0 us
+// with the library's queues and 7.25 without (tools/diag_pipe_sharing.py, profiles/r05_w_*; a process with more than four HIP
+// streams of its own collides with itself either way: 11 us).
 constexpr int QUEUES_CREATED = 4;
 constexpr uint32_t QUEUE_PACKETS = 1024;
 constexpr uint32_t SEGMENT_STEPS = 256;               // argument blocks are written (and flushed) a segment at a time
