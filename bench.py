@@ -1042,7 +1042,7 @@ def other_configs(torch, lib, device, device_index, h, stream_side=None) -> dict
     }
     del a, b
     out['configs[2]_long_sequence'] = long_sequence_leg(torch, lib, device, device_index, h, stream_side=stream_side)
-    out['configs[2]_with_legal_obs'] = legal_obs_leg(torch, lib, device, device_index, h)
+    out['configs[2]_with_legal_obs'] = legal_obs_leg(torch, lib, device, device_index, h, stream_side=stream_side)
     return out
 
 
@@ -1143,7 +1143,7 @@ def long_sequence_leg(torch, lib, device, device_index, h, n: int = 1 << 20, K: 
     return out
 
 
-def legal_obs_leg(torch, lib, device, device_index, h, n: int = 1 << 20, K: int = 200) -> dict:
+def legal_obs_leg(torch, lib, device, device_index, h, n: int = 1 << 20, K: int = 200, stream_side=None, stream_only: bool = False) -> dict:
     """What the reference's caller needs EVERY move (reinforce/training/self_play.py:316-317,354): transition + legal mask +
     observation of the new boards, from the EXTRAS variant of the step kernel in the same launch -- with float32 and with
     bfloat16 observations (the same values: e/16 is exact in both)."""
@@ -1153,18 +1153,28 @@ def legal_obs_leg(torch, lib, device, device_index, h, n: int = 1 << 20, K: int 
     for name, dtype, obs_bytes in (('obs_f32', torch.float32, 4), ('obs_bf16', torch.bfloat16, 2)):
         env, pool = _midgame_env(torch, device, n, with_legal=True, with_obs=True, obs_dtype=dtype)
         table = (ctypes.c_void_p * K)(*[pool[t & 7].data_ptr() for t in range(K)])
-        wall, ev = _timed_sequence(torch, lib, stream, device_index, h, env, table, K, env.flags, 1000, legal=env.legal.data_ptr(),
+        from simulate_2048_amd import capi
+
+        flags = env.flags | (capi.FLAG_NO_DIRECT if stream_only else 0)
+        calls_before = 0 if stream_only else lib.direct_stats(device_index)['calls']
+        wall, ev = _timed_sequence(torch, lib, stream, device_index, h, env, table, K, flags, 1000, legal=env.legal.data_ptr(),
                                    obs=env.obs.data_ptr())
+        took_direct = (not stream_only) and lib.direct_stats(device_index)['calls'] > calls_before
         per_board = ALGO_BYTES_PER_STEP + 1 + 16 * obs_bytes
         gbs = per_board * n / (ev / K) / 1e9
-        plan = lib.step_sequence_plan(n, K, env.flags)
+        plan = dict(lib.step_sequence_plan(n, K, flags), **({'route': 'direct', 'chains': 2, 'write_through': False} if took_direct else {'route': 'stream'}))
         out[name] = {'launch_plan': plan, 'event_us_per_step': ev / K * 1e6, 'wall_us_per_step': wall / K * 1e6, 'value': n * K / wall,
                      'unit': 'board-steps/s',
-                     'roofline': {'bound': 'hbm', 'kernel': f'step_kernel<true, false, {plan["boards_per_lane"]}>',
+                     'on_the_stream_route': None if not stream_side else (stream_side.get('configs[2]_with_legal_obs') or {}).get(name),
+                     'roofline': {'bound': 'hbm', 'kernel': (f'env2048_step_resident_large_extras' if took_direct else
+                                                             f'step_kernel<true, false, {plan["boards_per_lane"]}>'),
                                   'algorithmic_bytes_per_board_step': per_board, 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                   'frac': gbs / HBM_PEAK_GBS,
-                                  'regime': f'cache-resident equivalent: {n * (16 + 8 + 4 + 1 + 1 + 16 * obs_bytes) / 2**20:.0f} MiB working set < 256 MiB '
-                                            f'Infinity Cache (algorithmic bytes / event time per step)'}}
+                                  'regime': ('L2-resident boards, observation rows written through: an equivalent (algorithmic bytes / event time per '
+                                             'step) -- what crosses the fabric per board-step is the action, the reward / done / legal bytes and the '
+                                             f'{16 * obs_bytes} observation bytes' if took_direct else
+                                             f'cache-resident equivalent: {n * (16 + 8 + 4 + 1 + 1 + 16 * obs_bytes) / 2**20:.0f} MiB working set < 256 MiB '
+                                             f'Infinity Cache (algorithmic bytes / event time per step)')}}
         del env, pool
     return out
 
@@ -1238,6 +1248,7 @@ def stream_route_legs(torch, lib, device, device_index, h) -> dict:
                          'note': 'the same call on the stream route: 2 x 512 HIP launches (two streams, helper thread)'}
     del a, start, reward_rows, done_rows
     out['configs[2]_long_sequence'] = long_sequence_leg(torch, lib, device, device_index, h, stream_only=True)
+    out['configs[2]_with_legal_obs'] = legal_obs_leg(torch, lib, device, device_index, h, stream_only=True)
     return out
 
 

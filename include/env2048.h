@@ -227,8 +227,8 @@ ENV2048_EXPORT int env2048_step_sequence_plan(uint64_t n, uint32_t count, uint32
  * batches beyond the Infinity Cache lose, hence the bounds).  Results are bit-identical.  env2048_step_sequence_plan reports
  * the decision.
  *
- * The direct route.  A sequence of count >= 8 steps (ENV2048_DIRECT_MIN_STEPS) over n <= 2^21 boards that asks for no legal /
- * obs output (and carries none of NO_DIRECT, STORES_WRITE_THROUGH, TILE_*), on a stream that is not being captured, does not go
+ * The direct route.  A sequence of count >= 8 steps (ENV2048_DIRECT_MIN_STEPS) over n <= 2^21 boards (with none of NO_DIRECT,
+ * STORES_WRITE_THROUGH, TILE_* among its flags; any outputs), on a stream that is not being captured, does not go
  * through the HIP runtime at all: the library writes the `count` kernel-dispatch packets of each chain (two half-batch chains
  * from 2^18 boards, else one) into user-mode queues of its own -- created on a device's first such call together with a second
  * copy of the step kernels loaded through ROCr -- from the calling thread alone (0.13-0.25 us of host time per packet: no
@@ -292,7 +292,7 @@ ENV2048_EXPORT int env2048_helper_stats(int device, env2048_helper_info *out);
  * captured stream), sequences that had to be run again on the stream route (see env2048_step_sequence), the number of chains
  * of the last sequence and its duration ON THE DEVICE (first packet's start to last packet's end, from the queues' dispatch
  * timestamps; 0 when ENV2048_DIRECT_TIMING=0).  env2048_direct_eligible answers, without touching a device, whether a call
- * of this shape would be offered to the route (extras != 0: legal / obs / max_exp / normalised reward are asked for).
+ * of this shape would be offered to the route (`extras` is ignored: the route serves legal / obs / the normalised reward too).
  */
 typedef struct env2048_direct_info {
     uint32_t available, last_chains;

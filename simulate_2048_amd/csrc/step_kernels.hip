@@ -235,7 +235,7 @@ __device__ __forceinline__ void step_block(const StepArgs &a, uint4 *dir_lds, ui
 #endif
         }
         if (EXTRAS && FULL && a.obs)  // (the step words were copied to registers: the strip is free)
-            store_obs_any_coalesced(a.obs, strip, tile0 + 64u * j, a.n, lane, bd[j], auto_reset && done[j], through,
+            store_obs_any_coalesced(a.obs, strip, tile0 + 64u * j, a.n, lane, bd[j], auto_reset && done[j], through || RESIDENT,
                                     obs_format(a.flags));
     };
 
@@ -412,10 +412,11 @@ __global__ void advance_counter_kernel(unsigned long long *counter, unsigned lon
 // chain.  "Keeps landing on the same XCD" is checked, not assumed -- see step_resident_body.
 constexpr uint32_t RESIDENT_PRETEND_MOVED = 2u;  // (test hook of direct_dispatch.hpp) this launch's workgroups claim another XCD
 
-template <bool RANDOM, int BPL, bool FIRST>
+template <bool EXTRAS, bool RANDOM, int BPL, bool FIRST>
 __device__ __forceinline__ void step_resident_body(uint8_t *boards, const uint8_t *actions, uint64_t n, uint64_t env_base, uint32_t flags,
                                                    uint32_t seed_lo, uint32_t seed_hi, uint32_t step_lo, uint32_t step_hi, int32_t *reward,
-                                                   uint8_t *done, uint32_t mode, uint32_t *owner, uint32_t *placement_error, uint8_t *snapshot)
+                                                   uint8_t *done, uint32_t mode, uint32_t *owner, uint32_t *placement_error, uint8_t *snapshot,
+                                                   uint8_t *legal, void *obs)
 {
     // Where am I, and is that where this block's boards live?  The first launch of a chain (it reads the boards from memory:
     // its packet carries the acquire) writes the answer through to memory; every later launch reads it back past the caches it
@@ -430,7 +431,8 @@ __device__ __forceinline__ void step_resident_body(uint8_t *boards, const uint8_
     } else {
         home = __hip_atomic_load(owner + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    StepArgs a{n, env_base, boards, actions, reward, done, nullptr, nullptr, RngKey{seed_lo, seed_hi, step_lo, step_hi}, flags, nullptr};
+    StepArgs a{n, env_base, boards, actions, reward, done, EXTRAS ? legal : nullptr, EXTRAS ? obs : nullptr,
+               RngKey{seed_lo, seed_hi, step_lo, step_hi}, flags, nullptr};
     a.snapshot = snapshot;
     __shared__ uint4 dir_lds[8];
     __shared__ __attribute__((aligned(16))) uint32_t word_lds[WAVES_PER_BLOCK][word_strip_words(BPL)];
@@ -438,9 +440,9 @@ __device__ __forceinline__ void step_resident_body(uint8_t *boards, const uint8_
     __shared__ uint16_t reset_slot[block_boards(BPL)];
     const uint64_t block0 = (uint64_t)blockIdx.x * block_boards(BPL);
     if (block0 + block_boards(BPL) <= a.n)
-        step_block<false, true, RANDOM, BPL, true, FIRST>(a, dir_lds, word_lds, &queue_state, reset_slot);
+        step_block<EXTRAS, true, RANDOM, BPL, true, FIRST>(a, dir_lds, word_lds, &queue_state, reset_slot);
     else
-        step_block<false, false, RANDOM, BPL, true, FIRST>(a, dir_lds, word_lds, &queue_state, reset_slot);
+        step_block<EXTRAS, false, RANDOM, BPL, true, FIRST>(a, dir_lds, word_lds, &queue_state, reset_slot);
     if (home != xcc_id && threadIdx.x == 0u)  // (block + 1, the XCD this workgroup ran on, the XCD its boards live on)
         __hip_atomic_store(placement_error, (1u + (blockIdx.x & 0xffffu)) | (xcc_id << 16) | ((home & 0xffu) << 24), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_SYSTEM);
@@ -597,24 +599,30 @@ inline bool want_two_chains(uint64_t n, uint32_t count, uint32_t flags) { return
 // [step-kernel-source-begin]
 // The entry points of the direct-dispatch code object carry C names: direct_dispatch.hpp finds them by name in the image it
 // loads through ROCr (the HIP runtime never launches them).
-#define ENV2048_RESIDENT_KERNEL(NAME, RANDOM, BPL, FIRST)                                                                                            \
+#define ENV2048_RESIDENT_KERNEL(NAME, EXTRAS, RANDOM, BPL, FIRST)                                                                                    \
     extern "C" __global__ __launch_bounds__(BLOCK) void NAME(uint8_t *boards, const uint8_t *actions, uint64_t n, uint64_t env_base, uint32_t flags, \
                                                              uint32_t seed_lo, uint32_t seed_hi, uint32_t step_lo, uint32_t step_hi, int32_t *reward, \
                                                              uint8_t *done, uint32_t mode, uint32_t *owner, uint32_t *placement_error,          \
-                                                             uint8_t *snapshot)                                                                 \
+                                                             uint8_t *snapshot, uint8_t *legal, void *obs)                                      \
     {                                                                                                                                           \
-        step_resident_body<RANDOM, BPL, FIRST>(boards, actions, n, env_base, flags, seed_lo, seed_hi, step_lo, step_hi, reward, done, mode, owner,     \
-                                        placement_error, snapshot);                                                                             \
+        step_resident_body<EXTRAS, RANDOM, BPL, FIRST>(boards, actions, n, env_base, flags, seed_lo, seed_hi, step_lo, step_hi, reward, done,   \
+                                                       mode, owner, placement_error, snapshot, legal, obs);                                     \
     }
-// (_first: the launch that opens a chain -- it records every workgroup's XCD and copies the boards it loads into the snapshot)
-ENV2048_RESIDENT_KERNEL(env2048_step_resident_small, false, 1, false)
-ENV2048_RESIDENT_KERNEL(env2048_step_resident_small_random, true, 1, false)
-ENV2048_RESIDENT_KERNEL(env2048_step_resident_large, false, BOARDS_PER_LANE, false)
-ENV2048_RESIDENT_KERNEL(env2048_step_resident_large_random, true, BOARDS_PER_LANE, false)
-ENV2048_RESIDENT_KERNEL(env2048_step_resident_small_first, false, 1, true)
-ENV2048_RESIDENT_KERNEL(env2048_step_resident_small_random_first, true, 1, true)
-ENV2048_RESIDENT_KERNEL(env2048_step_resident_large_first, false, BOARDS_PER_LANE, true)
-ENV2048_RESIDENT_KERNEL(env2048_step_resident_large_random_first, true, BOARDS_PER_LANE, true)
+// (_first: the launch that opens a chain -- it records every workgroup's XCD and copies the boards it loads into the snapshot;
+// _extras: legal mask / observation / log-normalised reward, the observation rows leaving write-through so that they do not push
+// the boards out of the L2s)
+#define ENV2048_RESIDENT_FAMILY(STEM, EXTRAS)                                                      \
+    ENV2048_RESIDENT_KERNEL(env2048_step_resident_small##STEM, EXTRAS, false, 1, false)            \
+    ENV2048_RESIDENT_KERNEL(env2048_step_resident_small##STEM##_random, EXTRAS, true, 1, false)    \
+    ENV2048_RESIDENT_KERNEL(env2048_step_resident_large##STEM, EXTRAS, false, BOARDS_PER_LANE, false) \
+    ENV2048_RESIDENT_KERNEL(env2048_step_resident_large##STEM##_random, EXTRAS, true, BOARDS_PER_LANE, false) \
+    ENV2048_RESIDENT_KERNEL(env2048_step_resident_small##STEM##_first, EXTRAS, false, 1, true)     \
+    ENV2048_RESIDENT_KERNEL(env2048_step_resident_small##STEM##_random_first, EXTRAS, true, 1, true) \
+    ENV2048_RESIDENT_KERNEL(env2048_step_resident_large##STEM##_first, EXTRAS, false, BOARDS_PER_LANE, true) \
+    ENV2048_RESIDENT_KERNEL(env2048_step_resident_large##STEM##_random_first, EXTRAS, true, BOARDS_PER_LANE, true)
+ENV2048_RESIDENT_FAMILY(, false)
+ENV2048_RESIDENT_FAMILY(_extras, true)
+#undef ENV2048_RESIDENT_FAMILY
 #undef ENV2048_RESIDENT_KERNEL
 
 // [step-kernel-source-end]
@@ -733,8 +741,8 @@ int env2048_step_sequence(int device, void *stream, uint64_t n, uint64_t env_bas
     hipStream_t main_stream = (hipStream_t)stream;
     // The direct route (direct_dispatch.hpp): the sequence as AQL packets on the library's own queues, boards resident in the
     // XCD L2s between the first and the last launch.  NOT_TAKEN: nothing was enqueued, the stream route below runs the call.
-    if (direct::eligible(n, count, flags, legal || obs || (flags & ENV2048_FLAG_REWARD_LOG2_F32))) {
-        const direct::SequenceArgs seq{n, env_base, boards, actions, reward, done, row_stride, seed, step_index, count, flags};
+    if (direct::eligible(n, count, flags)) {
+        const direct::SequenceArgs seq{n, env_base, boards, actions, reward, done, legal, obs, row_stride, seed, step_index, count, flags};
         const int rc = direct::step_sequence(device, main_stream, seq);
         if (rc != direct::NOT_TAKEN && rc != direct::RERUN) return rc;  // (RERUN: the boards are as before the call -- the launches below redo it)
     }
@@ -837,7 +845,8 @@ int env2048_direct_stats(int device, env2048_direct_info *out)
 int env2048_direct_eligible(uint64_t n, uint32_t count, uint32_t flags, int32_t extras)
 {
     if (flags & ~STEP_FLAGS) return fail(ENV2048_ERR_INVALID_ARG, "env2048_direct_eligible: unknown flag bits 0x%x", flags);
-    return direct::eligible(n, count, flags, extras != 0) ? 1 : 0;
+    (void)extras;  // (since ABI 5 the route serves legal / obs / the normalised reward too)
+    return direct::eligible(n, count, flags) ? 1 : 0;
 }
 
 int env2048_direct_plan(uint64_t n, uint32_t count, uint32_t flags, int32_t extras, env2048_direct_plan_info *out)
@@ -846,7 +855,8 @@ int env2048_direct_plan(uint64_t n, uint32_t count, uint32_t flags, int32_t extr
     if (flags & ~STEP_FLAGS) return fail(ENV2048_ERR_INVALID_ARG, "env2048_direct_plan: unknown flag bits 0x%x", flags);
     memset(out, 0, sizeof *out);
     direct::Parts parts;
-    out->eligible = direct::eligible(n, count, flags, extras != 0) && direct::plan_parts(n, &parts) ? 1u : 0u;
+    (void)extras;
+    out->eligible = direct::eligible(n, count, flags) && direct::plan_parts(n, &parts) ? 1u : 0u;
     if (!out->eligible) return ENV2048_OK;
     out->chains = (uint32_t)parts.chains;
     for (int c = 0; c <= parts.chains; ++c) out->part_first[c] = parts.first[c];

@@ -22,12 +22,12 @@ AUTO, RANDOM, NO_DIRECT = capi.FLAG_AUTO_RESET, capi.FLAG_RANDOM_ACTIONS, capi.F
 
 
 def test_eligibility_is_a_function_of_sizes_and_flags():
-    """(no device) what is offered to the route: >= 8 steps, <= 2^21 boards, plain outputs, no hint that contradicts it."""
+    """(no device) what is offered to the route: >= 8 steps, <= 2^21 boards, any outputs, no hint that contradicts it."""
     lib = capi.Library()
     assert lib.direct_eligible(1 << 20, 20, AUTO) and lib.direct_eligible(1 << 16, 8, AUTO | RANDOM) and lib.direct_eligible(1 << 21, 200, 0)
     assert not lib.direct_eligible(1 << 20, 7, AUTO)                 # short sequences stay asynchronous launches
     assert not lib.direct_eligible((1 << 21) + 1, 200, AUTO)         # the boards must fit the L2s
-    assert not lib.direct_eligible(1 << 20, 20, AUTO, extras=True)   # legal / obs / max_exp / normalised reward
+    assert lib.direct_eligible(1 << 20, 20, AUTO, extras=True) and lib.direct_eligible(1 << 20, 20, AUTO | capi.FLAG_OBS_BF16 | capi.FLAG_REWARD_LOG2_F32)
     assert not lib.direct_eligible(1 << 20, 20, AUTO | NO_DIRECT)
     assert not lib.direct_eligible(1 << 20, 20, AUTO | capi.FLAG_STORES_WRITE_THROUGH)
     assert not lib.direct_eligible(1 << 20, 20, AUTO | capi.FLAG_TILE_SMALL) and not lib.direct_eligible(1 << 20, 20, AUTO | capi.FLAG_TILE_LARGE)
@@ -71,7 +71,7 @@ def test_the_plan_of_a_direct_sequence_covers_the_batch_and_the_steps():
 
     check()
     assert lib.direct_plan(1 << 22, 20, AUTO) == {'eligible': False, 'chains': 0, 'parts': [], 'segments': 0, 'segment_steps': 0}
-    assert not lib.direct_plan(1 << 20, 20, AUTO, extras=True)['eligible']
+    assert lib.direct_plan(1 << 20, 20, AUTO, extras=True)['eligible']
 
 
 gpu = pytest.mark.gpu
@@ -165,6 +165,44 @@ def test_direct_route_equals_stream_route(lib, route, n, T, stride_kind, random_
         assert np.array_equal(host_boards.numpy(), ref)
     if after['last_gpu_ns']:
         assert 0.5e3 * T < after['last_gpu_ns'] < 1e9   # a plausible device-side duration (0.5 us per step ... 1 s)
+
+
+@gpu
+@pytest.mark.parametrize('n,T,obs_flag,obs_dtype,normalised', [
+    (5000, 12, 0, torch.float32, False),                       # one chain, ragged
+    ((1 << 18) + 2048 + 3, 9, capi.FLAG_OBS_BF16, torch.bfloat16, False),   # two chains, ragged second half
+    (1 << 20, 8, 0, torch.float32, True),                      # the large tiling, log-normalised float reward rows
+    (1 << 19, 10, capi.FLAG_OBS_F16, torch.float16, False),
+])
+def test_direct_route_with_legal_mask_and_observations(lib, route, n, T, obs_flag, obs_dtype, normalised):
+    """The _extras kernels of the route (legal mask + observation rows written by the same launches, the observation rows
+    write-through so that they do not evict the boards): every row identical to the stream route's."""
+    flags = AUTO | obs_flag | (capi.FLAG_REWARD_LOG2_F32 if normalised else 0)
+    rng = np.random.default_rng(n)
+    start = midgame(lib, n, env_base=5)
+    acts = [torch.from_numpy(rng.integers(0, 4, size=n).astype(np.uint8)).cuda() for _ in range(T)]
+    table = (ctypes.c_void_p * T)(*[a.data_ptr() for a in acts])
+    out = []
+    for extra in (0, NO_DIRECT):
+        b = start.clone()
+        r = torch.zeros((T, n), dtype=torch.float32 if normalised else torch.int32, device='cuda')
+        d = torch.zeros((T, n), dtype=torch.uint8, device='cuda')
+        legal = torch.full((T, n), 77, dtype=torch.uint8, device='cuda')
+        obs = torch.full((T, n, 16), -1.0, dtype=obs_dtype, device='cuda')
+        before = lib.direct_stats(DEV)['calls']
+        lib.step_sequence(DEV, stream(), n, 5, p(b), table, p(r), p(d), p(legal), p(obs), n, SEED, 900, T, flags | extra)
+        assert lib.direct_stats(DEV)['calls'] == before + (1 if extra == 0 else 0)
+        out.append((b, r, d, legal, obs))
+    torch.cuda.synchronize()
+    for x, y in zip(*out):
+        assert torch.equal(x, y)
+    assert lib.direct_stats(DEV)['reruns'] == route['reruns']
+    if n <= 5000:   # ... and the oracle for the small case: legal mask and observation of every step
+        ref = start.cpu().numpy()
+        for t in range(T):
+            want = oracle.step_batch(ref, acts[t].cpu().numpy(), SEED, 900 + t, env_base=5, flags=AUTO, want_legal=True, want_obs=True)
+            ref = want['boards']
+            assert np.array_equal(out[0][3][t].cpu().numpy(), want['legal']) and np.array_equal(out[0][4][t].float().cpu().numpy(), want['obs']), t
 
 
 @gpu

@@ -34,7 +34,7 @@ if '--churn' in sys.argv:
     churn = ctypes.CDLL(str(churn_lib))
     threading.Thread(target=lambda: churn.queue_churn(1_000_000, 700), daemon=True).start()
 t0 = last = time.time()
-counts = {'calls': 0, 'steps': 0, 'board_steps': 0, 'oracle_checked': 0, 'two_chain_calls': 0, 'busy_stream_calls': 0}
+counts = {'extras_calls': 0, 'calls': 0, 'steps': 0, 'board_steps': 0, 'oracle_checked': 0, 'two_chain_calls': 0, 'busy_stream_calls': 0}
 S = lambda: torch.cuda.current_stream().cuda_stream
 P = lambda t: None if t is None else t.data_ptr()
 AUTO, RANDOM, NO_DIRECT = capi.FLAG_AUTO_RESET, capi.FLAG_RANDOM_ACTIONS, capi.FLAG_NO_DIRECT
@@ -70,6 +70,12 @@ while time.time() - t0 < budget:
         stride = 0
     rows = K if stride else 1
     with_reward = rng.random() < 0.85
+    extras = rng.random() < 0.3 and n * K <= 6e7   # legal mask + observation rows (f32 / f16 / bf16), sometimes the normalised reward
+    obs_flag, obs_dtype = [(0, torch.float32), (capi.FLAG_OBS_F16, torch.float16), (capi.FLAG_OBS_BF16, torch.bfloat16)][int(rng.integers(0, 3))]
+    normalised = extras and with_reward and rng.random() < 0.3
+    with_obs = extras and rng.random() < 0.8
+    if extras:
+        flags |= obs_flag | (capi.FLAG_REWARD_LOG2_F32 if normalised else 0)
     shift = int(rng.integers(0, 4))  # board base 16-byte aligned but not line aligned
     start = torch.zeros((n + 8, 16), dtype=torch.uint8, device='cuda')[shift:shift + n]
     lib.reset(0, S(), n, base, P(start), None, seed ^ 5, 0)
@@ -86,18 +92,22 @@ while time.time() - t0 < budget:
     for extra in (0, NO_DIRECT):
         b = torch.zeros((n + 8, 16), dtype=torch.uint8, device='cuda')[shift:shift + n]
         b.copy_(start)
-        r = torch.full((rows, max(stride, n)), -3, dtype=torch.int32, device='cuda') if with_reward else None
+        r = torch.full((rows, max(stride, n)), -3, dtype=torch.float32 if normalised else torch.int32, device='cuda') if with_reward else None
         d = torch.full((rows, max(stride, n)), 7, dtype=torch.uint8, device='cuda')
+        lg = torch.full((rows, max(stride, n)), 9, dtype=torch.uint8, device='cuda') if extras else None
+        ob = torch.full((rows, max(stride, n), 16), -2.0, dtype=obs_dtype, device='cuda') if with_obs else None
         before = lib.direct_stats(0)['calls']
         if busy and extra == 0:
             ballast.fill_(3)  # the caller's stream is busy when the call arrives
-        lib.step_sequence(0, S(), n, base, P(b), table, P(r), P(d), None, None, stride, seed, step0, K, flags | extra)
+        lib.step_sequence(0, S(), n, base, P(b), table, P(r), P(d), P(lg), P(ob), stride, seed, step0, K, flags | extra)
         assert lib.direct_stats(0)['calls'] == before + (1 if extra == 0 else 0), 'route taken'
-        out.append((b, r, d))
+        out.append((b, r, d, lg, ob))
     torch.cuda.synchronize()
-    (b1, r1, d1), (b2, r2, d2) = out
+    (b1, r1, d1, l1, o1), (b2, r2, d2, l2, o2) = out
     assert torch.equal(b1, b2) and torch.equal(d1, d2) and (r1 is None or torch.equal(r1, r2)), ('direct != stream', n, K, flags, stride)
-    if n * K <= 3e6 and acts is not None:
+    assert (l1 is None or torch.equal(l1, l2)) and (o1 is None or (o2 is not None and torch.equal(o1, o2))), ('direct != stream (legal / obs)', n, K, flags, stride)
+    counts['extras_calls'] += int(extras)
+    if n * K <= 3e6 and acts is not None and not extras:
         ref = start.cpu().numpy().copy()
         for t in range(K):
             want = oracle.step_batch(ref, acts[t].cpu().numpy(), seed, step0 + t, env_base=base, flags=flags)
