@@ -191,7 +191,10 @@ class ShardedEnv2048:
         """``count`` dependent steps per shard, each shard's launches enqueued by ONE env2048_step_sequence call from its own
         thread (host cost per launch = hipLaunchKernel itself, in parallel over the devices).  ``actions``: None (random) or a
         list over shards of (count, n_g) uint8 tensors (ordered behind their producer stream, see ``_handover``) or of ctypes
-        tables of ``count`` device pointers (raw pointers: the caller keeps that memory alive and ready)."""
+        tables of ``count`` device pointers (raw pointers: the caller keeps that memory alive and ready).
+        (From 8 steps and up to 2^21 boards per shard the call takes the library's direct route on every device -- its own
+        queues, boards resident in the XCD L2s -- and each shard's thread returns when its sequence has COMPLETED: include/env2048.h,
+        env2048_step_sequence.)"""
         events = self._handover(actions) if actions is not None else None
 
         def run(g):
