@@ -227,7 +227,7 @@ ENV2048_EXPORT int env2048_step_sequence_plan(uint64_t n, uint32_t count, uint32
  * batches beyond the Infinity Cache lose, hence the bounds).  Results are bit-identical.  env2048_step_sequence_plan reports
  * the decision.
  *
- * The direct route.  A sequence of count >= 8 steps (ENV2048_DIRECT_MIN_STEPS) over n <= 2^21 boards (with none of NO_DIRECT,
+ * The direct route.  A sequence of count >= 8 steps (ENV2048_DIRECT_MIN_STEPS) over n <= 1.5 x 2^20 boards (with none of NO_DIRECT,
  * STORES_WRITE_THROUGH, TILE_* among its flags; any outputs), on a stream that is not being captured, does not go
  * through the HIP runtime at all: the library writes the `count` kernel-dispatch packets of each chain (two half-batch chains
  * from 2^18 boards, else one) into user-mode queues of its own -- created on a device's first such call together with a second

@@ -74,7 +74,8 @@ constexpr uint32_t SEGMENT_STEPS = 256;               // argument blocks are wri
 constexpr uint32_t RING_SEGMENTS = 4;                 // ... into a ring of this many segments per chain
 constexpr size_t BLOCK_STRIDE = 128;                  // bytes per argument block (the kernel reads 120)
 constexpr uint32_t MAX_BLOCKS_PER_PART = 2048;        // workgroups of one launch (2^21 boards as ONE small-tiling part would be 4096: never planned)
-constexpr uint64_t RESIDENT_MAX_BOARDS = 1ull << 21;  // 16 B x 2^21 / 8 XCDs = the 4 MiB of one L2 (2^21: 11.4-11.8 us against 13.1-13.5 through HIP)
+constexpr uint64_t RESIDENT_MAX_BOARDS = 3ull << 19;  // 1.5 x 2^20: boards + output rows must fit the eight 4 MiB L2s -- direct / stream us per step at
+                                                      // 2^20: 5.8 / 7.4, 1.25 x 2^20: 8.3 / 9.0, 1.5 x: 8.8 / 9.7, 1.75 x: 12.0 / 11.1, 2^21: 12.9 / 12.2 (profiles/r05_z_*)
 constexpr uint64_t TWO_CHAINS_MIN_BOARDS = 1ull << 18;  // below: one chain (65 536 boards: 2.43 vs 2.41 us; 2^18: 3.3 vs 2.6)
 constexpr uint32_t DEFAULT_MIN_STEPS = 8;             // shorter sequences stay asynchronous launches on the caller's stream
 
@@ -383,10 +384,19 @@ inline uint32_t min_steps()
 
 // Is this call one for the direct route?  (pure: sizes and flags only -- env2048_direct_plan reports it; every output
 // env2048_step_sequence can ask for is served: reward / done, and legal / obs / the normalised reward by the _extras kernels)
+inline uint64_t max_boards()
+{
+    static const uint64_t v = [] {  // (ENV2048_EXP_DIRECT_MAX_LOG2: experiment switch, up to 2^23: profiles/r05_z_*)
+        const char *e = getenv("ENV2048_EXP_DIRECT_MAX_LOG2");
+        const long parsed = e ? atol(e) : 0;
+        return parsed >= 10 && parsed <= 23 ? 1ull << parsed : RESIDENT_MAX_BOARDS;
+    }();
+    return v;
+}
 inline bool eligible(uint64_t n, uint32_t count, uint32_t flags)
 {
     return !(flags & (ENV2048_FLAG_NO_DIRECT | ENV2048_FLAG_STORES_WRITE_THROUGH | ENV2048_FLAG_TILE_SMALL | ENV2048_FLAG_TILE_LARGE)) && n > 0 &&
-           n <= RESIDENT_MAX_BOARDS && count >= min_steps();
+           n <= max_boards() && count >= min_steps();
 }
 inline int chains_for(uint64_t n) { return n >= TWO_CHAINS_MIN_BOARDS ? CHAINS : 1; }
 

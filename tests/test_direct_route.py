@@ -22,11 +22,11 @@ AUTO, RANDOM, NO_DIRECT = capi.FLAG_AUTO_RESET, capi.FLAG_RANDOM_ACTIONS, capi.F
 
 
 def test_eligibility_is_a_function_of_sizes_and_flags():
-    """(no device) what is offered to the route: >= 8 steps, <= 2^21 boards, any outputs, no hint that contradicts it."""
+    """(no device) what is offered to the route: >= 8 steps, <= 1.5 x 2^20 boards, any outputs, no hint that contradicts it."""
     lib = capi.Library()
-    assert lib.direct_eligible(1 << 20, 20, AUTO) and lib.direct_eligible(1 << 16, 8, AUTO | RANDOM) and lib.direct_eligible(1 << 21, 200, 0)
+    assert lib.direct_eligible(1 << 20, 20, AUTO) and lib.direct_eligible(1 << 16, 8, AUTO | RANDOM) and lib.direct_eligible(3 << 19, 200, 0)
     assert not lib.direct_eligible(1 << 20, 7, AUTO)                 # short sequences stay asynchronous launches
-    assert not lib.direct_eligible((1 << 21) + 1, 200, AUTO)         # the boards must fit the L2s
+    assert not lib.direct_eligible((3 << 19) + 1, 200, AUTO)         # boards + output rows must fit the L2s
     assert lib.direct_eligible(1 << 20, 20, AUTO, extras=True) and lib.direct_eligible(1 << 20, 20, AUTO | capi.FLAG_OBS_BF16 | capi.FLAG_REWARD_LOG2_F32)
     assert not lib.direct_eligible(1 << 20, 20, AUTO | NO_DIRECT)
     assert not lib.direct_eligible(1 << 20, 20, AUTO | capi.FLAG_STORES_WRITE_THROUGH)
@@ -47,8 +47,8 @@ def test_the_plan_of_a_direct_sequence_covers_the_batch_and_the_steps():
     from hypothesis import strategies as st
 
     lib = capi.Library()
-    sizes = st.one_of(st.integers(1, 5000), st.integers((1 << 18) - 3000, (1 << 18) + 3000), st.integers(1 << 18, 1 << 21),
-                      st.sampled_from([1, 511, 512, 513, 2048, 65536, 1 << 18, 1 << 19, (1 << 19) + 1, 1 << 20, (1 << 21) - 1, 1 << 21]))
+    sizes = st.one_of(st.integers(1, 5000), st.integers((1 << 18) - 3000, (1 << 18) + 3000), st.integers(1 << 18, 3 << 19),
+                      st.sampled_from([1, 511, 512, 513, 2048, 65536, 1 << 18, 1 << 19, (1 << 19) + 1, 1 << 20, (3 << 19) - 1, 3 << 19]))
 
     @settings(max_examples=400, deadline=None)
     @given(n=sizes, count=st.integers(8, 5000), random_actions=st.booleans())
@@ -130,7 +130,7 @@ def run(lib, start, T, flags, env_base, stride, acts, with_reward=True, step0=50
     (1 << 20, 20, 'overwrite', False, True),   # the headline shape: two chains, large tiling
     (1 << 20, 12, 'rows', True, True),         # moves drawn in the kernel
     ((1 << 20) + 2048 + 77, 9, 'padded', False, False),  # ragged large tiling, padded rows, no auto-reset
-    (1 << 21, 8, 'overwrite', False, True),    # the largest batch the route takes
+    (3 << 19, 8, 'overwrite', False, True),    # the largest batch the route takes
 ])
 def test_direct_route_equals_stream_route(lib, route, n, T, stride_kind, random_actions, auto):
     flags = (AUTO if auto else 0) | (RANDOM if random_actions else 0)

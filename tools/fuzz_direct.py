@@ -1,5 +1,5 @@
 """Randomised differential run of the direct route of env2048_step_sequence (csrc/direct_dispatch.hpp) on the GPU box: random batch
-sizes (1 ... 2^21, ragged ends, both tilings, one and two chains), sequence lengths 8 ... 700 (several argument-ring segments),
+sizes (1 ... 1.5 x 2^20 and just beyond, ragged ends, both tilings, one and two chains), sequence lengths 8 ... 700 (several argument-ring segments),
 host action rows or in-kernel moves, auto-reset on / off, outputs in place / one row per step / padded rows, reward present or
 NULL, misaligned-by-16 board bases, busy caller streams -- every call compared with the same call on the stream route
 (ENV2048_FLAG_NO_DIRECT) byte for byte, small ones also with the oracle step by step.
@@ -52,7 +52,7 @@ def pick_n():
     if kind == 3:
         return int(rng.integers(1 << 19, (1 << 20) + 5000))  # two chains, large tiling
     if kind == 4:
-        return int(rng.choice([1 << 20, (1 << 20) + 2048, (1 << 21) - 1, 1 << 21]))
+        return int(rng.choice([1 << 20, (1 << 20) + 2048, (3 << 19) - 1, 3 << 19, (3 << 19) + 1]))
     return int(rng.integers(5000, 1 << 18))
 
 
@@ -100,7 +100,7 @@ while time.time() - t0 < budget:
         if busy and extra == 0:
             ballast.fill_(3)  # the caller's stream is busy when the call arrives
         lib.step_sequence(0, S(), n, base, P(b), table, P(r), P(d), P(lg), P(ob), stride, seed, step0, K, flags | extra)
-        assert lib.direct_stats(0)['calls'] == before + (1 if extra == 0 else 0), 'route taken'
+        assert lib.direct_stats(0)['calls'] == before + (1 if extra == 0 and lib.direct_eligible(n, K, flags) else 0), 'route taken'
         out.append((b, r, d, lg, ob))
     torch.cuda.synchronize()
     (b1, r1, d1, l1, o1), (b2, r2, d2, l2, o2) = out
