@@ -87,7 +87,11 @@ def lib():
 @pytest.fixture(scope='module')
 def route(lib):
     info = lib.direct_stats(DEV)
-    if not info['available'] and any(s in info['reason'] for s in ('not host-visible', 'disabled by ENV2048_DIRECT')):
+    # what the BOX can deny (no large BAR, a device that is not an 8-XCD gfx950, ROCr not reachable, the switch in the environment) skips;
+    # what only this build can get wrong (the embedded code object, its kernels, their argument layout) fails
+    environmental = ('not host-visible', 'disabled by ENV2048_DIRECT', 'no ROCr agent', 'memory pools not found', 'host-visible device memory',
+                     'hsa_init', 'XCDs', 'the code object is gfx950', 'hsa_queue_create', 'pinned host word')
+    if not info['available'] and any(s in info['reason'] for s in environmental):
         pytest.skip('direct route unavailable on this box: ' + info['reason'])
     assert info['available'], 'the direct route did not start on this MI355X: ' + info['reason']
     return info
