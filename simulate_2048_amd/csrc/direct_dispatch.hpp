@@ -458,6 +458,7 @@ inline int step_sequence(int device, hipStream_t stream, const SequenceArgs &a)
     static const bool timeline = getenv("ENV2048_DIRECT_DEBUG") != nullptr;  // (diagnostic: where the host's microseconds go)
     const double t_enter = timeline ? now_us() : 0.0;
     double t_stream = 0.0, t_first_packets = 0.0, t_all_packets = 0.0;
+    uint64_t ticks_first_packets = 0, ticks_complete = 0;
     hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
     if (stream && (hipStreamIsCapturing(stream, &capture) != hipSuccess || capture != hipStreamCaptureStatusNone)) {
         (void)hipGetLastError();
@@ -578,7 +579,10 @@ inline int step_sequence(int device, hipStream_t stream, const SequenceArgs &a)
                             packet_header(first_packet, last_packet), completion);
             }
         }
-        if (timeline && first_segment) t_first_packets = now_us();
+        if (timeline && first_segment) {
+            t_first_packets = now_us();
+            hsa_system_get_info(HSA_SYSTEM_INFO_TIMESTAMP, &ticks_first_packets);
+        }
         for (int c = 0; c < chains; ++c) d->next_block[c] += SEGMENT_STEPS;  // (a segment always occupies one whole part of the ring)
         d->packets += (uint64_t)steps * chains;
     }
@@ -595,6 +599,7 @@ inline int step_sequence(int device, hipStream_t stream, const SequenceArgs &a)
         set_reason(d, "a direct sequence did not complete in time: route switched off", HSA_STATUS_SUCCESS);
         return fail(ENV2048_ERR_DEVICE, "env2048_step_sequence: the direct-dispatch sequence did not complete (route switched off for this device)");
     }
+    if (timeline) hsa_system_get_info(HSA_SYSTEM_INFO_TIMESTAMP, &ticks_complete);
     if (timeline)
         fprintf(stderr, "[direct] K = %u: stream idle after %.2f us, first packets out after %.2f, all packets after %.2f, complete after %.2f\n", a.count,
                 t_stream - t_enter, t_first_packets - t_enter, t_all_packets - t_enter, now_us() - t_enter);
@@ -608,9 +613,9 @@ inline int step_sequence(int device, hipStream_t stream, const SequenceArgs &a)
             const hsa_status_t s0 = first_start[c] ? HSA_STATUS_SUCCESS : HSA_STATUS_ERROR;
             const hsa_status_t s1 = hsa_amd_profiling_get_dispatch_time(d->gpu, last_signal_used[c], &t1);
             if (debug)
-                fprintf(stderr, "[direct] chain %d: first packet %llu .. %llu (status %d), last packet %llu .. %llu (status %d), %llu ticks/s\n", c,
-                        (unsigned long long)t0.start, (unsigned long long)t0.end, (int)s0, (unsigned long long)t1.start, (unsigned long long)t1.end, (int)s1,
-                        (unsigned long long)d->timestamp_hz);
+                fprintf(stderr, "[direct] chain %d: first kernel starts %.2f us after its doorbell, the host sees completion %.2f us after the last kernel ended\n", c,
+                        ((double)t0.start - (double)ticks_first_packets) * 1e6 / (double)d->timestamp_hz,
+                        ((double)ticks_complete - (double)t1.end) * 1e6 / (double)d->timestamp_hz);
             if (s0 == HSA_STATUS_SUCCESS && s1 == HSA_STATUS_SUCCESS && t0.start != 0 && t1.end > t0.start && t1.end - t0.start < d->timestamp_hz * 3600ull)
                 longest = t1.end - t0.start > longest ? t1.end - t0.start : longest;
         }
