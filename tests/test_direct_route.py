@@ -264,8 +264,9 @@ def test_the_call_is_ordered_behind_the_stream_and_complete_on_return(lib, route
     lib.step_sequence(DEV, stream(), n, 0, p(b), table, p(r), p(d), None, None, 0, SEED, 43, T, AUTO)
     assert lib.direct_stats(DEV)['calls'] == calls + 1
     side = torch.cuda.Stream()
-    with torch.cuda.stream(side):   # another stream, no event between: the results are in memory already
+    with torch.cuda.stream(side):   # another stream, no event between the call and this copy: the results are in memory already
         seen_by_side = b.clone()
+    side.synchronize()              # (the copy is done before the next launch on the main stream rewrites `b`)
     lib.step(DEV, stream(), n, 0, p(b), p(acts[0]), p(r), p(d), None, None, SEED, 43 + T, AUTO)
     torch.cuda.synchronize()
     assert torch.equal(b, ref) and torch.equal(r, rr) and torch.equal(d, dd)
